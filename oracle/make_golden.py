@@ -1,0 +1,314 @@
+#!/usr/bin/env python3
+"""Generate tests/golden/*.pt by running the REAL reference modules on CPU.
+
+Runs only in the build container (needs /root/reference).  The reference is imported
+read-only; nothing of it is copied into this repository — the fixtures hold seeded
+inputs and the reference's outputs only.  TEST INFRASTRUCTURE (see oracle/__init__.py).
+
+Import recipe: the package ``__init__`` files pull in OpenEXR / torchvision /
+torchmetrics, which are not installed, so synthetic parent packages with the right
+``__path__`` are registered and empty stand-in modules are provided for the three
+missing third-party imports (none of their functionality is used by the hot path;
+PSNR is replaced by oracle.losses.psnr and SSIM by a constant, both outside the
+pinned quantities).
+
+    python oracle/make_golden.py            # writes tests/golden/
+"""
+
+from __future__ import annotations
+
+import importlib
+import os
+import shutil
+import sys
+import types
+
+import torch
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, REPO)
+REF = os.environ.get("LHG_REFERENCE", "/root/reference")
+OUT = os.path.join(REPO, "tests", "golden")
+
+from oracle import losses as o_losses  # noqa: E402
+from oracle import seeded  # noqa: E402
+
+
+def import_reference():
+    pk = types.ModuleType("learnedMethodForHologram")
+    pk.__path__ = [REF + "/learnedMethodForHologram"]
+    sys.modules["learnedMethodForHologram"] = pk
+    wk = types.ModuleType("learnedMethodForHologram.watermelon_hologram")
+    wk.__path__ = [REF + "/learnedMethodForHologram/watermelon_hologram"]
+    sys.modules["learnedMethodForHologram.watermelon_hologram"] = wk
+    for n in ("torchvision", "torchvision.transforms", "torchvision.models", "torchmetrics", "torchmetrics.image"):
+        sys.modules[n] = types.ModuleType(n)
+    sys.modules["torchvision"].transforms = sys.modules["torchvision.transforms"]
+    sys.modules["torchvision"].models = sys.modules["torchvision.models"]
+    sys.modules["torchvision.models"].VGG19_Weights = None
+
+    class _Metric:
+        def __init__(self, fn):
+            self.fn = fn
+
+        def to(self, _):
+            return self
+
+        def __call__(self, a, b):
+            return self.fn(a, b)
+
+    tm = sys.modules["torchmetrics.image"]
+    tm.PeakSignalNoiseRatio = lambda: _Metric(o_losses.psnr)
+    tm.StructuralSimilarityIndexMeasure = lambda: _Metric(lambda a, b: torch.zeros(()))
+    sys.modules["torchmetrics"].image = tm
+
+    m = lambda name: importlib.import_module("learnedMethodForHologram." + name)  # noqa: E731
+    return types.SimpleNamespace(
+        asm=m("angular_spectrum_method"),
+        nn=m("neural_network_components"),
+        util=m("utilities"),
+        generator=m("watermelon_hologram.generator"),
+        discriminator=m("watermelon_hologram.discriminator"),
+        loss=m("watermelon_hologram.loss_func"),
+        watermelon=m("watermelon_hologram.watermelon"),
+    )
+
+
+WL = torch.tensor([638e-9, 520e-9, 450e-9])
+PITCH = 3.74e-6
+STACK20 = torch.linspace(-4e-4, 0.0, 21)[:-1]  # ref: trainingModel.py:62
+
+
+def save(name, obj):
+    path = os.path.join(OUT, name)
+    torch.save(obj, path)
+    print(f"  wrote {name}: {os.path.getsize(path)/1024:.1f} KiB")
+
+
+def golden_constants(R):
+    out = {}
+    for tag, (r0, c0, pad, coef) in {"sq48": (48, 48, 8, 0.45), "rect32x48": (32, 48, 8, 0.35)}.items():
+        fx = R.asm.bandLimitedAngularSpectrumMethod_for_single_fixed_distance(
+            r0, c0, pad, coef, PITCH, WL, False, False, torch.tensor([1e-3]))
+        mu = R.asm.bandLimitedAngularSpectrumMethod_for_multiple_distances(
+            r0, c0, STACK20[:4], pad, coef, PITCH, WL, False, False)
+        out[tag] = dict(args=(r0, c0, pad, coef), shape=(fx.samplingRowNum, fx.samplingColNum),
+                        w=fx.w_grid, mask=fx.diffraction_limited_mask, H_fixed=fx.H, H_stack=mu.H,
+                        distances=STACK20[:4].clone())
+    # production size 384 + 2*320 = 1024: strided sub-samples + reductions
+    fx = R.asm.bandLimitedAngularSpectrumMethod_for_single_fixed_distance(
+        384, 384, 320, 0.45, PITCH, WL, False, False, torch.tensor([1e-3]))
+    mu = R.asm.bandLimitedAngularSpectrumMethod_for_multiple_distances(
+        384, 384, STACK20, 320, 0.45, PITCH, WL, False, False)
+    sl = (slice(None), slice(None, None, 127), slice(None, None, 131))
+    out["full1024"] = dict(
+        args=(384, 384, 320, 0.45), w_sub=fx.w_grid[sl].clone(), H_fixed_sub=fx.H[sl].clone(),
+        H_stack_sub=mu.H[:, :, ::127, ::131].clone(), mask_rowsum=fx.diffraction_limited_mask.sum(1),
+        H_fixed_sum=fx.H.sum(dim=(1, 2)), w_sum=fx.w_grid.double().sum(dim=(1, 2)))
+    try:
+        R.util.generate_circular_frequency_mask(64, 64, 64 * 0.6)
+        out["mask_raises"] = False
+    except ValueError:
+        out["mask_raises"] = True
+    save("constants.pt", out)
+
+
+def golden_asm(R):
+    r0 = c0 = 48
+    pad, coef = 8, 0.45
+    fx = R.asm.bandLimitedAngularSpectrumMethod_for_single_fixed_distance(
+        r0, c0, pad, coef, PITCH, WL, False, False, torch.tensor([1e-3]))
+    mu = R.asm.bandLimitedAngularSpectrumMethod_for_multiple_distances(
+        r0, c0, STACK20[:5], pad, coef, PITCH, WL, False, False)
+    g = torch.Generator().manual_seed(11)
+    amp = torch.rand((2, 3, r0, c0), generator=g) + 0.1
+    phs = torch.rand((2, 3, r0, c0), generator=g) * 6.2
+    poh = (torch.rand((2, 3, r0, c0), generator=g) - 0.5) * 9.0
+    tamp = torch.rand((2, 3, r0, c0), generator=g)
+    tphs = torch.rand((2, 3, r0, c0), generator=g)
+    out = dict(args=(r0, c0, pad, coef), amp=amp, phs=phs, poh=poh, tamp=tamp, tphs=tphs, stack=STACK20[:5].clone())
+    out["A5_field"] = fx.propagate_AP2C_backward(amp, phs)
+    out["A8_spectrum"] = fx.propagate_POH2Freq_forward(poh)
+    out["A8_amp"], out["A8_phs"] = fx.propagate_POH2AP_forward(poh)
+    out["A9_target_spectrum"] = mu.filter_AP2filteredFreq(tamp, tphs)
+    G = torch.cat((out["A8_spectrum"], out["A9_target_spectrum"]), 0)
+    torch.manual_seed(2024)
+    out["A9_indices"] = torch.randperm(5)[0:2]
+    torch.manual_seed(2024)
+    out["A9_idx_amp"], out["A9_idx_phs"] = mu.propagate_multiple_samples_with_random_fixed_multiple_distances_freq2amp(G)
+    out["A9_all_amp"], out["A9_all_phs"] = mu.propagate_multiple_samples_with_all_fixed_multiple_distances_freq2amp(G)
+    d_call = torch.linspace(4e-4, 10e-4, 3)
+    out["call_distances"] = d_call
+    out["call_amp"] = mu(torch.ones_like(poh), poh, d_call)
+    out["call_norm01"] = R.util.tensor_normalizor_2D(out["call_amp"])
+    save("asm_small.pt", out)
+
+
+def golden_unet_generator(R):
+    sd = seeded.generator_state_dict()
+    rows = cols = 32
+    pad = 16
+    torch.manual_seed(0)
+    G = R.generator.Generator(rows, cols, pad, 0.45, 3, PITCH, WL, torch.tensor([1e-3]))
+    missing = G.load_state_dict(sd, strict=True)
+    print("  generator load_state_dict(strict=True):", missing)
+    n_par = sum(p.numel() for p in G.parameters())
+    rgbd, _, _ = seeded.smooth_batch(2, rows, cols, seed=5)
+    out = dict(args=(rows, cols, pad, 0.45), rgbd=rgbd, n_params=n_par, n_keys=len(G.state_dict()),
+               key_shapes={k: tuple(v.shape) for k, v in G.state_dict().items()})
+    unet = G.part1.part1
+    G.eval()
+    with torch.no_grad():
+        out["unet_eval"] = unet(rgbd)
+        out["poh_eval"] = G(rgbd)
+    G.train()
+    x = rgbd.clone().requires_grad_(True)
+    y = unet(x)
+    proj = torch.randn(y.shape, generator=torch.Generator().manual_seed(3))
+    (y * proj).sum().backward()
+    out["unet_train"] = y.detach()
+    out["unet_proj"] = proj
+    out["unet_train_dx"] = x.grad.clone()
+    named = dict(G.named_parameters())
+    grads = {}
+    for k in ("part1.part1.encoder1.0.0.convolution_layer_1.weight", "part1.part1.encoder1.0.0.batch_norm_layer_1.weight",
+              "part1.part1.bottleneck.1.0.convolution_layer_2.bias", "part1.part1.bottleneck.2.weight",
+              "part1.part1.decoder4.0.convolution_layer_3.weight", "part1.part1.final_layer.0.weight",
+              "part1.part1.decoder2.0.0.batch_norm_layer_2.bias"):
+        gk = named[k].grad
+        grads[k] = dict(norm=gk.norm().item(), head=gk.flatten()[:64].clone())
+    out["unet_train_param_grads"] = grads
+    bn = G.state_dict()
+    out["bn_after_one_train_fwd"] = {k: bn[k].clone() for k in bn if k.startswith("part1.part1.decoder4.0.batch_norm_layer_2.")
+                                     or k.startswith("part1.part1.bottleneck.1.0.batch_norm_layer_1.")}
+    # full generator, train mode (second training forward: BN stats have moved once already)
+    G.load_state_dict(sd, strict=True)
+    G.train()
+    G.zero_grad()
+    x = rgbd.clone().requires_grad_(True)
+    poh = G(x)
+    projp = torch.randn(poh.shape, generator=torch.Generator().manual_seed(4))
+    # a smooth functional of POH that is invariant to 2*pi wraps
+    (torch.cos(poh) * projp).sum().backward()
+    out["poh_train"] = poh.detach()
+    out["poh_proj"] = projp
+    out["poh_train_dx"] = x.grad.clone()
+    named = dict(G.named_parameters())
+    out["poh_train_param_grads"] = {
+        k: dict(norm=named[k].grad.norm().item(), full=named[k].grad.clone())
+        for k in ("part2.part1.conv_r.params", "part2.part1.conv_g.bias", "part2.part1.conv_b.params",
+                  "part1.part1.final_layer.0.bias")}
+    save("generator_small.pt", out)
+
+
+def golden_critic(R):
+    sd = seeded.critic_state_dict()
+    D = R.discriminator.WGANGPDiscriminator192(None, 32, False)
+    print("  critic load_state_dict(strict=True):", D.load_state_dict(sd, strict=True))
+    g = torch.Generator().manual_seed(21)
+    real = torch.rand((2, 3, 32, 32), generator=g)
+    fake = torch.rand((2, 3, 32, 32), generator=g)
+    out = dict(real=real, fake=fake, n_params=sum(p.numel() for p in D.parameters()), n_keys=len(D.state_dict()),
+               key_shapes={k: tuple(v.shape) for k, v in D.state_dict().items()})
+    D.eval()
+    with torch.no_grad():
+        out["score_eval"] = D(real)
+    D.train()
+    ns = types.SimpleNamespace(discriminator=D, device=torch.device("cpu"))
+    torch.manual_seed(77)
+    out["alpha"] = torch.rand(2, 1, 1, 1)
+    # one critic iteration exactly as watermelon.py:244-256
+    real_v = D(real)
+    fake_v = D(fake)
+    torch.manual_seed(77)
+    gp = R.watermelon.watermelon.compute_gradient_penalty(ns, real, fake)
+    d_loss = (-torch.mean(real_v) + torch.mean(fake_v)) + 10 * gp
+    D.zero_grad()
+    d_loss.backward()
+    out.update(score_real_train=real_v.detach(), score_fake_train=fake_v.detach(), gp=gp.item(), d_loss=d_loss.item())
+    out["param_grads"] = {k: dict(norm=p.grad.norm().item(), head=p.grad.flatten()[:64].clone()) for k, p in D.named_parameters()}
+    out["bn_after"] = {k: v.clone() for k, v in D.state_dict().items() if k.startswith("block4.1.")}
+    save("critic_small.pt", out)
+
+
+def golden_losses(R):
+    g = torch.Generator().manual_seed(31)
+    hp = (torch.rand((2, 3, 24, 20), generator=g) * 6.28).requires_grad_(True)
+    tp = torch.rand((2, 3, 24, 20), generator=g) * 6.28
+    ha = torch.rand((2, 3, 24, 20), generator=g).requires_grad_(True)
+    ta = torch.rand((2, 3, 24, 20), generator=g)
+    focal = R.loss.focal_sincos_phase_gradient_loss(hp, tp)
+    tv = R.loss.total_variation_loss(ha, ta)
+    mse = torch.nn.functional.mse_loss(ha, ta)
+    (focal + 3 * tv + 5 * mse).backward()
+    save("losses_small.pt", dict(hat_phs=hp.detach(), tgt_phs=tp, hat_amp=ha.detach(), tgt_amp=ta, focal=focal.item(),
+                                 tv_loss=tv.item(), tv_hat=R.loss.total_variation(ha).item(), mse=mse.item(),
+                                 d_hat_phs=hp.grad.clone(), d_hat_amp=ha.grad.clone()))
+
+
+def golden_step(R):
+    """Run the reference's own training loop (watermelon.train, watermelon.py:92-416) for one
+    batch on an object assembled without ``__init__`` (which needs VGG19 weights + cuda)."""
+    rows = cols = 32
+    pad, coef, ratio = 16, 0.45, 2
+    stack = STACK20[:6]
+    sdG, sdD = seeded.generator_state_dict(), seeded.critic_state_dict()
+    torch.manual_seed(0)
+    W = object.__new__(R.watermelon.watermelon)
+    W.device = torch.device("cpu")
+    W.distance_stack, W.distance_num = stack, stack.size(0)
+    W.generator = R.generator.Generator(rows, cols, pad, coef, 3, PITCH, WL, torch.tensor([1e-3]))
+    W.generator.load_state_dict(sdG, strict=True)
+    W.discriminator = R.discriminator.WGANGPDiscriminator192(None, 32, False)
+    W.discriminator.load_state_dict(sdD, strict=True)
+    W.perceptual_loss = lambda a, b: torch.zeros(())  # VGG19 term: SURVEY §8f N1
+    W.propagator = R.asm.bandLimitedAngularSpectrumMethod_for_multiple_distances(
+        rows, cols, stack, pad, coef, PITCH, WL, False, False)
+    rgbd, tamp, tphs = seeded.smooth_batch(2, rows, cols, seed=9)
+    seed = 4242
+    torch.manual_seed(seed)
+    idx = torch.randperm(stack.size(0))[0:2]
+    alphas = [torch.rand(2, 1, 1, 1) for _ in range(ratio)]
+    torch.manual_seed(seed)
+    W.train([(rgbd, tamp, tphs)], [], phs_gradient_loss_weight=1, perceptual_loss_weight=0.0, pixel_loss_weight=1,
+            TV_loss_weight=1e-3, discriminator_loss_weight=1e-1, epoch_num=1, lr_G=1e-3, lr_D=1e-3,
+            save_path_G=None, save_path_D=None, info_print_interval=10**9, info_plot_interval=10**9,
+            loss_metrics_file=None, save_path_img=None, checkpoint_iterval=10**9,
+            discriminator_train_ratio=ratio, discriminator_lambda=10)
+    names = ("focal_phase_gradient_loss", "perceptual_loss", "pixel_loss", "TV_loss", "gan_loss", "G_loss", "D_loss")
+    out = dict(args=(rows, cols, pad, coef), ratio=ratio, stack=stack.clone(), rgbd=rgbd, tamp=tamp, tphs=tphs,
+               indices=idx, alphas=alphas, losses=dict(zip(names, W.train_losses_tensor.tolist())),
+               psnr=W.train_metrics_tensor[0].item())
+    post_G, post_D = W.generator.state_dict(), W.discriminator.state_dict()
+    out["post_G"] = {k: dict(sum=v.double().sum().item(), norm=v.double().norm().item(),
+                             delta=(v.double() - sdG[k].double()).norm().item()) for k, v in post_G.items()}
+    out["post_D"] = {k: dict(sum=v.double().sum().item(), norm=v.double().norm().item(),
+                             delta=(v.double() - sdD[k].double()).norm().item()) for k, v in post_D.items()}
+    out["post_G_small"] = {k: v.clone() for k, v in post_G.items() if k.startswith("part2.") or "final_layer" in k}
+    out["post_D_small"] = {k: v.clone() for k, v in post_D.items() if k.startswith("block1.") or k == "conv.bias"}
+    save("step_small.pt", out)
+
+
+def copy_known_answer():
+    """The reference's only result-pinning artefact: data files, copied as data."""
+    src = os.path.join(REF, "output", "test_output", "terminalTest")
+    dst = os.path.join(OUT, "kat_terminalTest")
+    os.makedirs(dst, exist_ok=True)
+    for f in sorted(os.listdir(src)):
+        shutil.copyfile(os.path.join(src, f), os.path.join(dst, f))
+        os.chmod(os.path.join(dst, f), 0o644)
+    print("  copied", sorted(os.listdir(dst)))
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    torch.set_num_threads(max(1, (os.cpu_count() or 2) // 2))
+    R = import_reference()
+    for fn in (golden_constants, golden_asm, golden_losses, golden_critic, golden_unet_generator, golden_step):
+        print(fn.__name__)
+        fn(R)
+    copy_known_answer()
+
+
+if __name__ == "__main__":
+    main()
