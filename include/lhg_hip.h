@@ -1,0 +1,203 @@
+/*
+ * lhg_hip.h — C ABI of liblhg_hip.so, the MI355X (gfx950) implementation of the
+ * RGBD -> phase-only-hologram hot path of WeijieXie/learned_hologram_gan.
+ *
+ * The reference has no FFI layer: its boundary is "Python module -> ATen op"
+ * (SURVEY.md §8b).  Each entry point below therefore replaces one ATen call site of
+ * the reference (cited as ref: <file>:<line> into the reference tree) and is what a
+ * ctypes / cffi binding on the reference side would bind.
+ *
+ * Conventions
+ *   - plain C: raw DEVICE pointers, ints, floats and a hipStream_t (passed as void*);
+ *     no torch types.  The library never allocates, frees or synchronises: every
+ *     workspace is passed in, every launch goes to `stream` (graph-capture safe).
+ *   - activations are NHWC fp32.  A tensor is (ptr, N, H, W, C, ld) where ld >= C is
+ *     the distance in floats between consecutive pixels, so a channel slice of a
+ *     wider buffer (concat-free UNet skips) is addressable.  C must be a multiple of
+ *     32 for GEMM inputs (producers zero-pad: lhg_nchw_to_nhwc).
+ *   - optical fields are planar (B,3,rows,cols) fp32 / interleaved complex64, exactly
+ *     the reference's NCHW tensors.
+ *   - return value: 0 = ok, otherwise an LHG_E_* code; lhg_last_error() gives the text.
+ */
+#ifndef LHG_HIP_H
+#define LHG_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LHG_ABI_VERSION 1
+
+enum {
+  LHG_OK = 0,
+  LHG_E_ARG = 1,      /* bad shape / alignment / unsupported size */
+  LHG_E_LAUNCH = 2,   /* hipGetLastError() != hipSuccess after a launch */
+  LHG_E_WORKSPACE = 3 /* workspace too small */
+};
+
+enum { LHG_ACT_NONE = 0, LHG_ACT_RELU = 1, LHG_ACT_LEAKY = 2, LHG_ACT_SIGMOID = 3 };
+
+typedef void* lhg_stream_t; /* hipStream_t */
+
+int lhg_abi_version(void);
+const char* lhg_last_error(void);
+
+/* ------------------------------------------------------------------ layout */
+/* NCHW (planar) -> NHWC with `ld` floats per pixel; channels C..ld-1 are zero-filled.
+ * Entry of the UNet / critic (ref: neural_network_components.py:303, discriminator.py:44). */
+int lhg_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, int ld, lhg_stream_t s);
+/* NHWC (first C of ld channels) -> NCHW.  Adjoint of the above. */
+int lhg_nhwc_to_nchw(const float* src, int ld, float* dst, int N, int C, int H, int W, lhg_stream_t s);
+
+/* Pack a PyTorch 4-D weight w[D0][D1][KH][KW] into GEMM panels dst[KH*KW][rows_pad][k_pad],
+ * K contiguous, zero padded.  rows_from_d0 = 1: rows = D0, K = D1 (Conv2d forward,
+ * ConvTranspose2d dgrad);  0: rows = D1, K = D0 (Conv2d dgrad, ConvTranspose2d forward).
+ * ref: F.conv2d / nn.LazyConv2d weights (OIHW) neural_network_components.py:9-19,
+ *      nn.LazyConvTranspose2d weights (IOHW) :270-286. */
+int lhg_pack_weight(const float* w, int D0, int D1, int KH, int KW, int rows_from_d0,
+                    float* dst, int rows_pad, int k_pad, lhg_stream_t s);
+
+/* ------------------------------------------------------------------ convolution family
+ * One implicit-GEMM engine (MFMA v_mfma_f32_32x32x2_f32, LDS-tiled, no im2col buffer).
+ * `wp` is a packed panel set from lhg_pack_weight.  Epilogue, in this order:
+ *   v = acc + bias[c];  v = v*scale[c] + shift[c];  v += res[pixel][c];  v = act(v)
+ * (each pointer may be NULL).  planar_out != 0 stores NCHW instead of NHWC.            */
+
+/* y = conv2d(x, W, stride, padding=KH/2).  ref: neural_network_components.py:27-30
+ * (3x3 s1, 1x1), discriminator.py:34-38 (3x3 s1/s2), :25 (1024->1 head). */
+int lhg_conv2d_forward(const float* x, int N, int H, int W, int Ci, int ldx,
+                       const float* wp, int rows_pad, int KH, int KW, int stride,
+                       float* y, int Co, int ldy,
+                       const float* bias, const float* scale, const float* shift,
+                       const float* res, int ldres, int act, float slope, int planar_out,
+                       lhg_stream_t s);
+
+/* gx = conv2d_backward_input(gy, W).  (H, W) are the INPUT extents of the forward conv.
+ * `wp` packed with rows_from_d0 = 0.  Replaces the autograd node of the call sites above;
+ * also the "double backward w.r.t. gy" of lhg_conv2d_forward.  ref: watermelon.py:466-473. */
+int lhg_conv2d_backward_input(const float* gy, int N, int H, int W, int Co, int ldgy,
+                              const float* wp, int rows_pad, int KH, int KW, int stride,
+                              float* gx, int Ci, int ldgx, lhg_stream_t s);
+
+/* Partial weight gradients: slabs[S][KH*KW][ci_pad][co_pad] (S = split count chosen by
+ * lhg_conv2d_wgrad_splits), to be summed by lhg_wgrad_reduce. */
+int lhg_conv2d_wgrad_splits(int N, int H, int W, int Ci, int Co, int KH, int KW, int stride);
+int lhg_conv2d_backward_weight(const float* x, int N, int H, int W, int Ci, int ldx,
+                               const float* gy, int Co, int ldgy, int KH, int KW, int stride,
+                               float* slabs, int S, int ci_pad, int co_pad, lhg_stream_t s);
+
+/* y = conv_transpose2d(x, W, kernel 2, stride 2).  ref: neural_network_components.py:270-286. */
+int lhg_conv_transpose2x2_forward(const float* x, int N, int H, int W, int Ci, int ldx,
+                                  const float* wp, int rows_pad, float* y, int Co, int ldy,
+                                  const float* bias, lhg_stream_t s);
+int lhg_conv_transpose2x2_backward_input(const float* gy, int N, int H, int W, int Co, int ldgy,
+                                         const float* wp, int rows_pad, float* gx, int Ci, int ldgx,
+                                         lhg_stream_t s);
+int lhg_conv_transpose2x2_wgrad_splits(int N, int H, int W, int Ci, int Co);
+int lhg_conv_transpose2x2_backward_weight(const float* x, int N, int H, int W, int Ci, int ldx,
+                                          const float* gy, int Co, int ldgy,
+                                          float* slabs, int S, int ci_pad, int co_pad, lhg_stream_t s);
+
+/* grad[D0][D1][KH][KW] = sum_s slabs[s][t][m][n]  (m = conv-input channel, n = conv-output
+ * channel).  m_is_d1 = 1 for Conv2d (OIHW: D0 = n, D1 = m), 0 for ConvTranspose2d (IOHW). */
+int lhg_wgrad_reduce(const float* slabs, int S, int T, int m_pad, int n_pad,
+                     float* grad, int D0, int D1, int m_is_d1, lhg_stream_t s);
+
+/* out[c] = sum over pixels of x[pixel][c]  (bias gradients).  ws: >= 2048*C floats. */
+int lhg_channel_sum(const float* x, long long pixels, int C, int ld, float* out, float* ws, lhg_stream_t s);
+
+/* ------------------------------------------------------------------ batch norm (train / eval)
+ * ref: nn.LazyBatchNorm2d neural_network_components.py:23-24, nn.BatchNorm2d discriminator.py:39.
+ * eps 1e-5.  stats[0..C) = batch mean, stats[C..2C) = 1/sqrt(biased var + eps).
+ * running_* (may be NULL) are updated with `momentum` using the unbiased variance.
+ * ws: >= 4096*C floats (partial sums, reduced in double). */
+int lhg_bn_stats(const float* x, long long pixels, int C, int ld, float* stats,
+                 float* running_mean, float* running_var, float momentum, float eps,
+                 float* ws, lhg_stream_t s);
+/* y = act((x - mean)*invstd*gamma + beta + res) */
+int lhg_bn_apply(const float* x, int ldx, long long pixels, int C, const float* stats,
+                 const float* gamma, const float* beta, const float* res, int ldres,
+                 int act, float slope, float* y, int ldy, lhg_stream_t s);
+/* Backward of y = act(bn(x) + res) given gy:  g = gy * act'(y);  gres = g (if non-NULL);
+ * gx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); ggamma = sum g*xhat; gbeta = sum g.
+ * `y` is the forward OUTPUT (sign gives the activation mask).  ws: >= 8192*C floats. */
+int lhg_bn_backward(const float* gy, int ldgy, const float* x, int ldx, const float* y, int ldy,
+                    long long pixels, int C, const float* stats, const float* gamma,
+                    int act, float slope, float* gx, int ldgx, float* gres, int ldgres,
+                    float* ggamma, float* gbeta, float* ws, lhg_stream_t s);
+/* Double backward of the gx output above (WGAN-GP, ref: watermelon.py:466-473):
+ * given ggx (cotangent of gx) returns ggy (cotangent of gy), gx2 (cotangent of x) and
+ * ggamma2 (cotangent of gamma).  ws: >= 5*4096*C floats. */
+int lhg_bn_backward_backward(const float* ggx, const float* gy, const float* x, const float* y,
+                             long long pixels, int C, const float* stats, const float* gamma,
+                             int act, float slope, float* ggy, float* gx2, float* ggamma2,
+                             float* ws, lhg_stream_t s);
+
+/* ------------------------------------------------------------------ pointwise / pooling */
+/* 2x2 stride-2 max pool, NHWC.  ref: neural_network_components.py:252-268. */
+int lhg_maxpool2x2_forward(const float* x, int N, int H, int W, int C, int ldx, float* y, int ldy, lhg_stream_t s);
+/* gx = gy routed to the first maximal element of each window (PyTorch tie rule). */
+int lhg_maxpool2x2_backward(const float* x, int ldx, const float* gy, int ldgy, int N, int H, int W, int C,
+                            float* gx, int ldgx, lhg_stream_t s);
+/* g_out = g * act'(y) with the mask taken from the forward output y. */
+int lhg_act_backward(const float* g, int ldg, const float* y, int ldy, long long pixels, int C,
+                     int act, float slope, float* out, int ldo, lhg_stream_t s);
+
+/* ------------------------------------------------------------------ angular spectrum (A5 A8 A9)
+ * One fused operator  out = crop( IFFT2( F1 (.) F2 (.) FFT2( pad( in ) ) ) )  on `planes`
+ * independent (rows0 x cols0) fields, done as three LDS-resident batched 1-D FFT passes
+ * that never materialise the zero padding.  ref: angular_spectrum_method.py:374-392,
+ * 503-552 (torch.fft.fft2 / ifft2 / F.pad / slicing call sites).
+ *   in_mode : 0 polar (a, phi*phase_scale)   1 phase only (e^{i phi})   2 complex
+ *   out_mode: 0 complex   1 |z| and angle(z) (+ optional complex copy)   2 |z| only
+ *   filter op per factor: 0 none, 1 multiply, 2 multiply by conj, 3 divide, 4 divide by conj
+ *   f_index[p] selects the (rows x cols) slab of the factor used by plane p.
+ * rows, cols (padded extents) must be powers of two in [16, 4096].
+ * ws: 2 * planes * rows0 * cols complex64.                                             */
+typedef struct lhg_asm_filter {
+  const float* f1; const int32_t* f1_index; int f1_op;  /* device pointers */
+  const float* f2; const int32_t* f2_index; int f2_op;
+} lhg_asm_filter;
+
+int lhg_asm_propagate(const float* in_a, const float* in_b, int in_mode, float phase_scale,
+                      int planes, int rows0, int cols0, int pad_r, int pad_c,
+                      const lhg_asm_filter* filt,
+                      float* out_a, float* out_b, float* out_complex, int out_mode,
+                      float* ws, size_t ws_bytes, const float* twiddle_rows, const float* twiddle_cols,
+                      lhg_stream_t s);
+/* spectrum = F1 (.) F2 (.) FFT2(pad(in)) written in full (planes, rows, cols) complex64
+ * (API parity with propagate_POH2Freq_forward / filter_AP2filteredFreq). */
+int lhg_asm_to_spectrum(const float* in_a, const float* in_b, int in_mode, float phase_scale,
+                        int planes, int rows0, int cols0, int pad_r, int pad_c,
+                        const lhg_asm_filter* filt, float* spectrum,
+                        float* ws, size_t ws_bytes, const float* twiddle_rows, const float* twiddle_cols,
+                        lhg_stream_t s);
+/* out = crop(IFFT2(F1 (.) F2 (.) spectrum)) from a full spectrum. */
+int lhg_asm_from_spectrum(const float* spectrum, int planes, int rows0, int cols0, int pad_r, int pad_c,
+                          const lhg_asm_filter* filt,
+                          float* out_a, float* out_b, float* out_complex, int out_mode,
+                          float* ws, size_t ws_bytes, const float* twiddle_rows, const float* twiddle_cols,
+                          lhg_stream_t s);
+/* twiddle[k] = exp(-2 pi i k / n), k < n, computed in double on the device. */
+int lhg_fft_twiddles(float* twiddle, int n, lhg_stream_t s);
+
+/* ------------------------------------------------------------------ AP2POH tail (A6 A7)
+ * field (planes,rows,cols) complex64 -> POH.  ref: AP2POH.py:105-116, utilities.py:53-66,
+ * neural_network_components.py:68-75.  taps[plane%3][3] = (centre, edge, corner), bias[plane%3]. */
+int lhg_symconv_field(const float* field, int planes, int rows, int cols, const float* taps, const float* bias,
+                      float* mod, float* plane_max /* [planes], atomically maxed; zero it first */, lhg_stream_t s);
+int lhg_double_phase_encode(const float* mod, const float* plane_max, int planes, int rows, int cols,
+                            float* poh, lhg_stream_t s);
+
+/* ------------------------------------------------------------------ optimiser
+ * torch.optim.Adam (no weight decay, no amsgrad) on one flat tensor.  ref: watermelon.py:137-138. */
+int lhg_adam_step(float* p, const float* g, float* m, float* v, long long n,
+                  float lr, float beta1, float beta2, float eps, int step, lhg_stream_t s);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LHG_HIP_H */

@@ -1,0 +1,400 @@
+// Fused angular-spectrum operator for gfx950:
+//     out = crop( IFFT2( F1 (.) F2 (.) FFT2( pad( in ) ) ) )
+// on `planes` independent rows0 x cols0 fields (the reference issues
+// F.pad, torch.fft.fft2, complex multiplies, torch.fft.ifft2 and a slice as separate ATen ops on
+// full rows x cols planes, angular_spectrum_method.py:374-392, 503-552).
+//
+// HBM-bound, so the design goal is bytes: the zero padding is never written or read.
+//   pass 1  rows_forward : polar->complex, zero-extend a row in LDS, 1-D FFT along columns,
+//                          only the rows0 non-zero rows exist            -> T1[plane][rows0][cols]
+//   pass 2  cols_filter  : 16 adjacent columns per workgroup (128-byte segments), zero-extend to
+//                          `rows` in LDS, FFT, multiply by the transfer-function slab(s),
+//                          inverse FFT, keep the rows0 cropped rows      -> T2[plane][rows0][cols]
+//   pass 3  rows_inverse : 1-D inverse FFT, crop to cols0, |z| / angle(z) / complex epilogue.
+// Per plane-pair of 2-D transforms this moves ~11 MB at 384^2/1024^2 instead of the 67 MB of two
+// dense fft2 calls (DESIGN.md has the accounting).  The 1-D transforms are Stockham autosort
+// radix-4 (+ one radix-2 stage for odd log2 n) in LDS with a host-exact twiddle table
+// (computed in double), in place with register staging (read-all / barrier / write-all).
+#include "common.h"
+
+namespace lhg {
+
+enum { IN_POLAR = 0, IN_PHASE = 1, IN_COMPLEX = 2 };
+enum { OUT_COMPLEX = 0, OUT_ABS_ANGLE = 1, OUT_ABS = 2 };
+enum { F_NONE = 0, F_MUL = 1, F_MUL_CONJ = 2, F_DIV = 3, F_DIV_CONJ = 4 };
+
+constexpr int MAX_IT = 4;  // butterflies per thread per stage
+
+__device__ __forceinline__ float2 cmul(float2 a, float2 b) { return make_float2(a.x * b.x - a.y * b.y, a.x * b.y + a.y * b.x); }
+__device__ __forceinline__ float2 cadd(float2 a, float2 b) { return make_float2(a.x + b.x, a.y + b.y); }
+__device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(a.x - b.x, a.y - b.y); }
+
+// nf transforms of length n at buf + f*stride.  tw: n entries exp(-2 pi i k / n) (LDS).
+// All threads of the workgroup must call this (barriers inside).
+template <bool INV>
+__device__ void lds_fft(float2* buf, int n, int nf, int stride, const float2* tw) {
+  const int nthreads = blockDim.x, tid = threadIdx.x;
+  for (int p = 1; p < n;) {
+    const int R = (n / p >= 4) ? 4 : 2;
+    const int T = n / R;
+    const int total = nf * T;
+    const int twstep = n / (p * R);
+    float2 u[MAX_IT][4];
+    if (R == 4) {
+#pragma unroll
+      for (int it = 0; it < MAX_IT; ++it) {
+        const int b = tid + it * nthreads;
+        if (b < total) {
+          const int f = b / T, i = b - f * T;
+          const int k = i & (p - 1);
+          const float2* x = buf + f * stride + i;
+          float2 u0 = x[0], u1 = x[T], u2 = x[2 * T], u3 = x[3 * T];
+          if (p > 1) {
+            float2 w1 = tw[k * twstep], w2 = tw[2 * k * twstep], w3 = tw[3 * k * twstep];
+            if (INV) { w1.y = -w1.y; w2.y = -w2.y; w3.y = -w3.y; }
+            u1 = cmul(u1, w1); u2 = cmul(u2, w2); u3 = cmul(u3, w3);
+          }
+          const float2 v0 = cadd(u0, u2), v1 = csub(u0, u2), v2 = cadd(u1, u3), d = csub(u1, u3);
+          const float2 v3 = INV ? make_float2(-d.y, d.x) : make_float2(d.y, -d.x);
+          u[it][0] = cadd(v0, v2); u[it][1] = cadd(v1, v3); u[it][2] = csub(v0, v2); u[it][3] = csub(v1, v3);
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < MAX_IT; ++it) {
+        const int b = tid + it * nthreads;
+        if (b < total) {
+          const int f = b / T, i = b - f * T;
+          const int k = i & (p - 1);
+          float2* y = buf + f * stride + ((i - k) << 2) + k;
+          y[0] = u[it][0]; y[p] = u[it][1]; y[2 * p] = u[it][2]; y[3 * p] = u[it][3];
+        }
+      }
+      __syncthreads();
+    } else {
+      // radix-2 tail: 2*T == n, so up to 2*MAX_IT butterflies per thread
+#pragma unroll
+      for (int it = 0; it < 2 * MAX_IT; ++it) {
+        const int b = tid + it * nthreads;
+        if (b < total) {
+          const int f = b / T, i = b - f * T;
+          const int k = i & (p - 1);
+          const float2* x = buf + f * stride + i;
+          float2 u0 = x[0], u1 = x[T];
+          float2 w = tw[k * twstep];
+          if (INV) w.y = -w.y;
+          u1 = cmul(u1, w);
+          u[it >> 1][(it & 1) * 2] = cadd(u0, u1);
+          u[it >> 1][(it & 1) * 2 + 1] = csub(u0, u1);
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < 2 * MAX_IT; ++it) {
+        const int b = tid + it * nthreads;
+        if (b < total) {
+          const int f = b / T, i = b - f * T;
+          const int k = i & (p - 1);
+          float2* y = buf + f * stride + ((i - k) << 1) + k;
+          y[0] = u[it >> 1][(it & 1) * 2];
+          y[p] = u[it >> 1][(it & 1) * 2 + 1];
+        }
+      }
+      __syncthreads();
+    }
+    p *= R;
+  }
+}
+
+__device__ __forceinline__ float2 apply_filter(float2 z, float2 f, int op) {
+  switch (op) {
+    case F_MUL: return cmul(z, f);
+    case F_MUL_CONJ: return cmul(z, make_float2(f.x, -f.y));
+    case F_DIV: {
+      const float inv = 1.f / (f.x * f.x + f.y * f.y);
+      const float2 r = cmul(z, make_float2(f.x, -f.y));
+      return make_float2(r.x * inv, r.y * inv);
+    }
+    case F_DIV_CONJ: {
+      const float inv = 1.f / (f.x * f.x + f.y * f.y);
+      const float2 r = cmul(z, f);
+      return make_float2(r.x * inv, r.y * inv);
+    }
+    default: return z;
+  }
+}
+
+extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
+
+// ---------------------------------------------------------------------------------------- pass 1
+// grid.x = ceil(planes*rows0 / nf); block 256 threads; LDS: tw[n] + nf*n complex
+__global__ __launch_bounds__(256) void rows_forward_kernel(const float* __restrict__ in_a, const float* __restrict__ in_b, int in_mode,
+                                                           float phase_scale, int total_rows, int cols0, int pad_c, int n, int nf,
+                                                           const float2* __restrict__ twg, float2* __restrict__ t1) {
+  float2* tw = reinterpret_cast<float2*>(lds_raw);
+  float2* buf = tw + n;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < n; i += 256) tw[i] = twg[i];
+  for (int i = tid; i < nf * n; i += 256) buf[i] = make_float2(0.f, 0.f);
+  __syncthreads();
+  const int row0 = blockIdx.x * nf;
+  for (int i = tid; i < nf * cols0; i += 256) {
+    const int f = i / cols0, x = i - f * cols0;
+    const int row = row0 + f;
+    if (row < total_rows) {
+      const size_t o = (size_t)row * cols0 + x;
+      float2 z;
+      if (in_mode == IN_COMPLEX) {
+        z = reinterpret_cast<const float2*>(in_a)[o];
+      } else {
+        const float ph = (in_mode == IN_POLAR ? in_b[o] : in_a[o]) * phase_scale;
+        float sn, cs;
+        sincosf(ph, &sn, &cs);
+        const float a = in_mode == IN_POLAR ? in_a[o] : 1.f;
+        z = make_float2(a * cs, a * sn);
+      }
+      buf[f * n + pad_c + x] = z;
+    }
+  }
+  __syncthreads();
+  lds_fft<false>(buf, n, nf, n, tw);
+  for (int i = tid; i < nf * n; i += 256) {
+    const int f = i / n;
+    const int row = row0 + f;
+    if (row < total_rows) t1[(size_t)row * n + (i - f * n)] = buf[i];
+  }
+}
+
+// ---------------------------------------------------------------------------------------- pass 2
+struct ColsParams {
+  const float2* src; int src_rows, src_off;   // rows present in src (rows0 or R) and their offset inside R
+  float2* dst; int dst_rows, dst_off;
+  int planes, R, C, G;                        // G columns per workgroup
+  int do_fwd, do_inv;
+  float scale;
+  const float2* f1; const int* f1_index; int f1_op;
+  const float2* f2; const int* f2_index; int f2_op;
+  const float2* tw;                           // R entries
+};
+
+__global__ __launch_bounds__(1024) void cols_filter_kernel(const ColsParams p) {
+  float2* tw = reinterpret_cast<float2*>(lds_raw);
+  float2* buf = tw + p.R;
+  const int stride = p.R + 1;
+  const int tid = threadIdx.x, nth = blockDim.x;
+  const int groups = p.C / p.G;
+  const int plane = blockIdx.x / groups, c0 = (blockIdx.x - plane * groups) * p.G;
+  for (int i = tid; i < p.R; i += nth) tw[i] = p.tw[i];
+  // load G columns (zero outside the stored rows)
+  for (int i = tid; i < p.R * p.G; i += nth) {
+    const int g = i % p.G, r = i / p.G;
+    const int sr = r - p.src_off;
+    float2 z = make_float2(0.f, 0.f);
+    if (sr >= 0 && sr < p.src_rows) z = p.src[((size_t)plane * p.src_rows + sr) * p.C + c0 + g];
+    buf[g * stride + r] = z;
+  }
+  __syncthreads();
+  if (p.do_fwd) lds_fft<false>(buf, p.R, p.G, stride, tw);
+  const int s1 = p.f1_op ? (p.f1_index ? p.f1_index[plane] : 0) : 0;
+  const int s2 = p.f2_op ? (p.f2_index ? p.f2_index[plane] : 0) : 0;
+  if (p.f1_op || p.f2_op || p.scale != 1.f) {
+    for (int i = tid; i < p.R * p.G; i += nth) {
+      const int g = i % p.G, k = i / p.G;
+      float2 z = buf[g * stride + k];
+      if (p.f1_op) z = apply_filter(z, p.f1[((size_t)s1 * p.R + k) * p.C + c0 + g], p.f1_op);
+      if (p.f2_op) z = apply_filter(z, p.f2[((size_t)s2 * p.R + k) * p.C + c0 + g], p.f2_op);
+      z.x *= p.scale; z.y *= p.scale;
+      buf[g * stride + k] = z;
+    }
+    __syncthreads();
+  }
+  if (p.do_inv) lds_fft<true>(buf, p.R, p.G, stride, tw);
+  for (int i = tid; i < p.dst_rows * p.G; i += nth) {
+    const int g = i % p.G, r = i / p.G;
+    p.dst[((size_t)plane * p.dst_rows + r) * p.C + c0 + g] = buf[g * stride + r + p.dst_off];
+  }
+}
+
+// ---------------------------------------------------------------------------------------- pass 3
+__global__ __launch_bounds__(256) void rows_inverse_kernel(const float2* __restrict__ t2, int total_rows, int cols0, int pad_c, int n, int nf,
+                                                           const float2* __restrict__ twg, float* __restrict__ out_a, float* __restrict__ out_b,
+                                                           float2* __restrict__ out_c, int out_mode) {
+  float2* tw = reinterpret_cast<float2*>(lds_raw);
+  float2* buf = tw + n;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < n; i += 256) tw[i] = twg[i];
+  const int row0 = blockIdx.x * nf;
+  for (int i = tid; i < nf * n; i += 256) {
+    const int f = i / n;
+    const int row = row0 + f;
+    buf[i] = row < total_rows ? t2[(size_t)row * n + (i - f * n)] : make_float2(0.f, 0.f);
+  }
+  __syncthreads();
+  lds_fft<true>(buf, n, nf, n, tw);
+  for (int i = tid; i < nf * cols0; i += 256) {
+    const int f = i / cols0, x = i - f * cols0;
+    const int row = row0 + f;
+    if (row >= total_rows) continue;
+    const float2 z = buf[f * n + pad_c + x];
+    const size_t o = (size_t)row * cols0 + x;
+    if (out_mode == OUT_COMPLEX) {
+      out_c[o] = z;
+    } else {
+      out_a[o] = hypotf(z.x, z.y);
+      if (out_mode == OUT_ABS_ANGLE) out_b[o] = atan2f(z.y, z.x);
+      if (out_c) out_c[o] = z;
+    }
+  }
+}
+
+__global__ void twiddle_kernel(float2* tw, int n) {
+  const int k = blockIdx.x * blockDim.x + threadIdx.x;
+  if (k >= n) return;
+  double s, c;
+  sincospi(2.0 * (double)k / (double)n, &s, &c);
+  tw[k] = make_float2((float)c, (float)(-s));
+}
+
+// ---------------------------------------------------------------------------------------- host
+static bool pow2_in_range(int n) { return n >= 16 && n <= 4096 && (n & (n - 1)) == 0; }
+
+static int rows_nf(int n) { return n >= 4096 ? 1 : 4096 / n > 64 ? 64 : 4096 / n; }
+
+static int set_dyn_lds(const void* fn, size_t bytes) {
+  if (bytes > 160 * 1024) return fail(LHG_E_ARG, "asm: LDS request %zu exceeds 160 KiB", bytes);
+  if (bytes > 48 * 1024) {
+    hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
+    if (e != hipSuccess) return fail(LHG_E_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
+  }
+  return LHG_OK;
+}
+
+static int run_rows_forward(const float* in_a, const float* in_b, int in_mode, float phase_scale, int planes, int rows0, int cols0,
+                            int pad_c, int cols, const float* tw_cols, float2* t1, hipStream_t st) {
+  const int nf = rows_nf(cols);
+  const size_t lds = (size_t)(cols + nf * cols) * sizeof(float2);
+  int rc = set_dyn_lds(reinterpret_cast<const void*>(rows_forward_kernel), lds);
+  if (rc) return rc;
+  const int total_rows = planes * rows0;
+  hipLaunchKernelGGL(rows_forward_kernel, dim3((total_rows + nf - 1) / nf), dim3(256), lds, st, in_a, in_b, in_mode, phase_scale,
+                     total_rows, cols0, pad_c, cols, nf, reinterpret_cast<const float2*>(tw_cols), t1);
+  return check_launch("rows_forward");
+}
+
+static int run_rows_inverse(const float2* t2, int planes, int rows0, int cols0, int pad_c, int cols, const float* tw_cols, float* out_a,
+                            float* out_b, float* out_c, int out_mode, hipStream_t st) {
+  const int nf = rows_nf(cols);
+  const size_t lds = (size_t)(cols + nf * cols) * sizeof(float2);
+  int rc = set_dyn_lds(reinterpret_cast<const void*>(rows_inverse_kernel), lds);
+  if (rc) return rc;
+  const int total_rows = planes * rows0;
+  hipLaunchKernelGGL(rows_inverse_kernel, dim3((total_rows + nf - 1) / nf), dim3(256), lds, st, t2, total_rows, cols0, pad_c, cols, nf,
+                     reinterpret_cast<const float2*>(tw_cols), out_a, out_b, reinterpret_cast<float2*>(out_c), out_mode);
+  return check_launch("rows_inverse");
+}
+
+static int run_cols(ColsParams& p, hipStream_t st) {
+  // G columns per workgroup: 16 (128-byte segments) while G*R <= 16*threads keeps <= MAX_IT butterflies per thread
+  int G = 16;
+  while (G > 1 && (size_t)G * (p.R + 1) * sizeof(float2) + (size_t)p.R * sizeof(float2) > 150 * 1024) G >>= 1;
+  int threads = 1024;
+  while (G > 1 && (long long)G * p.R > 16ll * threads) G >>= 1;
+  if ((long long)G * p.R > 16ll * threads) return fail(LHG_E_ARG, "asm: column length %d unsupported", p.R);
+  while (threads > 64 && (long long)G * p.R <= 2ll * threads) threads >>= 1;  // small transforms: fewer idle waves
+  p.G = G;
+  const size_t lds = ((size_t)G * (p.R + 1) + p.R) * sizeof(float2);
+  int rc = set_dyn_lds(reinterpret_cast<const void*>(cols_filter_kernel), lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(cols_filter_kernel, dim3(p.planes * (p.C / G)), dim3(threads), lds, st, p);
+  return check_launch("cols_filter");
+}
+
+static int check_geometry(int planes, int rows0, int cols0, int pad_r, int pad_c, const char* what) {
+  const int R = rows0 + 2 * pad_r, C = cols0 + 2 * pad_c;
+  LHG_REQUIRE(planes > 0 && rows0 > 0 && cols0 > 0 && pad_r >= 0 && pad_c >= 0, "%s: bad extents", what);
+  LHG_REQUIRE(pow2_in_range(R) && pow2_in_range(C), "%s: padded extents %dx%d must be powers of two in [16,4096]", what, R, C);
+  return LHG_OK;
+}
+
+static void fill_filter(ColsParams& p, const lhg_asm_filter* f) {
+  if (!f) return;
+  p.f1 = reinterpret_cast<const float2*>(f->f1); p.f1_index = f->f1_index; p.f1_op = f->f1 ? f->f1_op : 0;
+  p.f2 = reinterpret_cast<const float2*>(f->f2); p.f2_index = f->f2_index; p.f2_op = f->f2 ? f->f2_op : 0;
+}
+
+}  // namespace lhg
+
+using namespace lhg;
+
+extern "C" {
+
+int lhg_fft_twiddles(float* twiddle, int n, lhg_stream_t s) {
+  LHG_REQUIRE(n > 0, "fft_twiddles: n must be positive");
+  hipLaunchKernelGGL(twiddle_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(s), reinterpret_cast<float2*>(twiddle), n);
+  return check_launch("twiddles");
+}
+
+int lhg_asm_propagate(const float* in_a, const float* in_b, int in_mode, float phase_scale, int planes, int rows0, int cols0, int pad_r,
+                      int pad_c, const lhg_asm_filter* filt, float* out_a, float* out_b, float* out_complex, int out_mode, float* ws,
+                      size_t ws_bytes, const float* twiddle_rows, const float* twiddle_cols, lhg_stream_t s) {
+  int rc = check_geometry(planes, rows0, cols0, pad_r, pad_c, "asm_propagate");
+  if (rc) return rc;
+  const int R = rows0 + 2 * pad_r, C = cols0 + 2 * pad_c;
+  const size_t tbytes = (size_t)planes * rows0 * C * sizeof(float2);
+  if (ws_bytes < 2 * tbytes) return fail(LHG_E_WORKSPACE, "asm_propagate: workspace %zu < %zu", ws_bytes, 2 * tbytes);
+  float2* t1 = reinterpret_cast<float2*>(ws);
+  float2* t2 = t1 + (size_t)planes * rows0 * C;
+  hipStream_t st = as_stream(s);
+  rc = run_rows_forward(in_a, in_b, in_mode, phase_scale, planes, rows0, cols0, pad_c, C, twiddle_cols, t1, st);
+  if (rc) return rc;
+  ColsParams p{};
+  p.src = t1; p.src_rows = rows0; p.src_off = pad_r; p.dst = t2; p.dst_rows = rows0; p.dst_off = pad_r;
+  p.planes = planes; p.R = R; p.C = C; p.do_fwd = 1; p.do_inv = 1; p.scale = 1.f / ((float)R * (float)C);
+  p.tw = reinterpret_cast<const float2*>(twiddle_rows);
+  fill_filter(p, filt);
+  rc = run_cols(p, st);
+  if (rc) return rc;
+  return run_rows_inverse(t2, planes, rows0, cols0, pad_c, C, twiddle_cols, out_a, out_b, out_complex, out_mode, st);
+}
+
+int lhg_asm_to_spectrum(const float* in_a, const float* in_b, int in_mode, float phase_scale, int planes, int rows0, int cols0, int pad_r,
+                        int pad_c, const lhg_asm_filter* filt, float* spectrum, float* ws, size_t ws_bytes, const float* twiddle_rows,
+                        const float* twiddle_cols, lhg_stream_t s) {
+  int rc = check_geometry(planes, rows0, cols0, pad_r, pad_c, "asm_to_spectrum");
+  if (rc) return rc;
+  const int R = rows0 + 2 * pad_r, C = cols0 + 2 * pad_c;
+  const size_t tbytes = (size_t)planes * rows0 * C * sizeof(float2);
+  if (ws_bytes < tbytes) return fail(LHG_E_WORKSPACE, "asm_to_spectrum: workspace %zu < %zu", ws_bytes, tbytes);
+  float2* t1 = reinterpret_cast<float2*>(ws);
+  hipStream_t st = as_stream(s);
+  rc = run_rows_forward(in_a, in_b, in_mode, phase_scale, planes, rows0, cols0, pad_c, C, twiddle_cols, t1, st);
+  if (rc) return rc;
+  ColsParams p{};
+  p.src = t1; p.src_rows = rows0; p.src_off = pad_r; p.dst = reinterpret_cast<float2*>(spectrum); p.dst_rows = R; p.dst_off = 0;
+  p.planes = planes; p.R = R; p.C = C; p.do_fwd = 1; p.do_inv = 0; p.scale = 1.f;
+  p.tw = reinterpret_cast<const float2*>(twiddle_rows);
+  fill_filter(p, filt);
+  return run_cols(p, st);
+}
+
+int lhg_asm_from_spectrum(const float* spectrum, int planes, int rows0, int cols0, int pad_r, int pad_c, const lhg_asm_filter* filt,
+                          float* out_a, float* out_b, float* out_complex, int out_mode, float* ws, size_t ws_bytes,
+                          const float* twiddle_rows, const float* twiddle_cols, lhg_stream_t s) {
+  int rc = check_geometry(planes, rows0, cols0, pad_r, pad_c, "asm_from_spectrum");
+  if (rc) return rc;
+  const int R = rows0 + 2 * pad_r, C = cols0 + 2 * pad_c;
+  const size_t tbytes = (size_t)planes * rows0 * C * sizeof(float2);
+  if (ws_bytes < tbytes) return fail(LHG_E_WORKSPACE, "asm_from_spectrum: workspace %zu < %zu", ws_bytes, tbytes);
+  float2* t2 = reinterpret_cast<float2*>(ws);
+  hipStream_t st = as_stream(s);
+  ColsParams p{};
+  p.src = reinterpret_cast<const float2*>(spectrum); p.src_rows = R; p.src_off = 0; p.dst = t2; p.dst_rows = rows0; p.dst_off = pad_r;
+  p.planes = planes; p.R = R; p.C = C; p.do_fwd = 0; p.do_inv = 1; p.scale = 1.f / ((float)R * (float)C);
+  p.tw = reinterpret_cast<const float2*>(twiddle_rows);
+  fill_filter(p, filt);
+  rc = run_cols(p, st);
+  if (rc) return rc;
+  return run_rows_inverse(t2, planes, rows0, cols0, pad_c, C, twiddle_cols, out_a, out_b, out_complex, out_mode, st);
+}
+
+}  // extern "C"

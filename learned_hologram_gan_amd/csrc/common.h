@@ -1,0 +1,62 @@
+// Shared helpers for the gfx950 kernels of liblhg_hip.so.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <cstdarg>
+#include <cstdio>
+
+#include "../../include/lhg_hip.h"
+
+namespace lhg {
+
+inline char* err_buf() {
+  static thread_local char buf[512] = "";
+  return buf;
+}
+
+inline int fail(int code, const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(err_buf(), 512, fmt, ap);
+  va_end(ap);
+  return code;
+}
+
+inline int check_launch(const char* what) {
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return fail(LHG_E_LAUNCH, "%s: %s", what, hipGetErrorString(e));
+  return LHG_OK;
+}
+
+inline hipStream_t as_stream(lhg_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
+
+constexpr int kWave = 64;  // CDNA wavefront
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+__device__ __forceinline__ float apply_act(float v, int act, float slope) {
+  switch (act) {
+    case LHG_ACT_RELU: return v > 0.f ? v : 0.f;
+    case LHG_ACT_LEAKY: return v > 0.f ? v : v * slope;
+    case LHG_ACT_SIGMOID: return 1.f / (1.f + expf(-v));
+    default: return v;
+  }
+}
+
+// derivative of the activation expressed through the forward OUTPUT y
+__device__ __forceinline__ float act_grad_from_output(float y, int act, float slope) {
+  switch (act) {
+    case LHG_ACT_RELU: return y > 0.f ? 1.f : 0.f;
+    case LHG_ACT_LEAKY: return y > 0.f ? 1.f : slope;
+    case LHG_ACT_SIGMOID: return y * (1.f - y);
+    default: return 1.f;
+  }
+}
+
+}  // namespace lhg
+
+#define LHG_REQUIRE(cond, ...) \
+  do {                         \
+    if (!(cond)) return lhg::fail(LHG_E_ARG, __VA_ARGS__); \
+  } while (0)

@@ -1,0 +1,536 @@
+// Implicit-GEMM convolution engine for gfx950 (MI355X), fp32 in / fp32 accumulate on the
+// matrix cores (v_mfma_f32_32x32x2_f32: exact fp32 fmaf chain, 157 TFLOP/s dense peak).
+//
+// Every convolution-like op of the hot path (Conv2d 3x3 s1/s2, 1x1, ConvTranspose2d 2x2 s2,
+// their input gradients and their weight gradients) is one of
+// two GEMM shapes over a common "gather geometry":
+//
+//   forward-type   out[pix(p)][n]   = sum_t sum_k  in[src(p,t)][k] * Wp[t][n][k]      (gg_kernel)
+//   wgrad-type     dW[t][m][n]      = sum_p        in[src(p,t)][m] * gout[pix(p)][n]  (wg_kernel)
+//
+// p runs over a sub-grid of output pixels (all of them, or one 2x2 parity class for the
+// stride-2 transposed forms), src(p,t) = istep*(i,j) + (dy[t],dx[t]) with zero fill outside the
+// image.  No im2col buffer exists anywhere: the gather happens while staging LDS tiles.
+//
+// Tiling (wave64, 4 waves / workgroup):
+//   gg: block tile BM pixels x BN channels x 32 k; A tile [BM][32] and B tile [BN][32] are both
+//       K-contiguous in global memory, staged through registers into LDS rows of 36 floats
+//       (16-byte aligned, conflict-free for ds_read_b128: 36*m mod 64 is injective on 16 rows).
+//       A lane reads 4 consecutive k per ds_read_b128 and feeds them to 4 successive MFMAs; the
+//       k -> (instruction, lane-half) assignment is a permutation shared by A and B, which the
+//       k-sum does not see.  Register prefetch of the next K step overlaps the MFMAs.
+//   wg: block tile 64 x 64 channels, K = 32 pixels per step, LDS tiles [32 px][64 ch]; lanes read
+//       consecutive channels (conflict-free ds_read_b32).  K (pixels) is split over blockIdx.z
+//       into partial slabs that lhg_wgrad_reduce sums (deterministic, no float atomics).
+#include "common.h"
+
+namespace lhg {
+
+struct Geom {
+  int N, Hi, Wi, Ci, ldi;  // gathered tensor
+  int Ho, Wo, Co, ldo;     // scattered tensor (full extents)
+  int gh, gw;              // sub-grid points per image
+  int oy0, ox0, ostep;     // out pixel = (oy0 + ostep*i, ox0 + ostep*j)
+  int istep;               // in pixel  = (istep*i + dy[t], istep*j + dx[t])
+  int T;
+  int dy[9], dx[9], ws[9];
+  int M;                   // N*gh*gw
+};
+
+struct GGParams {
+  Geom g;
+  const float* in;
+  const float* wp;  // [slab][rows_pad][Ci]
+  float* out;
+  const float* bias;
+  const float* scale;
+  const float* shift;
+  const float* res;
+  int ldres, rows_pad, act, planar_out;
+  float slope;
+};
+
+struct WGParams {
+  Geom g;
+  const float* in;    // [.., Ci]  -> m
+  const float* gout;  // [.., Co]  -> n
+  float* slabs;       // [S][Tslabs][m_pad][n_pad]
+  int m_pad, n_pad, Tslabs, kchunk;  // kchunk: pixels per split (multiple of 32)
+};
+
+__device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
+  return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
+}
+
+constexpr int BK = 32;
+constexpr int LDS_ROW = BK + 4;  // floats
+
+// ------------------------------------------------------------------------------------ gg_kernel
+template <int BM, int BN, int WGM, int WGN>
+__global__ __launch_bounds__(256, 2) void gg_kernel(const GGParams p) {
+  constexpr int TM = BM / WGM / 32, TN = BN / WGN / 32;
+  constexpr int A_LOADS = BM * 8 / 256, B_LOADS = BN * 8 / 256;
+  static_assert(WGM * WGN == 4 && TM >= 1 && TN >= 1, "4 waves per workgroup");
+  __shared__ __attribute__((aligned(16))) float smem[(BM + BN) * LDS_ROW];
+  float* sA = smem;
+  float* sB = smem + BM * LDS_ROW;
+
+  const Geom& g = p.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WGN, wn = wave % WGN;
+  const int n_tiles = p.rows_pad / BN;
+  const int mt = blockIdx.x / n_tiles, nt = blockIdx.x - mt * n_tiles;
+  const int ghw = g.gh * g.gw;
+
+  // per-thread gather rows
+  int a_n[A_LOADS], a_y[A_LOADS], a_x[A_LOADS];
+#pragma unroll
+  for (int i = 0; i < A_LOADS; ++i) {
+    const int m = mt * BM + (tid >> 3) + 32 * i;
+    if (m < g.M) {
+      const int n = m / ghw, rem = m - n * ghw;
+      const int gi = rem / g.gw, gj = rem - gi * g.gw;
+      a_n[i] = n;
+      a_y[i] = gi * g.istep;
+      a_x[i] = gj * g.istep;
+    } else {
+      a_n[i] = -1;
+      a_y[i] = a_x[i] = 0;
+    }
+  }
+  const int c4 = (tid & 7) * 4;
+  const int kch = g.Ci / BK;
+  const int steps = g.T * kch;
+
+  f32x4 ra[A_LOADS], rb[B_LOADS];
+  auto gload = [&](int s) {
+    const int t = s / kch, kc = s - t * kch;
+    const int dy = g.dy[t], dx = g.dx[t];
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) {
+      const int iy = a_y[i] + dy, ix = a_x[i] + dx;
+      const bool ok = a_n[i] >= 0 && (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi;
+      f32x4 v = {0.f, 0.f, 0.f, 0.f};
+      if (ok) v = *reinterpret_cast<const f32x4*>(p.in + ((size_t)(a_n[i] * g.Hi + iy) * g.Wi + ix) * g.ldi + kc * BK + c4);
+      ra[i] = v;
+    }
+    const float* wb = p.wp + ((size_t)g.ws[t] * p.rows_pad + nt * BN) * g.Ci + kc * BK + c4;
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i)
+      rb[i] = *reinterpret_cast<const f32x4*>(wb + (size_t)((tid >> 3) + 32 * i) * g.Ci);
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < A_LOADS; ++i) *reinterpret_cast<f32x4*>(sA + ((tid >> 3) + 32 * i) * LDS_ROW + c4) = ra[i];
+#pragma unroll
+    for (int i = 0; i < B_LOADS; ++i) *reinterpret_cast<f32x4*>(sB + ((tid >> 3) + 32 * i) * LDS_ROW + c4) = rb[i];
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int a = 0; a < TM; ++a)
+#pragma unroll
+    for (int b = 0; b < TN; ++b)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[a][b][r] = 0.f;
+
+  const int lr = lane & 31, lh = lane >> 5;
+  const float* fa = sA + (wm * TM * 32 + lr) * LDS_ROW + 4 * lh;
+  const float* fb = sB + (wn * TN * 32 + lr) * LDS_ROW + 4 * lh;
+
+  gload(0);
+  sstore();
+  __syncthreads();
+  for (int s = 0; s < steps; ++s) {
+    if (s + 1 < steps) gload(s + 1);
+#pragma unroll
+    for (int q = 0; q < 4; ++q) {
+      f32x4 a[TM], b[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) a[i] = *reinterpret_cast<const f32x4*>(fa + i * 32 * LDS_ROW + 8 * q);
+#pragma unroll
+      for (int i = 0; i < TN; ++i) b[i] = *reinterpret_cast<const f32x4*>(fb + i * 32 * LDS_ROW + 8 * q);
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) acc[i][j] = mfma32(a[i][e], b[j][e], acc[i][j]);
+    }
+    __syncthreads();
+    if (s + 1 < steps) sstore();
+    __syncthreads();
+  }
+
+  // ---- epilogue: scatter table for the BM rows of this tile, then fused bias/affine/residual/act
+  int* srow = reinterpret_cast<int*>(smem);
+  for (int r = tid; r < BM; r += 256) {
+    const int m = mt * BM + r;
+    int pix = -1;
+    if (m < g.M) {
+      const int n = m / ghw, rem = m - n * ghw;
+      const int gi = rem / g.gw, gj = rem - gi * g.gw;
+      pix = (n * g.Ho + g.oy0 + g.ostep * gi) * g.Wo + g.ox0 + g.ostep * gj;
+    }
+    srow[r] = pix;
+  }
+  __syncthreads();
+  const int plane = g.Ho * g.Wo;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int col = nt * BN + (wn * TN + j) * 32 + lr;
+    if (col >= g.Co) continue;
+    const float bias = p.bias ? p.bias[col] : 0.f;
+    const float sc = p.scale ? p.scale[col] : 1.f;
+    const float sh = p.shift ? p.shift[col] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int row = (wm * TM + i) * 32 + (r & 3) + 8 * (r >> 2) + 4 * lh;
+        const int pix = srow[row];
+        if (pix < 0) continue;
+        float v = acc[i][j][r] + bias;
+        v = v * sc + sh;
+        if (p.res) v += p.res[(size_t)pix * p.ldres + col];
+        v = apply_act(v, p.act, p.slope);
+        if (p.planar_out) {
+          const int n = pix / plane, hw = pix - n * plane;
+          p.out[((size_t)n * g.Co + col) * plane + hw] = v;
+        } else {
+          p.out[(size_t)pix * g.ldo + col] = v;
+        }
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------ wg_kernel
+constexpr int WG_TILE = 64;
+constexpr int WG_LDS_ROW = WG_TILE + 4;
+
+__global__ __launch_bounds__(256, 2) void wg_kernel(const WGParams p) {
+  __shared__ __attribute__((aligned(16))) float smem[2 * BK * WG_LDS_ROW];
+  float* sA = smem;                    // [32 px][64 m]
+  float* sB = smem + BK * WG_LDS_ROW;  // [32 px][64 n]
+  const Geom& g = p.g;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int n_tiles = p.n_pad / WG_TILE;
+  const int mt = blockIdx.x / n_tiles, nt = blockIdx.x - mt * n_tiles;
+  const int t = blockIdx.y;
+  const int split = blockIdx.z;
+  const int ghw = g.gh * g.gw;
+  const int dy = g.dy[t], dx = g.dx[t];
+
+  const int p_begin = split * p.kchunk;
+  const int p_end = min(g.M, p_begin + p.kchunk);
+  const int steps = (p_end - p_begin + BK - 1) / BK;
+
+  const int c4 = (tid & 15) * 4;
+  const int prow = tid >> 4;  // 0..15, +16
+  const bool a_col_ok = mt * WG_TILE + c4 < g.Ci;  // Ci, Co are multiples of 4 (ld alignment)
+  const bool b_col_ok = nt * WG_TILE + c4 < g.Co;
+
+  f32x4 ra[2], rb[2];
+  auto gload = [&](int s) {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int q = p_begin + s * BK + prow + 16 * i;
+      f32x4 va = {0.f, 0.f, 0.f, 0.f}, vb = {0.f, 0.f, 0.f, 0.f};
+      if (q < p_end) {
+        const int n = q / ghw, rem = q - n * ghw;
+        const int gi = rem / g.gw, gj = rem - gi * g.gw;
+        const int iy = gi * g.istep + dy, ix = gj * g.istep + dx;
+        if (a_col_ok && (unsigned)iy < (unsigned)g.Hi && (unsigned)ix < (unsigned)g.Wi)
+          va = *reinterpret_cast<const f32x4*>(p.in + ((size_t)(n * g.Hi + iy) * g.Wi + ix) * g.ldi + mt * WG_TILE + c4);
+        if (b_col_ok) {
+          const int oy = g.oy0 + g.ostep * gi, ox = g.ox0 + g.ostep * gj;
+          vb = *reinterpret_cast<const f32x4*>(p.gout + ((size_t)(n * g.Ho + oy) * g.Wo + ox) * g.ldo + nt * WG_TILE + c4);
+        }
+      }
+      ra[i] = va;
+      rb[i] = vb;
+    }
+  };
+  auto sstore = [&]() {
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      *reinterpret_cast<f32x4*>(sA + (prow + 16 * i) * WG_LDS_ROW + c4) = ra[i];
+      *reinterpret_cast<f32x4*>(sB + (prow + 16 * i) * WG_LDS_ROW + c4) = rb[i];
+    }
+  };
+
+  f32x16 acc;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) acc[r] = 0.f;
+  const int lr = lane & 31, lh = lane >> 5;
+  const float* fa = sA + lh * WG_LDS_ROW + wm * 32 + lr;
+  const float* fb = sB + lh * WG_LDS_ROW + wn * 32 + lr;
+
+  if (steps > 0) {
+    gload(0);
+    sstore();
+  }
+  __syncthreads();
+  for (int s = 0; s < steps; ++s) {
+    if (s + 1 < steps) gload(s + 1);
+#pragma unroll
+    for (int kk = 0; kk < BK / 2; ++kk) acc = mfma32(fa[2 * kk * WG_LDS_ROW], fb[2 * kk * WG_LDS_ROW], acc);
+    __syncthreads();
+    if (s + 1 < steps) sstore();
+    __syncthreads();
+  }
+
+  float* slab = p.slabs + (((size_t)split * p.Tslabs + g.ws[t]) * p.m_pad + mt * WG_TILE + wm * 32) * p.n_pad + nt * WG_TILE + wn * 32 + lr;
+#pragma unroll
+  for (int r = 0; r < 16; ++r) {
+    const int row = (r & 3) + 8 * (r >> 2) + 4 * lh;
+    slab[(size_t)row * p.n_pad] = acc[r];
+  }
+}
+
+// ------------------------------------------------------------------------------------ small kernels
+__global__ void pack_weight_kernel(const float* __restrict__ w, int D0, int D1, int T, int rows_from_d0,
+                                   float* __restrict__ dst, int rows_pad, int k_pad) {
+  const size_t total = (size_t)T * rows_pad * k_pad;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i % k_pad);
+    const int row = (int)((i / k_pad) % rows_pad);
+    const int t = (int)(i / ((size_t)k_pad * rows_pad));
+    const int rows = rows_from_d0 ? D0 : D1, K = rows_from_d0 ? D1 : D0;
+    float v = 0.f;
+    if (row < rows && k < K) {
+      const int d0 = rows_from_d0 ? row : k, d1 = rows_from_d0 ? k : row;
+      v = w[((size_t)d0 * D1 + d1) * T + t];
+    }
+    dst[i] = v;
+  }
+}
+
+__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int S, int T, int m_pad, int n_pad,
+                                    float* __restrict__ grad, int D0, int D1, int m_is_d1) {
+  const int M = m_is_d1 ? D1 : D0, Nn = m_is_d1 ? D0 : D1;
+  const size_t total = (size_t)T * M * Nn;
+  const size_t slab_stride = (size_t)T * m_pad * n_pad;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int n = (int)(i % Nn);
+    const int m = (int)((i / Nn) % M);
+    const int t = (int)(i / ((size_t)Nn * M));
+    const float* src = slabs + ((size_t)t * m_pad + m) * n_pad + n;
+    float acc = 0.f;
+    for (int s = 0; s < S; ++s) acc += src[s * slab_stride];
+    const int d0 = m_is_d1 ? n : m, d1 = m_is_d1 ? m : n;
+    grad[((size_t)d0 * D1 + d1) * T + t] = acc;
+  }
+}
+
+// ------------------------------------------------------------------------------------ host side
+static int launch_gg(GGParams& p, hipStream_t st) {
+  const Geom& g = p.g;
+  if (g.M <= 0) return LHG_OK;
+  LHG_REQUIRE(g.Ci % BK == 0 && g.Ci > 0, "gather-GEMM: K channels (%d) must be a positive multiple of 32", g.Ci);
+  LHG_REQUIRE(g.ldi % 4 == 0 && (reinterpret_cast<uintptr_t>(p.in) & 15) == 0, "gather-GEMM: input must be 16-byte aligned (ld %d)", g.ldi);
+  LHG_REQUIRE((reinterpret_cast<uintptr_t>(p.wp) & 15) == 0, "gather-GEMM: packed weights must be 16-byte aligned");
+  LHG_REQUIRE(p.rows_pad % 64 == 0 && p.rows_pad >= g.Co, "gather-GEMM: rows_pad %d must be a multiple of 64 covering Co=%d", p.rows_pad, g.Co);
+  LHG_REQUIRE((long long)g.N * g.Ho * g.Wo < (1ll << 31) && (long long)g.N * g.Hi * g.Wi < (1ll << 31), "gather-GEMM: more than 2^31 pixels");
+  auto blocks = [&](int bm, int bn) { return (long long)((g.M + bm - 1) / bm) * (p.rows_pad / bn); };
+  if (p.rows_pad % 128 == 0 && blocks(128, 128) >= 400) {
+    hipLaunchKernelGGL((gg_kernel<128, 128, 2, 2>), dim3((unsigned)blocks(128, 128)), dim3(256), 0, st, p);
+  } else if (blocks(256, 64) >= 400) {
+    hipLaunchKernelGGL((gg_kernel<256, 64, 4, 1>), dim3((unsigned)blocks(256, 64)), dim3(256), 0, st, p);
+  } else {
+    hipLaunchKernelGGL((gg_kernel<64, 64, 2, 2>), dim3((unsigned)blocks(64, 64)), dim3(256), 0, st, p);
+  }
+  return check_launch("gg_kernel");
+}
+
+static int launch_wg(WGParams& p, int S, hipStream_t st) {
+  const Geom& g = p.g;
+  LHG_REQUIRE(g.ldi % 4 == 0 && g.ldo % 4 == 0 && g.Ci % 4 == 0 && g.Co % 4 == 0, "wgrad: channel counts / strides must be multiples of 4");
+  LHG_REQUIRE((reinterpret_cast<uintptr_t>(p.in) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.gout) & 15) == 0, "wgrad: inputs must be 16-byte aligned");
+  LHG_REQUIRE(p.m_pad % 64 == 0 && p.n_pad % 64 == 0 && p.m_pad >= g.Ci && p.n_pad >= g.Co, "wgrad: bad padded extents");
+  LHG_REQUIRE(S >= 1 && S <= 65535, "wgrad: bad split count %d", S);
+  const int steps = (g.M + BK - 1) / BK;
+  p.kchunk = ((steps + S - 1) / S) * BK;
+  dim3 grid((p.m_pad / 64) * (p.n_pad / 64), g.T, S);
+  hipLaunchKernelGGL(wg_kernel, grid, dim3(256), 0, st, p);
+  return check_launch("wg_kernel");
+}
+
+static int pick_splits(long long pixels, int tiles) {
+  const long long steps = (pixels + BK - 1) / BK;
+  long long s = (1536 + tiles - 1) / tiles;
+  const long long cap = steps / 8 > 1 ? steps / 8 : 1;
+  if (s > cap) s = cap;
+  if (s < 1) s = 1;
+  if (s > 4096) s = 4096;
+  return (int)s;
+}
+
+static inline int pad64(int c) { return (c + 63) / 64 * 64; }
+
+// geometry of y = conv2d(x) (also used, read as "gout", for its weight gradient)
+static void conv_fwd_geom(Geom& g, int N, int H, int W, int Ci, int ldx, int Co, int ldy, int KH, int KW, int stride) {
+  const int ph = KH / 2, pw = KW / 2;
+  g.N = N; g.Hi = H; g.Wi = W; g.Ci = Ci; g.ldi = ldx;
+  g.Ho = (H + 2 * ph - KH) / stride + 1; g.Wo = (W + 2 * pw - KW) / stride + 1; g.Co = Co; g.ldo = ldy;
+  g.gh = g.Ho; g.gw = g.Wo; g.oy0 = g.ox0 = 0; g.ostep = 1; g.istep = stride;
+  g.T = KH * KW;
+  for (int kh = 0; kh < KH; ++kh)
+    for (int kw = 0; kw < KW; ++kw) {
+      const int t = kh * KW + kw;
+      g.dy[t] = kh - ph; g.dx[t] = kw - pw; g.ws[t] = t;
+    }
+  g.M = N * g.gh * g.gw;
+}
+
+static bool conv_args_ok(int KH, int KW, int stride) {
+  return KH == KW && (KH == 1 || KH == 3) && (stride == 1 || stride == 2);
+}
+
+}  // namespace lhg
+
+using namespace lhg;
+
+extern "C" {
+
+int lhg_pack_weight(const float* w, int D0, int D1, int KH, int KW, int rows_from_d0, float* dst, int rows_pad, int k_pad, lhg_stream_t s) {
+  const int rows = rows_from_d0 ? D0 : D1, K = rows_from_d0 ? D1 : D0;
+  LHG_REQUIRE(rows_pad >= rows && k_pad >= K && rows_pad % 64 == 0 && k_pad % 32 == 0, "pack_weight: bad padding (%d>=%d, %d>=%d)", rows_pad, rows, k_pad, K);
+  const size_t total = (size_t)KH * KW * rows_pad * k_pad;
+  const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
+  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, as_stream(s), w, D0, D1, KH * KW, rows_from_d0, dst, rows_pad, k_pad);
+  return check_launch("pack_weight");
+}
+
+int lhg_conv2d_forward(const float* x, int N, int H, int W, int Ci, int ldx, const float* wp, int rows_pad, int KH, int KW, int stride,
+                       float* y, int Co, int ldy, const float* bias, const float* scale, const float* shift,
+                       const float* res, int ldres, int act, float slope, int planar_out, lhg_stream_t s) {
+  LHG_REQUIRE(conv_args_ok(KH, KW, stride), "conv2d_forward: unsupported kernel %dx%d stride %d", KH, KW, stride);
+  GGParams p{};
+  conv_fwd_geom(p.g, N, H, W, Ci, ldx, Co, ldy, KH, KW, stride);
+  p.in = x; p.wp = wp; p.out = y; p.bias = bias; p.scale = scale; p.shift = shift; p.res = res; p.ldres = ldres;
+  p.rows_pad = rows_pad; p.act = act; p.slope = slope; p.planar_out = planar_out;
+  return launch_gg(p, as_stream(s));
+}
+
+int lhg_conv2d_backward_input(const float* gy, int N, int H, int W, int Co, int ldgy, const float* wp, int rows_pad, int KH, int KW, int stride,
+                              float* gx, int Ci, int ldgx, lhg_stream_t s) {
+  LHG_REQUIRE(conv_args_ok(KH, KW, stride), "conv2d_backward_input: unsupported kernel %dx%d stride %d", KH, KW, stride);
+  const int ph = KH / 2, pw = KW / 2;
+  const int Ho = (H + 2 * ph - KH) / stride + 1, Wo = (W + 2 * pw - KW) / stride + 1;
+  GGParams p{};
+  Geom& g = p.g;
+  g.N = N; g.Hi = Ho; g.Wi = Wo; g.Ci = Co; g.ldi = ldgy;  // gathered tensor = gy
+  g.Ho = H; g.Wo = W; g.Co = Ci; g.ldo = ldgx;             // scattered tensor = gx
+  p.in = gy; p.wp = wp; p.out = gx; p.rows_pad = rows_pad; p.act = LHG_ACT_NONE;
+  if (stride == 1) {
+    g.gh = H; g.gw = W; g.oy0 = g.ox0 = 0; g.ostep = 1; g.istep = 1; g.T = KH * KW;
+    for (int kh = 0; kh < KH; ++kh)
+      for (int kw = 0; kw < KW; ++kw) {
+        const int t = kh * KW + kw;
+        g.dy[t] = ph - kh; g.dx[t] = pw - kw; g.ws[t] = t;
+      }
+    g.M = N * H * W;
+    return launch_gg(p, as_stream(s));
+  }
+  // stride 2: one launch per output parity class; input row y receives kernel rows kh with
+  // (y + ph - kh) even, from gy row (y + ph - kh)/2.
+  for (int py = 0; py < 2; ++py)
+    for (int px = 0; px < 2; ++px) {
+      g.gh = (H - py + 1) / 2; g.gw = (W - px + 1) / 2;
+      if (g.gh <= 0 || g.gw <= 0) continue;
+      g.oy0 = py; g.ox0 = px; g.ostep = 2; g.istep = 1;
+      int T = 0;
+      for (int kh = 0; kh < KH; ++kh) {
+        if ((py + ph - kh) & 1) continue;
+        for (int kw = 0; kw < KW; ++kw) {
+          if ((px + pw - kw) & 1) continue;
+          g.dy[T] = (py + ph - kh) / 2; g.dx[T] = (px + pw - kw) / 2; g.ws[T] = kh * KW + kw;
+          ++T;
+        }
+      }
+      g.T = T;
+      g.M = N * g.gh * g.gw;
+      if (T == 0) return fail(LHG_E_ARG, "conv2d_backward_input: empty tap set");
+      int rc = launch_gg(p, as_stream(s));
+      if (rc) return rc;
+    }
+  return LHG_OK;
+}
+
+int lhg_conv2d_wgrad_splits(int N, int H, int W, int Ci, int Co, int KH, int KW, int stride) {
+  const int Ho = (H + 2 * (KH / 2) - KH) / stride + 1, Wo = (W + 2 * (KW / 2) - KW) / stride + 1;
+  return pick_splits((long long)N * Ho * Wo, (pad64(Ci) / 64) * (pad64(Co) / 64) * KH * KW);
+}
+
+int lhg_conv2d_backward_weight(const float* x, int N, int H, int W, int Ci, int ldx, const float* gy, int Co, int ldgy,
+                               int KH, int KW, int stride, float* slabs, int S, int ci_pad, int co_pad, lhg_stream_t s) {
+  LHG_REQUIRE(conv_args_ok(KH, KW, stride), "conv2d_backward_weight: unsupported kernel %dx%d stride %d", KH, KW, stride);
+  WGParams p{};
+  conv_fwd_geom(p.g, N, H, W, Ci, ldx, Co, ldgy, KH, KW, stride);
+  p.in = x; p.gout = gy; p.slabs = slabs; p.m_pad = ci_pad; p.n_pad = co_pad; p.Tslabs = KH * KW;
+  return launch_wg(p, S, as_stream(s));
+}
+
+// ---- ConvTranspose2d(kernel 2, stride 2): out[2i+py][2j+px][co] = sum_ci in[i][j][ci] * W[ci][co][py][px]
+static void convt_geom(Geom& g, int N, int H, int W, int Ci, int ldx, int Co, int ldy, int py, int px) {
+  g.N = N; g.Hi = H; g.Wi = W; g.Ci = Ci; g.ldi = ldx;
+  g.Ho = 2 * H; g.Wo = 2 * W; g.Co = Co; g.ldo = ldy;
+  g.gh = H; g.gw = W; g.oy0 = py; g.ox0 = px; g.ostep = 2; g.istep = 1;
+  g.T = 1; g.dy[0] = g.dx[0] = 0; g.ws[0] = py * 2 + px;
+  g.M = N * H * W;
+}
+
+int lhg_conv_transpose2x2_forward(const float* x, int N, int H, int W, int Ci, int ldx, const float* wp, int rows_pad,
+                                  float* y, int Co, int ldy, const float* bias, lhg_stream_t s) {
+  for (int py = 0; py < 2; ++py)
+    for (int px = 0; px < 2; ++px) {
+      GGParams p{};
+      convt_geom(p.g, N, H, W, Ci, ldx, Co, ldy, py, px);
+      p.in = x; p.wp = wp; p.out = y; p.bias = bias; p.rows_pad = rows_pad; p.act = LHG_ACT_NONE;
+      int rc = launch_gg(p, as_stream(s));
+      if (rc) return rc;
+    }
+  return LHG_OK;
+}
+
+int lhg_conv_transpose2x2_backward_input(const float* gy, int N, int H, int W, int Co, int ldgy, const float* wp, int rows_pad,
+                                         float* gx, int Ci, int ldgx, lhg_stream_t s) {
+  GGParams p{};
+  Geom& g = p.g;
+  g.N = N; g.Hi = 2 * H; g.Wi = 2 * W; g.Ci = Co; g.ldi = ldgy;
+  g.Ho = H; g.Wo = W; g.Co = Ci; g.ldo = ldgx;
+  g.gh = H; g.gw = W; g.oy0 = g.ox0 = 0; g.ostep = 1; g.istep = 2; g.T = 4;
+  for (int t = 0; t < 4; ++t) { g.dy[t] = t >> 1; g.dx[t] = t & 1; g.ws[t] = t; }
+  g.M = N * H * W;
+  p.in = gy; p.wp = wp; p.out = gx; p.rows_pad = rows_pad; p.act = LHG_ACT_NONE;
+  return launch_gg(p, as_stream(s));
+}
+
+int lhg_conv_transpose2x2_wgrad_splits(int N, int H, int W, int Ci, int Co) {
+  return pick_splits((long long)N * H * W, (pad64(Ci) / 64) * (pad64(Co) / 64));
+}
+
+int lhg_conv_transpose2x2_backward_weight(const float* x, int N, int H, int W, int Ci, int ldx, const float* gy, int Co, int ldgy,
+                                          float* slabs, int S, int ci_pad, int co_pad, lhg_stream_t s) {
+  for (int py = 0; py < 2; ++py)
+    for (int px = 0; px < 2; ++px) {
+      WGParams p{};
+      convt_geom(p.g, N, H, W, Ci, ldx, Co, ldgy, py, px);
+      p.in = x; p.gout = gy; p.slabs = slabs; p.m_pad = ci_pad; p.n_pad = co_pad; p.Tslabs = 4;
+      int rc = launch_wg(p, S, as_stream(s));
+      if (rc) return rc;
+    }
+  return LHG_OK;
+}
+
+int lhg_wgrad_reduce(const float* slabs, int S, int T, int m_pad, int n_pad, float* grad, int D0, int D1, int m_is_d1, lhg_stream_t s) {
+  const size_t total = (size_t)T * D0 * D1;
+  const int blocks = (int)std::min<size_t>((total + 255) / 256, 8192);
+  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, as_stream(s), slabs, S, T, m_pad, n_pad, grad, D0, D1, m_is_d1);
+  return check_launch("wgrad_reduce");
+}
+
+}  // extern "C"

@@ -1,0 +1,492 @@
+// Batch-norm (train statistics, apply, backward, double backward), pooling, layout and
+// pointwise kernels of the hot path — all HBM-bound streaming kernels over NHWC fp32:
+// 16-byte lanes along the channel axis, one pass per reduction, partials reduced in double.
+#include <algorithm>
+
+#include "common.h"
+
+namespace lhg {
+
+// thread (tx, ty): tx indexes a float4 column group, ty a pixel row inside the pass
+struct ColMap {
+  int lanes_c, rows;  // lanes_c * rows == 256
+};
+static inline ColMap col_map(int C) {
+  int c4 = C / 4;
+  int lanes = 1;
+  while (lanes < c4 && lanes < 256) lanes <<= 1;
+  return {lanes, 256 / lanes};
+}
+
+// ------------------------------------------------------------------ generic column reductions
+// NSUM partial sums per channel; functor F(pixel, c4 offset) -> array of NSUM float4 contributions
+template <int NSUM, class F>
+__device__ __forceinline__ void column_reduce(long long pixels, int C, int lanes_c, int rows, float* __restrict__ partial, F f) {
+  __shared__ float red[NSUM][256 * 4];
+  const int tx = threadIdx.x % lanes_c, ty = threadIdx.x / lanes_c;
+  const long long chunk = (pixels + gridDim.x - 1) / gridDim.x;
+  const long long p0 = blockIdx.x * chunk, p1 = min(pixels, p0 + chunk);
+  for (int cb0 = 0; cb0 < C; cb0 += lanes_c * 4) {  // uniform trip count: barriers inside
+    const int cb = cb0 + tx * 4;
+    const bool live = cb < C;
+    f32x4 acc[NSUM];
+#pragma unroll
+    for (int k = 0; k < NSUM; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (live)
+      for (long long q = p0 + ty; q < p1; q += rows) f(q, cb, acc);
+#pragma unroll
+    for (int k = 0; k < NSUM; ++k)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) red[k][(ty * lanes_c + tx) * 4 + e] = acc[k][e];
+    __syncthreads();
+    if (ty == 0 && live) {
+#pragma unroll
+      for (int k = 0; k < NSUM; ++k) {
+        f32x4 s = {0.f, 0.f, 0.f, 0.f};
+        for (int r = 0; r < rows; ++r)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) s[e] += red[k][(r * lanes_c + tx) * 4 + e];
+        *reinterpret_cast<f32x4*>(partial + ((size_t)blockIdx.x * NSUM + k) * C + cb) = s;
+      }
+    }
+    __syncthreads();
+  }
+}
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+
+// ------------------------------------------------------------------ BN statistics
+__global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict__ x, long long pixels, int C, int ld,
+                                                        int lanes_c, int rows, float* __restrict__ partial) {
+  // shifted sums around the first pixel of each channel (stable one-pass variance)
+  column_reduce<2>(pixels, C, lanes_c, rows, partial, [&](long long q, int cb, f32x4* acc) {
+    const f32x4 k = ld4(x + cb);
+    const f32x4 d = ld4(x + (size_t)q * ld + cb) - k;
+    acc[0] += d;
+    acc[1] += d * d;
+  });
+}
+
+__global__ void bn_stats_final(const float* __restrict__ partial, int nblk, const float* __restrict__ x, long long pixels, int C,
+                               float* __restrict__ stats, float* running_mean, float* running_var, float momentum, float eps) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  double s1 = 0, s2 = 0;
+  for (int b = 0; b < nblk; ++b) {
+    s1 += partial[((size_t)b * 2 + 0) * C + c];
+    s2 += partial[((size_t)b * 2 + 1) * C + c];
+  }
+  const double n = (double)pixels;
+  const double dm = s1 / n;
+  const double mean = (double)x[c] + dm;
+  double var = s2 / n - dm * dm;
+  if (var < 0) var = 0;
+  stats[c] = (float)mean;
+  stats[C + c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+  if (running_var) {
+    const double unbiased = n > 1 ? var * n / (n - 1) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
+// ------------------------------------------------------------------ BN apply (+residual, +activation)
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, int ldx, long long pixels, int C,
+                                                       const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                       const float* __restrict__ beta, const float* __restrict__ res, int ldres,
+                                                       int act, float slope, float* __restrict__ y, int ldy, int lanes_c, int rows) {
+  const int tx = threadIdx.x % lanes_c, ty = threadIdx.x / lanes_c;
+  for (int cb = tx * 4; cb < C; cb += lanes_c * 4) {
+    const f32x4 mean = ld4(stats + cb), inv = ld4(stats + C + cb);
+    const f32x4 a = inv * ld4(gamma + cb);
+    const f32x4 b = ld4(beta + cb) - mean * a;
+    for (long long q = (long long)blockIdx.x * rows + ty; q < pixels; q += (long long)gridDim.x * rows) {
+      f32x4 v = ld4(x + (size_t)q * ldx + cb) * a + b;
+      if (res) v += ld4(res + (size_t)q * ldres + cb);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act, slope);
+      st4(y + (size_t)q * ldy + cb, v);
+    }
+  }
+}
+
+// ------------------------------------------------------------------ BN backward
+__global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ gy, int ldgy, const float* __restrict__ x, int ldx,
+                                                      const float* __restrict__ y, int ldy, long long pixels, int C,
+                                                      const float* __restrict__ stats, int act, float slope, int lanes_c, int rows,
+                                                      float* __restrict__ partial) {
+  column_reduce<2>(pixels, C, lanes_c, rows, partial, [&](long long q, int cb, f32x4* acc) {
+    f32x4 g = ld4(gy + (size_t)q * ldgy + cb);
+    if (act != LHG_ACT_NONE) {
+      const f32x4 yy = ld4(y + (size_t)q * ldy + cb);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] *= act_grad_from_output(yy[e], act, slope);
+    }
+    const f32x4 xh = (ld4(x + (size_t)q * ldx + cb) - ld4(stats + cb)) * ld4(stats + C + cb);
+    acc[0] += g;
+    acc[1] += g * xh;
+  });
+}
+
+template <int NSUM>
+__global__ void reduce_partials(const float* __restrict__ partial, int nblk, int C, float* __restrict__ sums /* [NSUM][C] */) {
+  const int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  for (int k = 0; k < NSUM; ++k) {
+    double s = 0;
+    for (int b = 0; b < nblk; ++b) s += partial[((size_t)b * NSUM + k) * C + c];
+    sums[(size_t)k * C + c] = (float)s;
+  }
+}
+
+__global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ gy, int ldgy, const float* __restrict__ x, int ldx,
+                                                    const float* __restrict__ y, int ldy, long long pixels, int C,
+                                                    const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                    const float* __restrict__ sums, int act, float slope,
+                                                    float* __restrict__ gx, int ldgx, float* __restrict__ gres, int ldgres,
+                                                    float* __restrict__ ggamma, float* __restrict__ gbeta, int lanes_c, int rows) {
+  const int tx = threadIdx.x % lanes_c, ty = threadIdx.x / lanes_c;
+  const float invn = 1.f / (float)pixels;
+  for (int cb = tx * 4; cb < C; cb += lanes_c * 4) {
+    const f32x4 mean = ld4(stats + cb), inv = ld4(stats + C + cb), gam = ld4(gamma + cb);
+    const f32x4 sg = ld4(sums + cb), sgx = ld4(sums + C + cb);
+    if (blockIdx.x == 0 && ty == 0) {
+      if (ggamma) st4(ggamma + cb, sgx);
+      if (gbeta) st4(gbeta + cb, sg);
+    }
+    const f32x4 k = gam * inv, mg = sg * invn, mgx = sgx * invn;
+    for (long long q = (long long)blockIdx.x * rows + ty; q < pixels; q += (long long)gridDim.x * rows) {
+      f32x4 g = ld4(gy + (size_t)q * ldgy + cb);
+      if (act != LHG_ACT_NONE) {
+        const f32x4 yy = ld4(y + (size_t)q * ldy + cb);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) g[e] *= act_grad_from_output(yy[e], act, slope);
+      }
+      if (gres) st4(gres + (size_t)q * ldgres + cb, g);
+      const f32x4 xh = (ld4(x + (size_t)q * ldx + cb) - mean) * inv;
+      st4(gx + (size_t)q * ldgx + cb, k * (g - mg - xh * mgx));
+    }
+  }
+}
+
+// ------------------------------------------------------------------ BN double backward (WGAN-GP)
+// Notation (xc = x - mean, r = invstd, M = pixels, g = gy * act'(y), q = ggx):
+//   ggy = act'(y) * gamma*r * (q - mean(q) - xc r^2 mean(q xc))
+//   gx2 = gamma * r^3/M * [ xc*(S_q S_g / M - S_gq + 3 r^2 S_gx S_qx / M) + S_qx (S_g/M - g) + S_gx (S_q/M - q) ]
+//   ggamma2 = r * (S_gq - S_q S_g / M - r^2 S_gx S_qx / M)
+__global__ __launch_bounds__(256) void bn_bwd2_partial(const float* __restrict__ ggx, const float* __restrict__ gy,
+                                                       const float* __restrict__ x, const float* __restrict__ y, long long pixels, int C,
+                                                       const float* __restrict__ stats, int act, float slope, int lanes_c, int rows,
+                                                       float* __restrict__ partial) {
+  column_reduce<5>(pixels, C, lanes_c, rows, partial, [&](long long qi, int cb, f32x4* acc) {
+    const size_t o = (size_t)qi * C + cb;
+    f32x4 g = ld4(gy + o);
+    if (act != LHG_ACT_NONE) {
+      const f32x4 yy = ld4(y + o);
+#pragma unroll
+      for (int e = 0; e < 4; ++e) g[e] *= act_grad_from_output(yy[e], act, slope);
+    }
+    const f32x4 q = ld4(ggx + o);
+    const f32x4 xc = ld4(x + o) - ld4(stats + cb);
+    acc[0] += g;
+    acc[1] += g * xc;
+    acc[2] += q;
+    acc[3] += q * xc;
+    acc[4] += g * q;
+  });
+}
+
+__global__ __launch_bounds__(256) void bn_bwd2_apply(const float* __restrict__ ggx, const float* __restrict__ gy,
+                                                     const float* __restrict__ x, const float* __restrict__ y, long long pixels, int C,
+                                                     const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                     const float* __restrict__ sums, int act, float slope,
+                                                     float* __restrict__ ggy, float* __restrict__ gx2, float* __restrict__ ggamma2,
+                                                     int lanes_c, int rows) {
+  const int tx = threadIdx.x % lanes_c, ty = threadIdx.x / lanes_c;
+  const float invM = 1.f / (float)pixels;
+  for (int cb = tx * 4; cb < C; cb += lanes_c * 4) {
+    const f32x4 mean = ld4(stats + cb), r = ld4(stats + C + cb), gam = ld4(gamma + cb);
+    const f32x4 Sg = ld4(sums + cb), Sgx = ld4(sums + C + cb), Sq = ld4(sums + 2 * C + cb), Sqx = ld4(sums + 3 * C + cb),
+                Sgq = ld4(sums + 4 * C + cb);
+    const f32x4 r2 = r * r, r3 = r2 * r;
+    const f32x4 all_sub = Sq * Sg * invM - Sgq + r2 * Sgx * Sqx * (3.f * invM);
+    if (blockIdx.x == 0 && ty == 0 && ggamma2) st4(ggamma2 + cb, r * (Sgq - Sq * Sg * invM - r2 * Sgx * Sqx * invM));
+    const f32x4 kI = gam * r3 * invM, kO = gam * r;
+    for (long long qi = (long long)blockIdx.x * rows + ty; qi < pixels; qi += (long long)gridDim.x * rows) {
+      const size_t o = (size_t)qi * C + cb;
+      f32x4 g = ld4(gy + o), m = {1.f, 1.f, 1.f, 1.f};
+      if (act != LHG_ACT_NONE) {
+        const f32x4 yy = ld4(y + o);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) m[e] = act_grad_from_output(yy[e], act, slope);
+        g *= m;
+      }
+      const f32x4 q = ld4(ggx + o);
+      const f32x4 xc = ld4(x + o) - mean;
+      st4(gx2 + o, kI * (xc * all_sub + Sqx * (Sg * invM - g) + Sgx * (Sq * invM - q)));
+      st4(ggy + o, m * kO * (q - Sq * invM - xc * r2 * Sqx * invM));
+    }
+  }
+}
+
+// ------------------------------------------------------------------ channel sums (bias gradients)
+__global__ __launch_bounds__(256) void channel_sum_partial(const float* __restrict__ x, long long pixels, int C, int ld, int lanes_c, int rows,
+                                                           float* __restrict__ partial) {
+  column_reduce<1>(pixels, C, lanes_c, rows, partial, [&](long long q, int cb, f32x4* acc) { acc[0] += ld4(x + (size_t)q * ld + cb); });
+}
+
+// ------------------------------------------------------------------ layout
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int C, int HW, int ld) {
+  // one thread per (pixel, channel of ld); reads are strided by HW across channels but each
+  // channel plane is swept contiguously by consecutive pixels of consecutive blocks.
+  const size_t total = (size_t)N * HW * ld;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % ld);
+    const size_t pix = i / ld;
+    const size_t n = pix / HW, hw = pix - n * HW;
+    dst[i] = c < C ? src[(n * C + c) * HW + hw] : 0.f;
+  }
+}
+
+__global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, int ld, float* __restrict__ dst, int N, int C, int HW) {
+  const size_t total = (size_t)N * C * HW;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const size_t hw = i % HW;
+    const size_t nc = i / HW;
+    const size_t n = nc / C, c = nc - n * C;
+    dst[i] = src[(n * HW + hw) * ld + c];
+  }
+}
+
+// ------------------------------------------------------------------ max pool 2x2
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, int N, int H, int W, int C, int ldx,
+                                                          float* __restrict__ y, int ldy) {
+  const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
+  const size_t total = (size_t)N * Ho * Wo * C4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    const size_t op = i / C4;
+    const int ox = (int)(op % Wo);
+    const int oy = (int)((op / Wo) % Ho);
+    const size_t n = op / ((size_t)Wo * Ho);
+    const float* b = x + ((n * H + 2 * oy) * W + 2 * ox) * (size_t)ldx + c;
+    f32x4 v = ld4(b);
+    const f32x4 v1 = ld4(b + ldx), v2 = ld4(b + (size_t)W * ldx), v3 = ld4(b + (size_t)(W + 1) * ldx);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = fmaxf(fmaxf(v[e], v1[e]), fmaxf(v2[e], v3[e]));
+    st4(y + op * ldy + c, v);
+  }
+}
+
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gy, int ldgy,
+                                                          int N, int H, int W, int C, float* __restrict__ gx, int ldgx) {
+  const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
+  const size_t total = (size_t)N * Ho * Wo * C4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    const size_t op = i / C4;
+    const int ox = (int)(op % Wo);
+    const int oy = (int)((op / Wo) % Ho);
+    const size_t n = op / ((size_t)Wo * Ho);
+    const size_t base = ((n * H + 2 * oy) * W + 2 * ox);
+    const size_t offs[4] = {base, base + 1, base + W, base + W + 1};
+    f32x4 v[4];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) v[k] = ld4(x + offs[k] * ldx + c);
+    const f32x4 g = ld4(gy + op * ldgy + c);
+    f32x4 o[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int best = 0;
+      float bv = v[0][e];
+#pragma unroll
+      for (int k = 1; k < 4; ++k)
+        if (v[k][e] > bv) { bv = v[k][e]; best = k; }  // first maximum wins (row-major window scan)
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k][e] = k == best ? g[e] : 0.f;
+    }
+#pragma unroll
+    for (int k = 0; k < 4; ++k) st4(gx + offs[k] * ldgx + c, o[k]);
+  }
+}
+
+__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ g, int ldg, const float* __restrict__ y, int ldy,
+                                                      long long pixels, int C, int act, float slope, float* __restrict__ out, int ldo) {
+  const int C4 = C / 4;
+  const size_t total = (size_t)pixels * C4;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int c = (int)(i % C4) * 4;
+    const size_t q = i / C4;
+    f32x4 v = ld4(g + q * ldg + c);
+    const f32x4 yy = ld4(y + q * ldy + c);
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] *= act_grad_from_output(yy[e], act, slope);
+    st4(out + q * ldo + c, v);
+  }
+}
+
+// ------------------------------------------------------------------ Adam
+__global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                   float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
+                                                   float bc1, float bc2_sqrt) {
+  // torch.optim.Adam single-tensor path: m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
+  // denom = sqrt(v)/sqrt(1-b2^t) + eps; p -= (lr/(1-b1^t)) * m/denom
+  const float step_size = lr / bc1;
+  for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
+    const float gi = g[i];
+    const float mi = m[i] + (gi - m[i]) * (1.f - b1);  // lerp form used by torch
+    const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
+    m[i] = mi;
+    v[i] = vi;
+    const float denom = sqrtf(vi) / bc2_sqrt + eps;
+    p[i] -= step_size * (mi / denom);
+  }
+}
+
+static inline int grid_for(size_t work_items, int per_block = 256, int cap = 4096) {
+  size_t b = (work_items + per_block - 1) / per_block;
+  if (b < 1) b = 1;
+  if (b > (size_t)cap) b = cap;
+  return (int)b;
+}
+
+static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
+
+}  // namespace lhg
+
+using namespace lhg;
+
+#define LHG_NHWC_OK(ptr, C, ld, what)                                                                         \
+  LHG_REQUIRE((C) % 4 == 0 && (ld) % 4 == 0 && (ld) >= (C) && aligned16(ptr), "%s: NHWC tensor needs C%%4==0, ld%%4==0, 16-byte base (C=%d ld=%d)", what, (int)(C), (int)(ld))
+
+extern "C" {
+
+int lhg_abi_version(void) { return LHG_ABI_VERSION; }
+const char* lhg_last_error(void) { return err_buf(); }
+
+int lhg_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, int ld, lhg_stream_t s) {
+  LHG_REQUIRE(ld >= C, "nchw_to_nhwc: ld %d < C %d", ld, C);
+  const size_t total = (size_t)N * H * W * ld;
+  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, as_stream(s), src, dst, N, C, H * W, ld);
+  return check_launch("nchw_to_nhwc");
+}
+
+int lhg_nhwc_to_nchw(const float* src, int ld, float* dst, int N, int C, int H, int W, lhg_stream_t s) {
+  LHG_REQUIRE(ld >= C, "nhwc_to_nchw: ld %d < C %d", ld, C);
+  const size_t total = (size_t)N * C * H * W;
+  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, as_stream(s), src, ld, dst, N, C, H * W);
+  return check_launch("nhwc_to_nchw");
+}
+
+int lhg_channel_sum(const float* x, long long pixels, int C, int ld, float* out, float* ws, lhg_stream_t s) {
+  LHG_NHWC_OK(x, C, ld, "channel_sum");
+  const ColMap cm = col_map(C);
+  const int nblk = (int)std::min<long long>(2048, std::max<long long>(1, pixels / 256));
+  hipLaunchKernelGGL(channel_sum_partial, dim3(nblk), dim3(256), 0, as_stream(s), x, pixels, C, ld, cm.lanes_c, cm.rows, ws);
+  hipLaunchKernelGGL(reduce_partials<1>, dim3((C + 255) / 256), dim3(256), 0, as_stream(s), ws, nblk, C, out);
+  return check_launch("channel_sum");
+}
+
+int lhg_bn_stats(const float* x, long long pixels, int C, int ld, float* stats, float* running_mean, float* running_var,
+                 float momentum, float eps, float* ws, lhg_stream_t s) {
+  LHG_NHWC_OK(x, C, ld, "bn_stats");
+  LHG_REQUIRE(pixels > 0, "bn_stats: empty tensor");
+  const ColMap cm = col_map(C);
+  const int nblk = (int)std::min<long long>(1024, std::max<long long>(1, pixels / 256));
+  hipLaunchKernelGGL(bn_stats_partial, dim3(nblk), dim3(256), 0, as_stream(s), x, pixels, C, ld, cm.lanes_c, cm.rows, ws);
+  hipLaunchKernelGGL(bn_stats_final, dim3((C + 255) / 256), dim3(256), 0, as_stream(s), ws, nblk, x, pixels, C, stats, running_mean,
+                     running_var, momentum, eps);
+  return check_launch("bn_stats");
+}
+
+int lhg_bn_apply(const float* x, int ldx, long long pixels, int C, const float* stats, const float* gamma, const float* beta,
+                 const float* res, int ldres, int act, float slope, float* y, int ldy, lhg_stream_t s) {
+  LHG_NHWC_OK(x, C, ldx, "bn_apply(x)");
+  LHG_NHWC_OK(y, C, ldy, "bn_apply(y)");
+  if (res) LHG_NHWC_OK(res, C, ldres, "bn_apply(res)");
+  const ColMap cm = col_map(C);
+  const int nblk = grid_for((size_t)pixels, cm.rows * 4, 4096);
+  hipLaunchKernelGGL(bn_apply_kernel, dim3(nblk), dim3(256), 0, as_stream(s), x, ldx, pixels, C, stats, gamma, beta, res, ldres, act,
+                     slope, y, ldy, cm.lanes_c, cm.rows);
+  return check_launch("bn_apply");
+}
+
+int lhg_bn_backward(const float* gy, int ldgy, const float* x, int ldx, const float* y, int ldy, long long pixels, int C,
+                    const float* stats, const float* gamma, int act, float slope, float* gx, int ldgx, float* gres, int ldgres,
+                    float* ggamma, float* gbeta, float* ws, lhg_stream_t s) {
+  LHG_NHWC_OK(gy, C, ldgy, "bn_backward(gy)");
+  LHG_NHWC_OK(x, C, ldx, "bn_backward(x)");
+  LHG_NHWC_OK(gx, C, ldgx, "bn_backward(gx)");
+  if (act != LHG_ACT_NONE) LHG_NHWC_OK(y, C, ldy, "bn_backward(y)");
+  if (gres) LHG_NHWC_OK(gres, C, ldgres, "bn_backward(gres)");
+  const ColMap cm = col_map(C);
+  const int nblk = (int)std::min<long long>(1024, std::max<long long>(1, pixels / 256));
+  float* sums = ws + (size_t)nblk * 2 * C;
+  hipLaunchKernelGGL(bn_bwd_partial, dim3(nblk), dim3(256), 0, as_stream(s), gy, ldgy, x, ldx, y, ldy, pixels, C, stats, act, slope,
+                     cm.lanes_c, cm.rows, ws);
+  hipLaunchKernelGGL(reduce_partials<2>, dim3((C + 255) / 256), dim3(256), 0, as_stream(s), ws, nblk, C, sums);
+  const int nb2 = grid_for((size_t)pixels, cm.rows * 4, 4096);
+  hipLaunchKernelGGL(bn_bwd_apply, dim3(nb2), dim3(256), 0, as_stream(s), gy, ldgy, x, ldx, y, ldy, pixels, C, stats, gamma, sums, act,
+                     slope, gx, ldgx, gres, ldgres, ggamma, gbeta, cm.lanes_c, cm.rows);
+  return check_launch("bn_backward");
+}
+
+int lhg_bn_backward_backward(const float* ggx, const float* gy, const float* x, const float* y, long long pixels, int C,
+                             const float* stats, const float* gamma, int act, float slope, float* ggy, float* gx2, float* ggamma2,
+                             float* ws, lhg_stream_t s) {
+  LHG_NHWC_OK(ggx, C, C, "bn_backward_backward(ggx)");
+  LHG_REQUIRE(aligned16(gy) && aligned16(x) && aligned16(ggy) && aligned16(gx2), "bn_backward_backward: unaligned tensor");
+  const ColMap cm = col_map(C);
+  const int nblk = (int)std::min<long long>(1024, std::max<long long>(1, pixels / 256));
+  float* sums = ws + (size_t)nblk * 5 * C;
+  hipLaunchKernelGGL(bn_bwd2_partial, dim3(nblk), dim3(256), 0, as_stream(s), ggx, gy, x, y, pixels, C, stats, act, slope, cm.lanes_c,
+                     cm.rows, ws);
+  hipLaunchKernelGGL(reduce_partials<5>, dim3((C + 255) / 256), dim3(256), 0, as_stream(s), ws, nblk, C, sums);
+  const int nb2 = grid_for((size_t)pixels, cm.rows * 4, 4096);
+  hipLaunchKernelGGL(bn_bwd2_apply, dim3(nb2), dim3(256), 0, as_stream(s), ggx, gy, x, y, pixels, C, stats, gamma, sums, act, slope, ggy,
+                     gx2, ggamma2, cm.lanes_c, cm.rows);
+  return check_launch("bn_backward_backward");
+}
+
+int lhg_maxpool2x2_forward(const float* x, int N, int H, int W, int C, int ldx, float* y, int ldy, lhg_stream_t s) {
+  LHG_NHWC_OK(x, C, ldx, "maxpool(x)");
+  LHG_NHWC_OK(y, C, ldy, "maxpool(y)");
+  LHG_REQUIRE(H % 2 == 0 && W % 2 == 0, "maxpool2x2: odd extent %dx%d", H, W);
+  const size_t total = (size_t)N * (H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, as_stream(s), x, N, H, W, C, ldx, y, ldy);
+  return check_launch("maxpool_fwd");
+}
+
+int lhg_maxpool2x2_backward(const float* x, int ldx, const float* gy, int ldgy, int N, int H, int W, int C, float* gx, int ldgx,
+                            lhg_stream_t s) {
+  LHG_NHWC_OK(x, C, ldx, "maxpool_bwd(x)");
+  LHG_NHWC_OK(gy, C, ldgy, "maxpool_bwd(gy)");
+  LHG_NHWC_OK(gx, C, ldgx, "maxpool_bwd(gx)");
+  const size_t total = (size_t)N * (H / 2) * (W / 2) * (C / 4);
+  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, as_stream(s), x, ldx, gy, ldgy, N, H, W, C, gx,
+                     ldgx);
+  return check_launch("maxpool_bwd");
+}
+
+int lhg_act_backward(const float* g, int ldg, const float* y, int ldy, long long pixels, int C, int act, float slope, float* out,
+                     int ldo, lhg_stream_t s) {
+  LHG_NHWC_OK(g, C, ldg, "act_backward(g)");
+  LHG_NHWC_OK(y, C, ldy, "act_backward(y)");
+  LHG_NHWC_OK(out, C, ldo, "act_backward(out)");
+  const size_t total = (size_t)pixels * (C / 4);
+  hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, as_stream(s), g, ldg, y, ldy, pixels, C, act, slope,
+                     out, ldo);
+  return check_launch("act_backward");
+}
+
+int lhg_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps, int step,
+                  lhg_stream_t s) {
+  LHG_REQUIRE(step >= 1, "adam_step: step must be >= 1");
+  const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
+  hipLaunchKernelGGL(adam_kernel, dim3(grid_for((size_t)n, 256, 4096)), dim3(256), 0, as_stream(s), p, g, m, v, n, lr, beta1, beta2, eps,
+                     (float)bc1, (float)sqrt(bc2));
+  return check_launch("adam_step");
+}
+
+}  // extern "C"

@@ -1,0 +1,118 @@
+"""Single-node data parallelism: one process per GPU, torch.distributed ("nccl" = RCCL over xGMI
+on ROCm; "gloo" in the CPU tests).  The reference is single-device, so this layer
+is new: the batch is sharded across ranks, every rank holds a full replica, and gradients are
+averaged with bucketed all-reduces that start while backward is still running.
+
+Semantics (documented): BatchNorm statistics, the focal-loss max normalisers and the
+TV means are per replica; parameter gradients are averaged over ranks.
+"""
+
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+
+def init_from_env(backend: str | None = None):
+    """Initialise the default process group from RANK / WORLD_SIZE / MASTER_* (torchrun contract).
+    Returns (rank, world_size, local_rank).  No-op for a single process."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1 and not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29500")
+        if backend is None:
+            backend = "nccl" if torch.cuda.is_available() else "gloo"
+        if backend == "nccl":
+            torch.cuda.set_device(local)
+        dist.init_process_group(backend=backend, rank=rank, world_size=world)
+    return rank, world, local
+
+
+def world_size() -> int:
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+class GradSynchronizer:
+    """Average the gradients held in one flat buffer across ranks.
+
+    The flat gradient buffer (optim.FlatParams.grad) is cut into ``n_buckets`` contiguous
+    buckets in REVERSE parameter order (the last layers' gradients are produced first by
+    backward).  A post-accumulate hook on every parameter counts arrivals; when a bucket is
+    complete its all-reduce is launched asynchronously — on RCCL that runs on the communicator's
+    own stream, overlapping the rest of backward.  ``finish()`` waits and divides by the world
+    size.  xGMI is point-to-point (7 links x ~153 GB/s per GPU), so a few large buckets
+    (tens of MB) are preferred over many small ones.
+    """
+
+    def __init__(self, params, offsets, flat_grad: torch.Tensor, n_buckets: int = 4, group=None):
+        self.params, self.flat_grad, self.group = list(params), flat_grad, group
+        self.world = dist.get_world_size(group) if dist.is_initialized() else 1
+        n = len(self.params)
+        ends = [offsets[i + 1] if i + 1 < n else flat_grad.numel() for i in range(n)]
+        total = flat_grad.numel()
+        target = max(1, total // max(1, n_buckets))
+        # walk parameters from last to first, closing a bucket every `target` elements
+        self.bucket_of, self.ranges, self.expected = [0] * n, [], []
+        hi, count, b = total, 0, 0
+        for i in range(n - 1, -1, -1):
+            self.bucket_of[i] = b
+            count += 1
+            lo = offsets[i]
+            if hi - lo >= target or i == 0:
+                self.ranges.append((lo, hi))
+                self.expected.append(count)
+                hi, count, b = lo, 0, b + 1
+        del ends
+        self._arrived = [0] * len(self.ranges)
+        self._work = []
+        self._hooks = []
+        self.enabled = self.world > 1
+        if self.enabled:
+            for i, p in enumerate(self.params):
+                self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+
+    def _make_hook(self, i):
+        def hook(_param):
+            if not self._armed:
+                return
+            b = self.bucket_of[i]
+            self._arrived[b] += 1
+            if self._arrived[b] == self.expected[b]:
+                self._launch(b)
+        return hook
+
+    _armed = False
+
+    def _launch(self, b):
+        lo, hi = self.ranges[b]
+        self._work.append(dist.all_reduce(self.flat_grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        self._launched[b] = True
+
+    def start(self):
+        """Call right before ``loss.backward()``."""
+        self._arrived = [0] * len(self.ranges)
+        self._launched = [False] * len(self.ranges)
+        self._work = []
+        self._armed = self.enabled
+
+    def finish(self):
+        """Call after backward: launches buckets whose parameters got no gradient this pass,
+        waits for all reductions and turns sums into means."""
+        if not self.enabled:
+            return
+        self._armed = False
+        for b, done in enumerate(self._launched):
+            if not done:
+                self._launch(b)
+        for w in self._work:
+            w.wait()
+        self.flat_grad.div_(self.world)
+
+    def remove(self):
+        for h in self._hooks:
+            h.remove()
+        self._hooks = []

@@ -1,0 +1,525 @@
+"""torch.autograd ops over the C ABI of liblhg_hip.so.
+
+Activations between ops are NHWC fp32 tensors of shape (N, H, W, C) whose last dim has stride 1;
+channel slices of a wider buffer are allowed (the pixel stride is passed to the kernels as `ld`),
+which is how UNet skip connections avoid ``torch.cat`` copies.
+
+Every backward is written with the same differentiable ops (conv forward <-> input-gradient <->
+weight-gradient form a closed family; BN backward has an explicit double backward), so
+``autograd.grad(create_graph=True)`` through the critic — the WGAN-GP penalty of
+ref: watermelon_hologram/watermelon.py:458-477 — composes without any special casing.
+
+There is no CPU path here: every op raises if its tensors are not on the GPU.
+"""
+
+from __future__ import annotations
+
+import ctypes
+
+import torch
+from torch.autograd import Function
+
+from . import native
+from .native import ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_SIGMOID, call, ptr, stream_ptr  # noqa: F401
+
+BN_EPS = 1e-5
+BN_MOMENTUM = 0.1
+
+
+def pad_to(c: int, m: int) -> int:
+    return (c + m - 1) // m * m
+
+
+# --------------------------------------------------------------------------- descriptors
+def nhwc(t: torch.Tensor):
+    """(ptr, N, H, W, C, ld) of an NHWC view; validates the layout the kernels assume."""
+    if t.dim() != 4:
+        raise ValueError(f"expected a 4-D NHWC tensor, got shape {tuple(t.shape)}")
+    if t.dtype != torch.float32:
+        raise TypeError("hot-path tensors are fp32")
+    N, H, W, Cc = t.shape
+    s = t.stride()
+    ld = s[2] if W > 1 else (s[1] if H > 1 else max(Cc, s[2]))
+    ok = (Cc == 1 or s[3] == 1) and (W == 1 or s[2] == ld) and (H == 1 or s[1] == W * ld) and (N == 1 or s[0] == H * W * ld)
+    if not ok or ld < Cc:
+        raise ValueError(f"tensor is not an NHWC (sliced) view: shape {tuple(t.shape)} stride {s}")
+    return ptr(t), N, H, W, Cc, ld
+
+
+def new_nhwc(N, H, W, Cc, device):
+    return torch.empty((N, H, W, Cc), dtype=torch.float32, device=device)
+
+
+class OutSlot:
+    """Destination view for an op's output (e.g. a channel slice of a skip-concat buffer).
+    Deliberately NOT a Tensor so that Function.apply does not treat it as an autograd input:
+    the op writes through the raw pointer and returns a detached alias of the view, which
+    autograd then owns like any freshly allocated output."""
+
+    __slots__ = ("t",)
+
+    def __init__(self, t):
+        self.t = t
+
+
+def _resolve_out(out, shape, device):
+    if out is None:
+        return torch.empty(shape, dtype=torch.float32, device=device)
+    t = out.t
+    if tuple(t.shape) != tuple(shape):
+        raise ValueError(f"output slot has shape {tuple(t.shape)}, op produces {tuple(shape)}")
+    return t.detach()
+
+
+class CatViewsFn(Function):
+    """torch.cat((a, b), channel) where a and b were already written into the two channel
+    slices of `buf` by their producers: forward is free, backward hands out grad slices.
+    ref: torch.cat call sites neural_network_components.py:310-313 (skip first)."""
+
+    @staticmethod
+    def forward(ctx, a, b, buf_slot):
+        ctx.ca = a.shape[-1]
+        return buf_slot.t.detach()
+
+    @staticmethod
+    def backward(ctx, g):
+        return g[..., : ctx.ca], g[..., ctx.ca :], None
+
+
+def _dense(t):
+    """Materialise a strided NHWC view as a dense tensor when a kernel needs ld == C."""
+    return t if t.is_contiguous() else t.contiguous()
+
+
+# --------------------------------------------------------------------------- weight packing
+_pack_cache: dict = {}
+
+
+def pack_weight(w: torch.Tensor, rows_from_d0: bool, k_pad_to: int = 32) -> torch.Tensor:
+    """OIHW / IOHW -> [KH*KW][rows_pad][k_pad] panels (lhg_pack_weight), cached per weight version."""
+    D0, D1, KH, KW = w.shape
+    rows, K = (D0, D1) if rows_from_d0 else (D1, D0)
+    rows_pad, k_pad = pad_to(rows, 64), pad_to(K, k_pad_to)
+    key = (w.data_ptr(), w._version, rows_from_d0, k_pad)
+    slot = (id(w), rows_from_d0, k_pad)
+    hit = _pack_cache.get(slot)
+    if hit is not None and hit[0] == key:
+        return hit[1]
+    wd = w.detach()
+    if not wd.is_contiguous():
+        wd = wd.contiguous()
+    out = torch.empty((KH * KW, rows_pad, k_pad), dtype=torch.float32, device=w.device)
+    call("lhg_pack_weight", ptr(wd), D0, D1, KH, KW, int(rows_from_d0), ptr(out), rows_pad, k_pad, stream_ptr())
+    if len(_pack_cache) > 512:
+        _pack_cache.clear()
+    _pack_cache[slot] = (key, out)
+    return out
+
+
+def bump_version(t: torch.Tensor):
+    """Raw-pointer writes do not touch autograd's version counter; bump it so cached packed
+    weights are invalidated after an optimiser step."""
+    try:
+        torch.autograd.graph.increment_version(t)
+    except AttributeError:  # pragma: no cover
+        t.add_(0)
+
+
+# --------------------------------------------------------------------------- layout
+class ToNHWC(Function):
+    """NCHW -> NHWC with zero-padded channels."""
+
+    @staticmethod
+    def forward(ctx, x, ld):
+        x = x.contiguous()
+        N, Cc, H, W = x.shape
+        ctx.C = Cc
+        out = new_nhwc(N, H, W, ld, x.device)
+        call("lhg_nchw_to_nhwc", ptr(x), ptr(out), N, Cc, H, W, ld, stream_ptr())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return ToNCHW.apply(g, ctx.C), None
+
+
+class ToNCHW(Function):
+    """First C channels of an NHWC tensor -> NCHW."""
+
+    @staticmethod
+    def forward(ctx, x, Cc):
+        p, N, H, W, Cx, ld = nhwc(x)
+        ctx.Cx = Cx
+        out = torch.empty((N, Cc, H, W), dtype=torch.float32, device=x.device)
+        call("lhg_nhwc_to_nchw", p, ld, ptr(out), N, Cc, H, W, stream_ptr())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return ToNHWC.apply(g, ctx.Cx), None
+
+
+# --------------------------------------------------------------------------- convolution family
+def _conv_out_hw(H, W, k, stride):
+    p = k // 2
+    return (H + 2 * p - k) // stride + 1, (W + 2 * p - k) // stride + 1
+
+
+def conv2d_forward_raw(x, w, bias, stride, act=ACT_NONE, slope=0.0, scale=None, shift=None, res=None, out=None, planar=False):
+    """y = act((conv(x, w) + bias) * scale + shift + res); no autograd."""
+    px, N, H, W, Ci, ldx = nhwc(x)
+    Co, Ciw, KH, KW = w.shape
+    if pad_to(Ciw, 32) != Ci:
+        raise ValueError(f"conv2d: input has {Ci} channels, weight expects {Ciw} (padded {pad_to(Ciw, 32)})")
+    wp = pack_weight(w, True)
+    Ho, Wo = _conv_out_hw(H, W, KH, stride)
+    if planar:
+        y = _resolve_out(out, (N, Co, Ho, Wo), x.device)
+        py, ldy = ptr(y), Co
+    else:
+        y = _resolve_out(out, (N, Ho, Wo, Co), x.device)
+        py, _, _, _, _, ldy = nhwc(y)
+    pres, ldres = (None, 0)
+    if res is not None:
+        pres, _, _, _, _, ldres = nhwc(res)
+    call("lhg_conv2d_forward", px, N, H, W, Ci, ldx, ptr(wp), wp.shape[1], KH, KW, stride, py, Co, ldy,
+         ptr(bias), ptr(scale), ptr(shift), pres, ldres, act, float(slope), int(planar), stream_ptr())
+    return y
+
+
+def _padded_gy(gy, k_multiple=32):
+    """The GEMM K axis must be a multiple of 32 channels: zero-pad narrow gradients (head: 6, critic head: 1)."""
+    Cc = gy.shape[-1]
+    if Cc % k_multiple == 0:
+        return gy
+    out = torch.zeros(gy.shape[:-1] + (pad_to(Cc, k_multiple),), dtype=gy.dtype, device=gy.device)
+    out[..., :Cc] = gy
+    return out
+
+
+class Conv2dFn(Function):
+    """y = conv2d(x, w, stride, padding=k//2) + bias.  x NHWC with C padded to 32; w OIHW."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, out):
+        ctx.save_for_backward(x, w)
+        ctx.stride, ctx.has_bias = stride, bias is not None
+        return conv2d_forward_raw(x, w, bias, stride, out=out)
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = Conv2dInputGradFn.apply(gy, w, ctx.stride, x.shape[1], x.shape[2], x.shape[3])
+        if ctx.needs_input_grad[1]:
+            gw = Conv2dWeightGradFn.apply(x, gy, w.shape, ctx.stride)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = channel_sum(gy)
+        return gx, gw, gb, None, None
+
+
+class Conv2dInputGradFn(Function):
+    """gx = d conv2d / d x contracted with gy.  Returns (N, H, W, pad32(Ci))."""
+
+    @staticmethod
+    def forward(ctx, gy, w, stride, H, W, Cx):
+        gyp = _padded_gy(gy)
+        ctx.save_for_backward(gy, w)
+        ctx.stride = stride
+        pg, N, Ho, Wo, Cg, ldg = nhwc(gyp)
+        Co, Ci, KH, KW = w.shape
+        wp = pack_weight(w, False, 32)
+        if wp.shape[2] != Cg:
+            raise ValueError(f"conv2d input-grad: gy has {Cg} channels, packed K is {wp.shape[2]}")
+        gx = new_nhwc(N, H, W, Cx, gy.device)
+        if Cx > Ci:
+            gx[..., Ci:].zero_()
+        pgx, _, _, _, _, ldgx = nhwc(gx)
+        call("lhg_conv2d_backward_input", pg, N, H, W, Cg, ldg, ptr(wp), wp.shape[1], KH, KW, stride, pgx, Ci, ldgx, stream_ptr())
+        return gx
+
+    @staticmethod
+    def backward(ctx, ggx):
+        gy, w = ctx.saved_tensors
+        g_gy = g_w = None
+        if ctx.needs_input_grad[0]:
+            g_gy = Conv2dFn.apply(ggx, w, None, ctx.stride, None)
+        if ctx.needs_input_grad[1]:
+            g_w = Conv2dWeightGradFn.apply(ggx, gy, w.shape, ctx.stride)
+        return g_gy, g_w, None, None, None, None
+
+
+class Conv2dWeightGradFn(Function):
+    """gw (OIHW) = sum over pixels of x (gathered) outer gy."""
+
+    @staticmethod
+    def forward(ctx, x, gy, wshape, stride):
+        ctx.save_for_backward(x, gy)
+        ctx.stride, ctx.wshape = stride, tuple(wshape)
+        Co, Ci, KH, KW = wshape
+        gyp = _padded_gy(gy, 4)
+        px, N, H, W, Cx, ldx = nhwc(x)
+        pg, _, _, _, Cg, ldg = nhwc(gyp)
+        lib = native.load()
+        S = lib.lhg_conv2d_wgrad_splits(N, H, W, Cx, Cg, KH, KW, stride)
+        ci_pad, co_pad = pad_to(Cx, 64), pad_to(Cg, 64)
+        slabs = torch.empty((S, KH * KW, ci_pad, co_pad), dtype=torch.float32, device=x.device)
+        call("lhg_conv2d_backward_weight", px, N, H, W, Cx, ldx, pg, Cg, ldg, KH, KW, stride, ptr(slabs), S, ci_pad, co_pad, stream_ptr())
+        gw = torch.empty(ctx.wshape, dtype=torch.float32, device=x.device)
+        call("lhg_wgrad_reduce", ptr(slabs), S, KH * KW, ci_pad, co_pad, ptr(gw), Co, Ci, 1, stream_ptr())
+        return gw
+
+    @staticmethod
+    def backward(ctx, ggw):
+        x, gy = ctx.saved_tensors
+        g_x = g_gy = None
+        if ctx.needs_input_grad[0]:
+            g_x = Conv2dInputGradFn.apply(gy, ggw, ctx.stride, x.shape[1], x.shape[2], x.shape[3])
+        if ctx.needs_input_grad[1]:
+            g_gy = Conv2dFn.apply(x, ggw, None, ctx.stride, None)
+        return g_x, g_gy, None, None
+
+
+class ConvTranspose2x2Fn(Function):
+    """y = conv_transpose2d(x, w, stride=2) + bias with kernel 2.  w IOHW (Cin, Cout, 2, 2)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, out):
+        ctx.save_for_backward(x, w)
+        ctx.has_bias = bias is not None
+        px, N, H, W, Ci, ldx = nhwc(x)
+        Ciw, Co, KH, KW = w.shape
+        assert (KH, KW) == (2, 2) and Ciw == Ci, "conv_transpose2x2: weight/input mismatch"
+        wp = pack_weight(w, False)  # rows = Cout, K = Cin
+        y = _resolve_out(out, (N, 2 * H, 2 * W, Co), x.device)
+        py, _, _, _, _, ldy = nhwc(y)
+        call("lhg_conv_transpose2x2_forward", px, N, H, W, Ci, ldx, ptr(wp), wp.shape[1], py, Co, ldy, ptr(bias), stream_ptr())
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w = ctx.saved_tensors
+        gx = gw = gb = None
+        Ci, Co = w.shape[0], w.shape[1]
+        if ctx.needs_input_grad[0]:
+            pg, N, H2, W2, Cg, ldg = nhwc(gy)
+            wp = pack_weight(w, True)  # rows = Cin, K = Cout
+            gx = new_nhwc(N, H2 // 2, W2 // 2, Ci, gy.device)
+            pgx, _, _, _, _, ldgx = nhwc(gx)
+            call("lhg_conv_transpose2x2_backward_input", pg, N, H2 // 2, W2 // 2, Cg, ldg, ptr(wp), wp.shape[1], pgx, Ci, ldgx, stream_ptr())
+        if ctx.needs_input_grad[1]:
+            px, N, H, W, Cx, ldx = nhwc(x)
+            pg, _, _, _, Cg, ldg = nhwc(gy)
+            lib = native.load()
+            S = lib.lhg_conv_transpose2x2_wgrad_splits(N, H, W, Cx, Cg)
+            ci_pad, co_pad = pad_to(Cx, 64), pad_to(Cg, 64)
+            slabs = torch.empty((S, 4, ci_pad, co_pad), dtype=torch.float32, device=x.device)
+            call("lhg_conv_transpose2x2_backward_weight", px, N, H, W, Cx, ldx, pg, Cg, ldg, ptr(slabs), S, ci_pad, co_pad, stream_ptr())
+            gw = torch.empty_like(w)
+            call("lhg_wgrad_reduce", ptr(slabs), S, 4, ci_pad, co_pad, ptr(gw), Ci, Co, 0, stream_ptr())
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = channel_sum(gy)
+        return gx, gw, gb, None
+
+
+def channel_sum(t):
+    """sum over (N,H,W) of an NHWC tensor -> (C,).  Used for bias gradients (linear in t)."""
+    return ChannelSumFn.apply(t)
+
+
+class ChannelSumFn(Function):
+    @staticmethod
+    def forward(ctx, t):
+        p, N, H, W, Cc, ld = nhwc(t)
+        ctx.shape = t.shape
+        out = torch.empty((Cc,), dtype=torch.float32, device=t.device)
+        ws = torch.empty((2048 * Cc,), dtype=torch.float32, device=t.device)
+        call("lhg_channel_sum", p, N * H * W, Cc, ld, ptr(out), ptr(ws), stream_ptr())
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return g.view(1, 1, 1, -1).expand(ctx.shape)
+
+
+# --------------------------------------------------------------------------- activations
+class ActGradFn(Function):
+    """g * act'(y) with the mask read from the forward output (linear in g)."""
+
+    @staticmethod
+    def forward(ctx, g, y, act, slope):
+        ctx.act, ctx.slope = act, slope
+        ctx.save_for_backward(y)
+        pg, N, H, W, Cc, ldg = nhwc(g)
+        py, _, _, _, _, ldy = nhwc(y)
+        out = new_nhwc(N, H, W, Cc, g.device)
+        call("lhg_act_backward", pg, ldg, py, ldy, N * H * W, Cc, act, float(slope), ptr(out), Cc, stream_ptr())
+        return out
+
+    @staticmethod
+    def backward(ctx, gg):
+        (y,) = ctx.saved_tensors
+        return ActGradFn.apply(gg, y, ctx.act, ctx.slope), None, None, None
+
+
+class ConvBiasActFn(Function):
+    """y = act(conv2d(x, w) + bias) with the activation fused in the GEMM epilogue
+    (critic block1, ref: discriminator.py:16-19)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, act, slope):
+        y = conv2d_forward_raw(x, w, bias, stride, act=act, slope=slope)
+        ctx.save_for_backward(x, w, y)
+        ctx.stride, ctx.act, ctx.slope, ctx.has_bias = stride, act, slope, bias is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        g = ActGradFn.apply(gy, y, ctx.act, ctx.slope)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = Conv2dInputGradFn.apply(g, w, ctx.stride, x.shape[1], x.shape[2], x.shape[3])
+        if ctx.needs_input_grad[1]:
+            gw = Conv2dWeightGradFn.apply(x, g, w.shape, ctx.stride)
+        if ctx.has_bias and ctx.needs_input_grad[2]:
+            gb = channel_sum(g)
+        return gx, gw, gb, None, None, None
+
+
+# --------------------------------------------------------------------------- batch norm
+def _bn_ws(Cc, device, mult=8192):
+    return torch.empty((mult * Cc,), dtype=torch.float32, device=device)
+
+
+class BatchNormTrainFn(Function):
+    """y = act(BN_batchstats(x) * gamma + beta [+ res]); updates running stats in place.
+    ref: F.batch_norm(training=True) via nn.LazyBatchNorm2d, neural_network_components.py:27-31;
+    nn.BatchNorm2d discriminator.py:39."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, res, act, slope, out):
+        px, N, H, W, Cc, ldx = nhwc(x)
+        pixels = N * H * W
+        stats = torch.empty((2 * Cc,), dtype=torch.float32, device=x.device)
+        call("lhg_bn_stats", px, pixels, Cc, ldx, ptr(stats), ptr(running_mean), ptr(running_var), BN_MOMENTUM, BN_EPS,
+             ptr(_bn_ws(Cc, x.device, 4096)), stream_ptr())
+        y = _resolve_out(out, (N, H, W, Cc), x.device)
+        py, _, _, _, _, ldy = nhwc(y)
+        pres, ldres = (None, 0)
+        if res is not None:
+            pres, _, _, _, _, ldres = nhwc(res)
+        call("lhg_bn_apply", px, ldx, pixels, Cc, ptr(stats), ptr(gamma), ptr(beta), pres, ldres, act, float(slope), py, ldy, stream_ptr())
+        ctx.save_for_backward(x, y, gamma, stats)
+        ctx.act, ctx.slope, ctx.has_res = act, slope, res is not None
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, y, gamma, stats = ctx.saved_tensors
+        gx, gres, ggamma, gbeta = BatchNormGradFn.apply(gy, x, y, gamma, stats, ctx.act, ctx.slope, ctx.has_res)
+        return gx, ggamma, gbeta, None, None, (gres if ctx.has_res else None), None, None, None
+
+
+class BatchNormGradFn(Function):
+    """First backward of BatchNormTrainFn as a differentiable op (needed by the gradient penalty)."""
+
+    @staticmethod
+    def forward(ctx, gy, x, y, gamma, stats, act, slope, want_res):
+        pg, N, H, W, Cc, ldg = nhwc(gy)
+        px, _, _, _, _, ldx = nhwc(x)
+        py, _, _, _, _, ldy = nhwc(y)
+        pixels = N * H * W
+        gx = new_nhwc(N, H, W, Cc, gy.device)
+        gres = new_nhwc(N, H, W, Cc, gy.device) if want_res else None
+        ggamma = torch.empty((Cc,), dtype=torch.float32, device=gy.device)
+        gbeta = torch.empty((Cc,), dtype=torch.float32, device=gy.device)
+        call("lhg_bn_backward", pg, ldg, px, ldx, py, ldy, pixels, Cc, ptr(stats), ptr(gamma), act, float(slope),
+             ptr(gx), Cc, ptr(gres), Cc, ptr(ggamma), ptr(gbeta), ptr(_bn_ws(Cc, gy.device)), stream_ptr())
+        ctx.save_for_backward(gy, x, y, gamma, stats)
+        ctx.act, ctx.slope, ctx.want_res = act, slope, want_res
+        ctx.set_materialize_grads(False)
+        if gres is None:
+            gres = torch.empty(0, device=gy.device)
+            ctx.mark_non_differentiable(gres)
+        return gx, gres, ggamma, gbeta
+
+    @staticmethod
+    def backward(ctx, ggx, ggres, gggamma, ggbeta):
+        gy, x, y, gamma, stats = ctx.saved_tensors
+        if ggres is not None or gggamma is not None or ggbeta is not None:
+            raise NotImplementedError("double backward through the residual / gamma / beta gradients of batch norm "
+                                      "is not part of the hot path (the gradient penalty differentiates d/dx only)")
+        if ggx is None:
+            return None, None, None, None, None, None, None, None
+        N, H, W, Cc = x.shape
+        pixels = N * H * W
+        ggx_d, gy_d, x_d, y_d = _dense(ggx), _dense(gy), _dense(x), _dense(y)
+        ggy = new_nhwc(N, H, W, Cc, x.device)
+        gx2 = new_nhwc(N, H, W, Cc, x.device)
+        ggamma2 = torch.empty((Cc,), dtype=torch.float32, device=x.device)
+        call("lhg_bn_backward_backward", ptr(ggx_d), ptr(gy_d), ptr(x_d), ptr(y_d), pixels, Cc, ptr(stats), ptr(gamma),
+             ctx.act, float(ctx.slope), ptr(ggy), ptr(gx2), ptr(ggamma2), ptr(_bn_ws(Cc, x.device, 5 * 4096 + 8)), stream_ptr())
+        return ggy, gx2, None, ggamma2, None, None, None, None
+
+
+def batch_norm_eval_affine(gamma, beta, running_mean, running_var):
+    """Per-channel (scale, shift) of an eval-mode BN, folded into the conv epilogue."""
+    scale = gamma / torch.sqrt(running_var + BN_EPS)
+    return scale, beta - running_mean * scale
+
+
+# --------------------------------------------------------------------------- pooling
+class MaxPool2x2Fn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        px, N, H, W, Cc, ldx = nhwc(x)
+        y = new_nhwc(N, H // 2, W // 2, Cc, x.device)
+        call("lhg_maxpool2x2_forward", px, N, H, W, Cc, ldx, ptr(y), Cc, stream_ptr())
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        px, N, H, W, Cc, ldx = nhwc(x)
+        pg, _, _, _, _, ldg = nhwc(gy)
+        gx = new_nhwc(N, H, W, Cc, x.device)
+        call("lhg_maxpool2x2_backward", px, ldx, pg, ldg, N, H, W, Cc, ptr(gx), Cc, stream_ptr())
+        return gx
+
+
+# --------------------------------------------------------------------------- sigmoid head (planar output)
+class SigmoidHeadFn(Function):
+    """y (N, Co, H, W) = sigmoid(conv1x1(x) + bias), written planar by the GEMM epilogue.
+    ref: neural_network_components.py:292-295."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        y = conv2d_forward_raw(x, w, bias, 1, act=ACT_SIGMOID, planar=True)
+        ctx.save_for_backward(x, w, y)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        x, w, y = ctx.saved_tensors
+        g_pre = gy * y * (1 - y)  # (N, Co, H, W): 6 planes, negligible
+        g_nhwc = ToNHWC.apply(g_pre, 32)
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gx = Conv2dInputGradFn.apply(g_nhwc, w, 1, x.shape[1], x.shape[2], x.shape[3])
+        if ctx.needs_input_grad[1]:
+            gw = Conv2dWeightGradFn.apply(x, g_nhwc, w.shape, 1)
+        if ctx.needs_input_grad[2]:
+            gb = g_pre.sum(dim=(0, 2, 3))
+        return gx, gw, gb
+
+
+# --------------------------------------------------------------------------- optimiser
+def adam_step_(p, g, m, v, lr, beta1, beta2, eps, step):
+    call("lhg_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps), int(step), stream_ptr())
+    bump_version(p)
+
+
+_ = ctypes  # keep the import explicit: AsmFilter users import ctypes through native

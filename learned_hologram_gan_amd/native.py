@@ -1,0 +1,126 @@
+"""ctypes binding of liblhg_hip.so (C ABI: include/lhg_hip.h).
+
+The product path has no CPU or eager-PyTorch fallback: if the library is missing, fails to load
+or lacks a symbol, ``load()`` raises.  Every wrapper passes raw device pointers and PyTorch's
+current HIP stream, and turns a non-zero status into ``RuntimeError(lhg_last_error())``.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+import re
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "liblhg_hip.so")
+HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "lhg_hip.h")
+
+ACT_NONE, ACT_RELU, ACT_LEAKY, ACT_SIGMOID = 0, 1, 2, 3
+IN_POLAR, IN_PHASE, IN_COMPLEX = 0, 1, 2
+OUT_COMPLEX, OUT_ABS_ANGLE, OUT_ABS = 0, 1, 2
+F_NONE, F_MUL, F_MUL_CONJ, F_DIV, F_DIV_CONJ = 0, 1, 2, 3, 4
+
+_p, _i, _f, _ll, _sz = C.c_void_p, C.c_int, C.c_float, C.c_longlong, C.c_size_t
+
+
+class AsmFilter(C.Structure):
+    _fields_ = [("f1", _p), ("f1_index", _p), ("f1_op", _i), ("f2", _p), ("f2_index", _p), ("f2_op", _i)]
+
+
+# name -> argtypes (restype is int unless listed in _RESTYPE)
+_SIGNATURES = {
+    "lhg_abi_version": [],
+    "lhg_last_error": [],
+    "lhg_nchw_to_nhwc": [_p, _p, _i, _i, _i, _i, _i, _p],
+    "lhg_nhwc_to_nchw": [_p, _i, _p, _i, _i, _i, _i, _p],
+    "lhg_pack_weight": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _p],
+    "lhg_conv2d_forward": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _i, _i, _f, _i, _p],
+    "lhg_conv2d_backward_input": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p],
+    "lhg_conv2d_wgrad_splits": [_i, _i, _i, _i, _i, _i, _i, _i],
+    "lhg_conv2d_backward_weight": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _p],
+    "lhg_conv_transpose2x2_forward": [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _i, _p, _p],
+    "lhg_conv_transpose2x2_backward_input": [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _i, _p],
+    "lhg_conv_transpose2x2_wgrad_splits": [_i, _i, _i, _i, _i],
+    "lhg_conv_transpose2x2_backward_weight": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _i, _i, _i, _p],
+    "lhg_wgrad_reduce": [_p, _i, _i, _i, _i, _p, _i, _i, _i, _p],
+    "lhg_channel_sum": [_p, _ll, _i, _i, _p, _p, _p],
+    "lhg_bn_stats": [_p, _ll, _i, _i, _p, _p, _p, _f, _f, _p, _p],
+    "lhg_bn_apply": [_p, _i, _ll, _i, _p, _p, _p, _p, _i, _i, _f, _p, _i, _p],
+    "lhg_bn_backward": [_p, _i, _p, _i, _p, _i, _ll, _i, _p, _p, _i, _f, _p, _i, _p, _i, _p, _p, _p, _p],
+    "lhg_bn_backward_backward": [_p, _p, _p, _p, _ll, _i, _p, _p, _i, _f, _p, _p, _p, _p, _p],
+    "lhg_maxpool2x2_forward": [_p, _i, _i, _i, _i, _i, _p, _i, _p],
+    "lhg_maxpool2x2_backward": [_p, _i, _p, _i, _i, _i, _i, _i, _p, _i, _p],
+    "lhg_act_backward": [_p, _i, _p, _i, _ll, _i, _i, _f, _p, _i, _p],
+    "lhg_asm_propagate": [_p, _p, _i, _f, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _sz, _p, _p, _p],
+    "lhg_asm_to_spectrum": [_p, _p, _i, _f, _i, _i, _i, _i, _i, _p, _p, _p, _sz, _p, _p, _p],
+    "lhg_asm_from_spectrum": [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _sz, _p, _p, _p],
+    "lhg_fft_twiddles": [_p, _i, _p],
+    "lhg_symconv_field": [_p, _i, _i, _i, _p, _p, _p, _p, _p],
+    "lhg_double_phase_encode": [_p, _p, _i, _i, _i, _p, _p],
+    "lhg_adam_step": [_p, _p, _p, _p, _ll, _f, _f, _f, _f, _i, _p],
+}
+_RESTYPE = {"lhg_last_error": C.c_char_p}
+
+_lib = None
+
+
+class NativeLibraryError(RuntimeError):
+    pass
+
+
+def declared_symbols(header_path: str = HEADER_PATH):
+    """Function names declared in include/lhg_hip.h (used by the CPU test that checks that the
+    library exports exactly the declared ABI)."""
+    text = open(header_path).read()
+    text = re.sub(r"/\*.*?\*/", "", text, flags=re.S)
+    return sorted(set(re.findall(r"\b(lhg_[a-z0-9_]+)\s*\(", text)))
+
+
+def load():
+    """Load the gfx950 library; raises NativeLibraryError when it cannot be used."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise NativeLibraryError(
+            f"{LIB_PATH} is missing: build it with `python __graft_entry__.py` "
+            "(hipcc --offload-arch=gfx950). There is no CPU / eager fallback for the hot path."
+        )
+    try:
+        lib = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover
+        raise NativeLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    for name, argtypes in _SIGNATURES.items():
+        try:
+            fn = getattr(lib, name)
+        except AttributeError as e:
+            raise NativeLibraryError(f"{LIB_PATH} does not export {name}") from e
+        fn.argtypes = argtypes
+        fn.restype = _RESTYPE.get(name, C.c_int)
+    got = lib.lhg_abi_version()
+    if got != 1:
+        raise NativeLibraryError(f"ABI version mismatch: library {got}, binding 1")
+    _lib = lib
+    return lib
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def ptr(t):
+    if t is None:
+        return None
+    if not t.is_cuda:
+        raise NativeLibraryError("HIP op called with a CPU tensor: the hot path runs on the GPU only (no CPU fallback)")
+    return t.data_ptr()
+
+
+def call(name: str, *args):
+    lib = load()
+    rc = getattr(lib, name)(*args)
+    if rc != 0:
+        msg = lib.lhg_last_error().decode("utf-8", "replace")
+        raise RuntimeError(f"{name} failed ({rc}): {msg}")

@@ -1,0 +1,188 @@
+"""Network building blocks with the reference's class names and ``state_dict`` schema
+(ref: learnedMethodForHologram/neural_network_components.py:6-95, 241-315), computed by the
+HIP ops of hip_ops.py on NHWC activations.
+
+``nn.Conv2d`` / ``nn.BatchNorm2d`` / ``nn.ConvTranspose2d`` objects are used as PARAMETER
+CONTAINERS only (same key names, OIHW / IOHW fp32 shapes, running statistics and
+``num_batches_tracked`` as the reference checkpoints); their ``forward`` is never called.
+The reference's lazy layers infer ``in_channels`` on the first call; here it is an explicit
+constructor argument with the value the hot path uses.
+"""
+
+from __future__ import annotations
+
+import warnings
+
+import torch
+from torch import nn
+
+from . import hip_ops as ops
+from .hip_ops import ACT_NONE, ACT_RELU, OutSlot
+
+
+def _bn_eval_affine(bn: nn.BatchNorm2d):
+    return ops.batch_norm_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var)
+
+
+def _warn_eval_grad(name):
+    warnings.warn(f"{name}: eval-mode forward runs the fused inference kernels and is not differentiable "
+                  "(the reference only evaluates under torch.no_grad())", stacklevel=3)
+
+
+class ResidualBlock(nn.Module):
+    """relu(BN2(conv3x3(relu(BN1(conv3x3(X))))) + conv1x1(X)). ref: neural_network_components.py:6-32."""
+
+    def __init__(self, num_channels, use_1x1conv=False, strides=1, in_channels=None):
+        super().__init__()
+        in_channels = num_channels if in_channels is None else in_channels
+        self.in_channels, self.num_channels, self.strides = in_channels, num_channels, strides
+        self.convolution_layer_1 = nn.Conv2d(in_channels, num_channels, kernel_size=3, padding=(1, 1), stride=strides)
+        self.convolution_layer_2 = nn.Conv2d(num_channels, num_channels, kernel_size=3, padding=(1, 1))
+        self.convolution_layer_3 = nn.Conv2d(in_channels, num_channels, kernel_size=1, stride=strides) if use_1x1conv else None
+        self.batch_norm_layer_1 = nn.BatchNorm2d(num_channels)
+        self.batch_norm_layer_2 = nn.BatchNorm2d(num_channels)
+
+    # NHWC in (channels padded to 32), NHWC out; `out` optionally names the destination view
+    def forward_nhwc(self, x, out: OutSlot | None = None):
+        c1, c2, c3 = self.convolution_layer_1, self.convolution_layer_2, self.convolution_layer_3
+        b1, b2 = self.batch_norm_layer_1, self.batch_norm_layer_2
+        if self.training:
+            y = ops.Conv2dFn.apply(x, c1.weight, c1.bias, self.strides, None)
+            y = ops.BatchNormTrainFn.apply(y, b1.weight, b1.bias, b1.running_mean, b1.running_var, None, ACT_RELU, 0.0, None)
+            y = ops.Conv2dFn.apply(y, c2.weight, c2.bias, 1, None)
+            skip = ops.Conv2dFn.apply(x, c3.weight, c3.bias, self.strides, None) if c3 is not None else x
+            b1.num_batches_tracked += 1
+            b2.num_batches_tracked += 1
+            return ops.BatchNormTrainFn.apply(y, b2.weight, b2.bias, b2.running_mean, b2.running_var, skip, ACT_RELU, 0.0, out)
+        if torch.is_grad_enabled() and (x.requires_grad or c1.weight.requires_grad):
+            _warn_eval_grad("ResidualBlock")
+        with torch.no_grad():
+            s1, t1 = _bn_eval_affine(b1)
+            s2, t2 = _bn_eval_affine(b2)
+            y = ops.conv2d_forward_raw(x, c1.weight, c1.bias, self.strides, act=ACT_RELU, scale=s1, shift=t1)
+            skip = ops.conv2d_forward_raw(x, c3.weight, c3.bias, self.strides) if c3 is not None else x
+            return ops.conv2d_forward_raw(y, c2.weight, c2.bias, 1, act=ACT_RELU, scale=s2, shift=t2, res=skip, out=out)
+
+    def forward(self, X):
+        x = ops.ToNHWC.apply(X, ops.pad_to(X.shape[1], 32))
+        return ops.ToNCHW.apply(self.forward_nhwc(x), self.num_channels)
+
+
+class SymmetricConv2d(nn.Module):
+    """1-channel 3x3 conv whose taps share one parameter per squared distance from the centre
+    (index 0 centre, 1 edge, 2 corner) + scalar bias. ref: neural_network_components.py:35-75.
+    Evaluated as a 9-term shifted sum (pointwise on a 384^2 plane), not as a GEMM."""
+
+    def __init__(self, kernel_size=3, padding=1):
+        super().__init__()
+        if kernel_size != 3 or padding != 1:
+            raise NotImplementedError("the hot path uses kernel_size=3, padding=1")
+        self.kernel_size, self.padding, self.center = kernel_size, padding, kernel_size // 2
+        self.params = nn.Parameter(torch.abs(torch.randn(3)))
+        self.bias = nn.Parameter(torch.zeros(1))
+        self.distance_map = torch.tensor([[2, 1, 2], [1, 0, 1], [2, 1, 2]], dtype=torch.long)  # plain attribute, as in the reference
+
+    def forward(self, x):
+        p = torch.nn.functional.pad(x, (1, 1, 1, 1))
+        H, W = x.shape[-2], x.shape[-1]
+        win = lambda dy, dx: p[..., 1 + dy:1 + dy + H, 1 + dx:1 + dx + W]  # noqa: E731
+        edge = win(-1, 0) + win(1, 0) + win(0, -1) + win(0, 1)
+        corner = win(-1, -1) + win(-1, 1) + win(1, -1) + win(1, 1)
+        return self.params[0] * x + self.params[1] * edge + self.params[2] * corner + self.bias
+
+
+class ChannelWiseSymmetricConv(nn.Module):
+    """One SymmetricConv2d per colour. ref: neural_network_components.py:78-95."""
+
+    def __init__(self, kernel_size=3, padding=1):
+        super().__init__()
+        self.conv_r = SymmetricConv2d(kernel_size, padding)
+        self.conv_g = SymmetricConv2d(kernel_size, padding)
+        self.conv_b = SymmetricConv2d(kernel_size, padding)
+
+    def forward(self, x):
+        return torch.cat((self.conv_r(x[:, 0:1]), self.conv_g(x[:, 1:2]), self.conv_b(x[:, 2:3])), dim=1)
+
+    def taps_and_bias(self):
+        """(3,3) taps [colour][centre, edge, corner] and (3,) biases for the fused inference kernel."""
+        convs = (self.conv_r, self.conv_g, self.conv_b)
+        return torch.stack([c.params for c in convs]).contiguous(), torch.cat([c.bias for c in convs]).contiguous()
+
+
+class fakeChannelWiseSymmetricConv(nn.Module):
+    def __init__(self, kernel_size=3, padding=1):
+        super().__init__()
+
+    def forward(self, x):
+        return x
+
+
+class UNet(nn.Module):
+    """Four-level residual UNet, widths 64..1024, MaxPool 2x2 down, ConvTranspose 2x2 up, 1x1 sigmoid head.
+    ref: neural_network_components.py:241-315.  Skip concatenations are channel slices of one NHWC
+    buffer written in place by their producers (skip first, as torch.cat((encoderN, up), 1))."""
+
+    def __init__(self, output_channels=6, in_channels=4):
+        super().__init__()
+        self.output_channels, self.in_channels = output_channels, in_channels
+        pool = lambda: nn.MaxPool2d(kernel_size=2, stride=2)  # noqa: E731  (parameter-less; keeps the Sequential indices)
+        self.encoder1 = nn.Sequential(self.conv_block(64, in_channels))
+        self.encoder2 = nn.Sequential(pool(), self.conv_block(128, 64))
+        self.encoder3 = nn.Sequential(pool(), self.conv_block(256, 128))
+        self.encoder4 = nn.Sequential(pool(), self.conv_block(512, 256))
+        self.bottleneck = nn.Sequential(pool(), self.conv_block(1024, 512), nn.ConvTranspose2d(1024, 512, kernel_size=2, stride=2))
+        self.decoder1 = nn.Sequential(self.conv_block(512, 1024), nn.ConvTranspose2d(512, 256, kernel_size=2, stride=2))
+        self.decoder2 = nn.Sequential(self.conv_block(256, 512), nn.ConvTranspose2d(256, 128, kernel_size=2, stride=2))
+        self.decoder3 = nn.Sequential(self.conv_block(128, 256), nn.ConvTranspose2d(128, 64, kernel_size=2, stride=2))
+        self.decoder4 = self.conv_block(64, 128)
+        self.final_layer = nn.Sequential(nn.Conv2d(64, output_channels, kernel_size=1), nn.Sigmoid())
+
+    def conv_block(self, out_channels, in_channels=None):
+        return nn.Sequential(ResidualBlock(out_channels, use_1x1conv=True, in_channels=in_channels))
+
+    @staticmethod
+    def _block(seq_entry):
+        return seq_entry[0] if isinstance(seq_entry, nn.Sequential) else seq_entry
+
+    def _up(self, convt: nn.ConvTranspose2d, x, out: OutSlot):
+        if self.training:
+            return ops.ConvTranspose2x2Fn.apply(x, convt.weight, convt.bias, out)
+        with torch.no_grad():
+            return ops.ConvTranspose2x2Fn.apply(x, convt.weight, convt.bias, out)
+
+    def _cat(self, skip, up, buf):
+        if self.training:
+            return ops.CatViewsFn.apply(skip, up, OutSlot(buf))
+        return buf
+
+    def forward(self, X):
+        if X.shape[1] != self.in_channels or X.shape[2] % 16 or X.shape[3] % 16:
+            raise ValueError(f"UNet expects (B,{self.in_channels},H,W) with H, W multiples of 16, got {tuple(X.shape)}")
+        N, _, H, W = X.shape
+        dev = X.device
+        x = ops.ToNHWC.apply(X, 32)
+        new = lambda h, w, c: torch.empty((N, h, w, c), dtype=torch.float32, device=dev)  # noqa: E731
+        buf4, buf3, buf2, buf1 = new(H, W, 128), new(H // 2, W // 2, 256), new(H // 4, W // 4, 512), new(H // 8, W // 8, 1024)
+        pool = ops.MaxPool2x2Fn.apply
+
+        e1 = self._block(self.encoder1[0]).forward_nhwc(x, OutSlot(buf4[..., :64]))
+        e2 = self._block(self.encoder2[1]).forward_nhwc(pool(e1), OutSlot(buf3[..., :128]))
+        e3 = self._block(self.encoder3[1]).forward_nhwc(pool(e2), OutSlot(buf2[..., :256]))
+        e4 = self._block(self.encoder4[1]).forward_nhwc(pool(e3), OutSlot(buf1[..., :512]))
+        b = self._block(self.bottleneck[1]).forward_nhwc(pool(e4))
+        u = self._up(self.bottleneck[2], b, OutSlot(buf1[..., 512:]))
+        d = self._block(self.decoder1[0]).forward_nhwc(self._cat(e4, u, buf1))
+        u = self._up(self.decoder1[1], d, OutSlot(buf2[..., 256:]))
+        d = self._block(self.decoder2[0]).forward_nhwc(self._cat(e3, u, buf2))
+        u = self._up(self.decoder2[1], d, OutSlot(buf3[..., 128:]))
+        d = self._block(self.decoder3[0]).forward_nhwc(self._cat(e2, u, buf3))
+        u = self._up(self.decoder3[1], d, OutSlot(buf4[..., 64:]))
+        d = self._block(self.decoder4).forward_nhwc(self._cat(e1, u, buf4))
+        head = self.final_layer[0]
+        if self.training:
+            return ops.SigmoidHeadFn.apply(d, head.weight, head.bias)
+        with torch.no_grad():
+            return ops.conv2d_forward_raw(d, head.weight, head.bias, 1, act=ops.ACT_SIGMOID, planar=True)
+
+
+_ = ACT_NONE

@@ -1,0 +1,287 @@
+"""GAN trainer with the reference's constructor / ``train`` keyword set, loss bookkeeping JSON schema
+and checkpoint naming (ref: learnedMethodForHologram/watermelon_hologram/watermelon.py:33-631).
+
+The per-batch body of the reference loop (:207-277) lives in ``train_step`` so that bench.py and
+the parity tests drive exactly what ``train`` runs.  Differences that are deliberate:
+  * hat / target planes come from one fused propagation each (no (2B,3,R,C) spectra in HBM);
+  * both Adam updates are single fused launches over flat parameter buffers;
+  * with torch.distributed initialised, gradients are averaged across ranks (RCCL) with
+    bucketed all-reduces overlapped with backward; BN / loss normalisers stay per replica.
+The VGG19 perceptual term (loss_func.py:12-51) is SURVEY §8f N1: ``perceptual_loss_weight`` must be 0
+unless a perceptual module is supplied.
+"""
+
+from __future__ import annotations
+
+import json
+
+import torch
+import torch.autograd as autograd
+import torch.nn.functional as F
+
+from ..angular_spectrum_method import bandLimitedAngularSpectrumMethod_for_multiple_distances
+from ..distributed import GradSynchronizer
+from ..optim import FlatParams, FusedAdam
+from ..utilities import try_gpu
+from .discriminator import WGANGPDiscriminator192, fakeDiscriminator
+from .generator import Generator
+from .loss_func import fakePerceptualLoss, focal_sincos_phase_gradient_loss, total_variation_loss
+
+LOSS_NAMES = ("focal_phase_gradient_loss", "perceptual_loss", "pixel_loss", "TV_loss", "gan_loss", "G_loss", "D_loss")
+
+
+def psnr(hat, target):
+    """torchmetrics PeakSignalNoiseRatio() defaults: data_range = max(target) - min(target)."""
+    rng = target.max() - target.min()
+    return 10.0 * torch.log10(rng * rng / F.mse_loss(hat, target))
+
+
+def ssim(hat, target, kernel_size=11, sigma=1.5, k1=0.01, k2=0.03):
+    """Gaussian-window SSIM in the torchmetrics default configuration (parity unpinned: torchmetrics
+    is not installed in the build image)."""
+    C = hat.shape[1]
+    rng = torch.maximum(hat.max() - hat.min(), target.max() - target.min())
+    c1, c2 = (k1 * rng) ** 2, (k2 * rng) ** 2
+    ax = torch.arange(kernel_size, dtype=torch.float32, device=hat.device) - (kernel_size - 1) / 2
+    g = torch.exp(-(ax / sigma) ** 2 / 2)
+    g = (g / g.sum()).view(1, 1, -1)
+    win = (g.transpose(1, 2) * g).expand(C, 1, kernel_size, kernel_size).contiguous()
+    pad = (kernel_size - 1) // 2
+    stack = torch.cat((hat, target, hat * hat, target * target, hat * target), 0)
+    mu = F.conv2d(F.pad(stack, (pad, pad, pad, pad), mode="reflect"), win, groups=C)
+    B = hat.shape[0]
+    mx, my, sxx, syy, sxy = mu[:B], mu[B:2 * B], mu[2 * B:3 * B], mu[3 * B:4 * B], mu[4 * B:]
+    vx, vy, cxy = sxx - mx * mx, syy - my * my, sxy - mx * my
+    s = ((2 * mx * my + c1) * (2 * cxy + c2)) / ((mx * mx + my * my + c1) * (vx + vy + c2))
+    return s[..., pad:-pad, pad:-pad].mean()
+
+
+class watermelon:
+    def __init__(self, filter_radius_coefficient=0.5, pad_size=416, kernel_size=3,
+                 distance_stack=torch.linspace(-1.5e-4, 0.0, 8)[:-1], pretrained_model_path_G=None, pretrained_model_path_D=None,
+                 input_shape=(1, 4, 192, 192), cuda=True, perceptual_loss=None):
+        self.device = try_gpu() if cuda else torch.device("cpu")
+        self.distance_stack = distance_stack.to(self.device)
+        self.distance_num = distance_stack.size(0)
+        wl = torch.tensor([638e-9, 520e-9, 450e-9])
+        self.generator = Generator(sample_row_num=input_shape[-2], sample_col_num=input_shape[-1], pad_size=pad_size,
+                                   filter_radius_coefficient=filter_radius_coefficient, kernel_size=kernel_size, pixel_pitch=3.74e-6,
+                                   wave_length=wl, distance=torch.tensor([1e-3]), pretrained_model_path=pretrained_model_path_G)
+        self.discriminator = self._make_discriminator(pretrained_model_path_D)
+        self.perceptual_loss = perceptual_loss if perceptual_loss is not None else fakePerceptualLoss()
+        self._has_perceptual = perceptual_loss is not None
+        self.propagator = bandLimitedAngularSpectrumMethod_for_multiple_distances(
+            sample_row_num=input_shape[-2], sample_col_num=input_shape[-1], distances=distance_stack, pad_size=pad_size,
+            filter_radius_coefficient=filter_radius_coefficient, pixel_pitch=3.74e-6, wave_length=wl, band_limit=False, cuda=True)
+        if pretrained_model_path_G is not None:
+            print(f"Generator loaded from {pretrained_model_path_G}")
+        if pretrained_model_path_D is not None:
+            print(f"Discriminator loaded from {pretrained_model_path_D}")
+        self._opt_G = self._opt_D = self._sync_G = self._sync_D = None
+
+    def _make_discriminator(self, path):
+        return WGANGPDiscriminator192(pretrained_model_path=path, cuda=True)
+
+    # ------------------------------------------------------------------ configuration of one run
+    def configure(self, phs_gradient_loss_weight=1, perceptual_loss_weight=1.0, pixel_loss_weight=1.0, TV_loss_weight=1e-3,
+                  discriminator_loss_weight=1.0, lr_G=1e-3, lr_D=1e-3, discriminator_train_ratio=2, discriminator_lambda=10,
+                  grad_buckets=4):
+        if perceptual_loss_weight and not self._has_perceptual:
+            raise NotImplementedError("the VGG19 perceptual loss is not built yet (SURVEY §8f N1): pass perceptual_loss_weight=0 "
+                                      "or supply a perceptual module")
+        self.phs_gradient_loss_weight, self.perceptual_loss_weight = phs_gradient_loss_weight, perceptual_loss_weight
+        self.pixel_loss_weight, self.TV_loss_weight = pixel_loss_weight, TV_loss_weight
+        self.discriminator_loss_weight = discriminator_loss_weight
+        self.discriminator_train_ratio, self.discriminator_lambda = discriminator_train_ratio, discriminator_lambda
+        self.generator.to(self.device)
+        flat_G = FlatParams(self.generator)
+        self._opt_G = FusedAdam(flat_G, lr=lr_G)
+        self._sync_G = GradSynchronizer(flat_G.params, flat_G.offsets, flat_G.grad, grad_buckets)
+        trainable_D = [p for p in self.discriminator.parameters() if p.requires_grad]
+        if discriminator_train_ratio > 0 and trainable_D and isinstance(self.discriminator, WGANGPDiscriminator192):
+            flat_D = FlatParams(self.discriminator)
+            self._opt_D = FusedAdam(flat_D, lr=lr_D)
+            self._sync_D = GradSynchronizer(flat_D.params, flat_D.offsets, flat_D.grad, max(1, grad_buckets // 2))
+        else:
+            self._opt_D = self._sync_D = None
+        self.train_losses_tensor = torch.zeros(7, device=self.device)
+        self.train_metrics_tensor = torch.zeros(2, device=self.device)
+
+    # ------------------------------------------------------------------ pieces of the step
+    def compute_gradient_penalty(self, real_samples, fake_samples, alpha=None):
+        """ref: watermelon.py:458-477."""
+        if alpha is None:
+            alpha = torch.rand(real_samples.size(0), 1, 1, 1).to(self.device)
+        interpolates = (alpha * real_samples + ((1 - alpha) * fake_samples)).requires_grad_(True)
+        d_interpolates = self.discriminator(interpolates)
+        gradients = autograd.grad(outputs=d_interpolates, inputs=interpolates, grad_outputs=torch.ones_like(d_interpolates),
+                                  create_graph=True, retain_graph=True, only_inputs=True)[0]
+        gradients = gradients.view(gradients.size(0), -1)
+        return ((gradients.norm(2, dim=1) - 1) ** 2).mean()
+
+    def G_loss(self, hat_amps, target_amps, hat_phs, target_phs, loss_from_discriminator, recorder=None):
+        """ref: watermelon.py:418-445."""
+        phs_loss = focal_sincos_phase_gradient_loss(hat_phs, target_phs) * self.phs_gradient_loss_weight
+        perceptual = self.perceptual_loss(hat_amps, target_amps) * self.perceptual_loss_weight
+        pixel = F.mse_loss(hat_amps, target_amps) * self.pixel_loss_weight
+        tv = total_variation_loss(hat_amps, target_amps) * self.TV_loss_weight
+        gan = loss_from_discriminator * self.discriminator_loss_weight
+        loss = phs_loss + perceptual + pixel + tv + gan
+        if recorder is not None:
+            with torch.no_grad():
+                recorder += torch.stack([t.detach().reshape(()).float() for t in (phs_loss, perceptual, pixel, tv, gan, loss)]
+                                        + [torch.zeros((), device=recorder.device)])
+        return loss
+
+    def record_metrics(self, hat_amps, target_amps, recorder=None):
+        with torch.no_grad():
+            recorder += torch.stack([psnr(hat_amps, target_amps), ssim(hat_amps, target_amps)])
+
+    def reconstruct(self, RGBD, target_amp, target_phs, plane_indices=None):
+        """G forward + hat/target amplitude and phase at one plane per sample (watermelon.py:216-241)."""
+        POH = self.generator(RGBD)
+        if plane_indices is None:
+            plane_indices = self.propagator.draw_indices(RGBD.size(0))
+        hat_a, hat_p, tgt_a, tgt_p = self.propagator.reconstruct_planes(self.generator.part2.propagator, POH, target_amp, target_phs,
+                                                                         plane_indices)
+        return POH, hat_a, tgt_a, hat_p, tgt_p
+
+    def train_step(self, RGBD, target_amp, target_phs, plane_indices=None, gp_alphas=None):
+        """One batch of the reference loop (watermelon.py:207-277).  Returns detached tensors for logging."""
+        if self._opt_G is None:
+            raise RuntimeError("call configure(...) (or train(...)) before train_step")
+        ratio = self.discriminator_train_ratio if self._opt_D is not None else 0
+        POH, hat_amps, target_amps, hat_phases, target_phases = self.reconstruct(RGBD, target_amp, target_phs, plane_indices)
+        fake = hat_amps.detach()
+        d_total = torch.zeros((), device=self.device)
+        for it in range(ratio):
+            real_validity = self.discriminator(target_amps)
+            fake_validity = self.discriminator(fake)
+            gp = self.compute_gradient_penalty(target_amps, fake, None if gp_alphas is None else gp_alphas[it])
+            d_loss = (-torch.mean(real_validity) + torch.mean(fake_validity)) + self.discriminator_lambda * gp
+            self._opt_D.zero_grad()
+            self._sync_D.start()
+            d_loss.backward(retain_graph=True)
+            self._sync_D.finish()
+            self._opt_D.step()
+            d_total = d_total + d_loss.detach() / ratio
+        loss_from_discriminator = -torch.mean(self.discriminator(hat_amps))
+        g_loss = self.G_loss(hat_amps, target_amps, hat_phases, target_phases, loss_from_discriminator, self.train_losses_tensor)
+        self._opt_G.zero_grad()
+        self._sync_G.start()
+        g_loss.backward()
+        self._sync_G.finish()
+        self._opt_G.step()
+        self.train_losses_tensor[-1] += d_total
+        return dict(POH=POH.detach(), hat_amps=hat_amps.detach(), target_amps=target_amps.detach(), G_loss=g_loss.detach(), D_loss=d_total)
+
+    # ------------------------------------------------------------------ the reference's loop
+    def train(self, data_loader_train, data_loader_val, phs_gradient_loss_weight=1, perceptual_loss_weight=1.0, pixel_loss_weight=1.0,
+              TV_loss_weight=1e-3, discriminator_loss_weight=1.0, epoch_num=2, lr_G=1e-3, lr_D=1e-3, save_path_G=None, save_path_D=None,
+              info_print_interval=100, info_plot_interval=600, loss_metrics_file=None, save_path_img=None, checkpoint_iterval=5,
+              discriminator_train_ratio=2, discriminator_lambda=10, step_scheduler_G_gamma=0.1, step_scheduler_D_gamma=0.9999,
+              visualization_RGBD_AP=None):
+        if save_path_G is None:
+            print("!!!!!!The save path of the generator is not specified, the model will not be saved!!!!!!")
+        if save_path_D is None:
+            print("!!!!!!The save path of the discriminator is not specified, the model will not be saved!!!!!!")
+        self.configure(phs_gradient_loss_weight, perceptual_loss_weight, pixel_loss_weight, TV_loss_weight, discriminator_loss_weight,
+                       lr_G, lr_D, discriminator_train_ratio, discriminator_lambda)
+        self.dict_for_losses_metrics = {
+            "epoch": [], "n_batch_in_epoch": [], "n_train": [], "n_batch": [],
+            "train_losses_tensor": {k: [] for k in LOSS_NAMES}, "train_metrics_tensor": {"PSNR": [], "SSIM": []},
+            "validate_losses_tensor": {k: [] for k in LOSS_NAMES}, "validate_metrics_tensor": {"PSNR": [], "SSIM": []},
+        }
+        losses_last = torch.zeros(7, device=self.device)
+        metrics_last = torch.zeros(2, device=self.device)
+        n_train = n_batch = n_batch_last = 0
+        for epoch in range(epoch_num):
+            self.generator.train()
+            self.discriminator.train()
+            for n_batch_in_epoch, (RGBD, target_amp, target_phs) in enumerate(data_loader_train):
+                n_batch += 1
+                n_train += RGBD.size(0)
+                out = self.train_step(RGBD, target_amp, target_phs)
+                self.record_metrics(out["hat_amps"], out["target_amps"], self.train_metrics_tensor)
+                if n_batch % info_print_interval == 0:
+                    with torch.no_grad():
+                        v_losses, v_metrics = self._validate_generator(data_loader_val)
+                    t_losses = (self.train_losses_tensor - losses_last) / (n_batch - n_batch_last)
+                    t_metrics = (self.train_metrics_tensor - metrics_last) / (n_batch - n_batch_last)
+                    fmt = lambda t: ", ".join(f"{k} {v}" for k, v in zip(LOSS_NAMES, t.tolist()))  # noqa: E731
+                    print(f"epoch {epoch}, batch {n_batch_in_epoch + 1} ({n_train} samples and {n_batch} batches have been trained):\n"
+                          f"      train: {fmt(t_losses)};\n      train: PSNR {t_metrics[0]}, SSIM {t_metrics[1]};\n"
+                          f"      validate: {fmt(v_losses)};\n      validate: PSNR {v_metrics[0]}, SSIM {v_metrics[1]};\n")
+                    self._add_losses_metrics_to_dict(epoch, n_batch_in_epoch, n_train, n_batch, v_losses, v_metrics, t_losses, t_metrics,
+                                                     self.dict_for_losses_metrics)
+                    losses_last, metrics_last = self.train_losses_tensor.clone(), self.train_metrics_tensor.clone()
+                    n_batch_last = n_batch
+            if epoch % checkpoint_iterval == 0:
+                self._checkpoint(save_path_G, save_path_D, loss_metrics_file, suffix=f"_epoch{epoch}")
+        self._checkpoint(save_path_G, save_path_D, loss_metrics_file, suffix="")
+
+    def _checkpoint(self, save_path_G, save_path_D, loss_metrics_file, suffix):
+        """<save_path> and <save_path minus .pth>_epoch{n}.pth (watermelon.py:361-374, 406-412)."""
+        for path, module, name in ((save_path_G, self.generator, "Generator"), (save_path_D, self.discriminator, "Discriminator")):
+            if path is not None:
+                p = path.replace(".pth", f"{suffix}.pth") if suffix else path
+                torch.save(module.state_dict(), p)
+                print(f"{name} saved to {p}")
+        if loss_metrics_file is not None:
+            self._save_losses_metrics_to_dict(loss_metrics_file)
+            print(f"losses and metrics saved to {loss_metrics_file}")
+
+    def _validate_generator(self, data_loader_val):
+        """Eval-mode G/D over all planes (ref: watermelon.py:479-552)."""
+        self.generator.eval()
+        self.discriminator.eval()
+        v_losses = torch.zeros(7, device=self.device)
+        v_metrics = torch.zeros(2, device=self.device)
+        n_batch = 0
+        with torch.no_grad():
+            fixed = self.generator.part2.propagator
+            for RGBD, target_amp, target_phs in data_loader_val:
+                n_batch += 1
+                B = RGBD.size(0)
+                POH = self.generator(RGBD)
+                hat_target_freq = torch.cat((fixed.propagate_POH2Freq_forward(POH), self.propagator.filter_AP2filteredFreq(target_amp, target_phs)), 0)
+                amps, phss = self.propagator.propagate_multiple_samples_with_all_fixed_multiple_distances_freq2amp(hat_target_freq)
+                n = B * self.distance_num
+                v_losses[-1] = 0.0
+                adv = -torch.mean(self.discriminator(amps[:n]))
+                self.G_loss(amps[:n], amps[n:], phss[:n], phss[n:], adv, v_losses)
+                self.record_metrics(amps[:n], amps[n:], v_metrics)
+        self.generator.train()
+        self.discriminator.train()
+        return v_losses / max(n_batch, 1), v_metrics / max(n_batch, 1)
+
+    def _add_losses_metrics_to_dict(self, epoch, n_batch_in_epoch, n_train, n_batch, v_losses, v_metrics, t_losses, t_metrics, recorder=None):
+        for k, v in (("epoch", epoch), ("n_batch_in_epoch", n_batch_in_epoch), ("n_train", n_train), ("n_batch", n_batch)):
+            recorder[k].append(v)
+        for i, name in enumerate(LOSS_NAMES):
+            recorder["train_losses_tensor"][name].append(t_losses[i].item())
+            recorder["validate_losses_tensor"][name].append(v_losses[i].item())
+        for i, name in enumerate(("PSNR", "SSIM")):
+            recorder["train_metrics_tensor"][name].append(t_metrics[i].item())
+            recorder["validate_metrics_tensor"][name].append(v_metrics[i].item())
+
+    def _save_losses_metrics_to_dict(self, loss_metrics_file):
+        with open(loss_metrics_file, "w") as f:
+            json.dump(self.dict_for_losses_metrics, f)
+
+
+class watermelon_without_GAN(watermelon):
+    """The variant the shipped CLI trains (trainingModel.py:4): no critic, ratio 0. ref: watermelon.py:637-715."""
+
+    def __init__(self, filter_radius_coefficient=0.5, pad_size=416, distance_stack=torch.linspace(-1.5e-4, 0.0, 8)[:-1],
+                 pretrained_model_path_G=None, pretrained_model_path_D=None, input_shape=(1, 4, 192, 192), cuda=True, perceptual_loss=None):
+        super().__init__(filter_radius_coefficient=filter_radius_coefficient, pad_size=pad_size, distance_stack=distance_stack,
+                         pretrained_model_path_G=pretrained_model_path_G, pretrained_model_path_D=None, input_shape=input_shape,
+                         cuda=cuda, perceptual_loss=perceptual_loss)
+
+    def _make_discriminator(self, path):
+        return fakeDiscriminator(pretrained_model_path=None, feature_d=32, cuda=True)
+
+    def train(self, data_loader_train, data_loader_val, **kw):
+        kw.update(discriminator_loss_weight=0.0, discriminator_train_ratio=0, discriminator_lambda=0.0)
+        super().train(data_loader_train, data_loader_val, **kw)

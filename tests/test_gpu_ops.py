@@ -1,0 +1,241 @@
+"""GPU parity of the individual HIP ops (through the C ABI) against plain PyTorch fp32 on the CPU.
+Run on the MI355X box:  python -m pytest tests -m gpu -q
+"""
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_err
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+TOL = 2e-5  # fp32 GEMMs with different summation order
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from learned_hologram_gan_amd import hip_ops
+
+    return hip_ops
+
+
+def to_nhwc(x, ld=None):
+    """CPU NCHW -> GPU NHWC (channels zero-padded to ld)."""
+    N, C, H, W = x.shape
+    ld = ld or C
+    out = torch.zeros(N, H, W, ld)
+    out[..., :C] = x.permute(0, 2, 3, 1)
+    return out.to(DEV)
+
+
+def to_nchw(y, C=None):
+    y = y.detach().cpu()
+    C = C or y.shape[-1]
+    return y[..., :C].permute(0, 3, 1, 2).contiguous()
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return (torch.rand(shape, generator=g) * 2 - 1) * scale
+
+
+CONV_CASES = [
+    # N, Ci, Co, H, W, k, stride
+    (2, 64, 64, 24, 20, 3, 1),     # 256x64 or 64x64 tile, ragged M
+    (1, 32, 128, 40, 40, 3, 1),    # 128-wide N tile
+    (2, 128, 256, 16, 16, 3, 1),
+    (1, 64, 6, 16, 24, 1, 1),      # narrow head
+    (2, 4, 64, 16, 16, 3, 1),      # Ci padded 4 -> 32
+    (2, 3, 32, 16, 16, 3, 1),      # critic first layer
+    (2, 32, 64, 18, 22, 3, 2),     # stride 2
+    (1, 1024, 1, 6, 6, 3, 1),      # critic head
+    (3, 256, 128, 8, 8, 1, 1),     # 1x1
+    (4, 64, 64, 96, 96, 3, 1),     # enough blocks for the 256x64 tile path
+    (2, 128, 128, 64, 64, 3, 1),   # 128x128 tile path
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES, ids=lambda c: "x".join(map(str, c)))
+def test_conv2d_forward_and_gradients(ops, case):
+    N, Ci, Co, H, W, k, stride = case
+    x = rnd(N, Ci, H, W, seed=1)
+    w = rnd(Co, Ci, k, k, seed=2, scale=(Ci * k * k) ** -0.5)
+    b = rnd(Co, seed=3, scale=0.1)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv2d(xr, wr, br, stride=stride, padding=k // 2)
+    proj = rnd(*yr.shape, seed=4)
+    (yr * proj).sum().backward()
+
+    ld = ops.pad_to(Ci, 32)
+    xg = to_nhwc(x, ld).requires_grad_(True)
+    wg, bg = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    yg = ops.Conv2dFn.apply(xg, wg, bg, stride, None)
+    assert rel_err(to_nchw(yg), yr.detach()) < TOL
+    (yg * to_nhwc(proj)).sum().backward()
+    assert rel_err(to_nchw(xg.grad, Ci), xr.grad) < TOL
+    if ld > Ci:
+        assert xg.grad[..., Ci:].abs().max().item() == 0
+    assert rel_err(wg.grad.cpu(), wr.grad) < 5e-5
+    assert rel_err(bg.grad.cpu(), br.grad) < 5e-5
+
+
+def test_conv2d_fused_epilogue(ops):
+    N, Ci, Co, H, W = 2, 64, 64, 12, 12
+    x, w, b = rnd(N, Ci, H, W, seed=1), rnd(Co, Ci, 3, 3, seed=2, scale=0.05), rnd(Co, seed=3)
+    sc, sh, res = rnd(Co, seed=4) + 1.5, rnd(Co, seed=5), rnd(N, Co, H, W, seed=6)
+    ref = F.leaky_relu((F.conv2d(x, w, b, padding=1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)) + res, 0.2)
+    y = ops.conv2d_forward_raw(to_nhwc(x), w.to(DEV), b.to(DEV), 1, act=ops.ACT_LEAKY, slope=0.2, scale=sc.to(DEV), shift=sh.to(DEV),
+                               res=to_nhwc(res))
+    assert rel_err(to_nchw(y), ref) < TOL
+    # planar sigmoid head
+    w1, b1 = rnd(6, Ci, 1, 1, seed=7, scale=0.2), rnd(6, seed=8)
+    yp = ops.conv2d_forward_raw(to_nhwc(x), w1.to(DEV), b1.to(DEV), 1, act=ops.ACT_SIGMOID, planar=True)
+    assert rel_err(yp.cpu(), torch.sigmoid(F.conv2d(x, w1, b1))) < TOL
+    # output into a channel slice of a wider buffer
+    buf = torch.full((N, H, W, 128), 7.0, device=DEV)
+    ops.conv2d_forward_raw(to_nhwc(x), w.to(DEV), b.to(DEV), 1, out=ops.OutSlot(buf[..., 64:]))
+    assert rel_err(to_nchw(buf[..., 64:]), F.conv2d(x, w, b, padding=1)) < TOL
+    assert (buf[..., :64] == 7.0).all()
+
+
+@pytest.mark.parametrize("case", [(2, 64, 32, 8, 10), (1, 128, 64, 12, 12), (2, 1024, 512, 2, 2)], ids=str)
+def test_conv_transpose2x2(ops, case):
+    N, Ci, Co, H, W = case
+    x, w, b = rnd(N, Ci, H, W, seed=1), rnd(Ci, Co, 2, 2, seed=2, scale=Ci ** -0.5), rnd(Co, seed=3, scale=0.1)
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = F.conv_transpose2d(xr, wr, br, stride=2)
+    proj = rnd(*yr.shape, seed=4)
+    (yr * proj).sum().backward()
+    xg = to_nhwc(x).requires_grad_(True)
+    wg, bg = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    yg = ops.ConvTranspose2x2Fn.apply(xg, wg, bg, None)
+    assert rel_err(to_nchw(yg), yr.detach()) < TOL
+    (yg * to_nhwc(proj)).sum().backward()
+    assert rel_err(to_nchw(xg.grad), xr.grad) < TOL
+    assert rel_err(wg.grad.cpu(), wr.grad) < 5e-5
+    assert rel_err(bg.grad.cpu(), br.grad) < 5e-5
+
+
+@pytest.mark.parametrize("act,slope,with_res", [(1, 0.0, True), (2, 0.2, False), (0, 0.0, False)])
+def test_batch_norm_train_forward_backward(ops, act, slope, with_res):
+    N, C, H, W = 3, 64, 10, 14
+    x = rnd(N, C, H, W, seed=1) * 2 + 0.7
+    gam, bet = rnd(C, seed=2) + 1.5, rnd(C, seed=3)
+    res = rnd(N, C, H, W, seed=4) if with_res else None
+    rm, rv = rnd(C, seed=5), rnd(C, seed=6).abs() + 0.5
+    xr, gr, br = x.clone().requires_grad_(True), gam.clone().requires_grad_(True), bet.clone().requires_grad_(True)
+    rr = res.clone().requires_grad_(True) if with_res else None
+    rm_r, rv_r = rm.clone(), rv.clone()
+    pre = F.batch_norm(xr, rm_r, rv_r, gr, br, True, 0.1, 1e-5)
+    if with_res:
+        pre = pre + rr
+    yr = F.relu(pre) if act == 1 else (F.leaky_relu(pre, slope) if act == 2 else pre)
+    proj = rnd(*yr.shape, seed=7)
+    (yr * proj).sum().backward()
+
+    xg = to_nhwc(x).requires_grad_(True)
+    gg, bg = gam.to(DEV).requires_grad_(True), bet.to(DEV).requires_grad_(True)
+    rg = to_nhwc(res).requires_grad_(True) if with_res else None
+    rm_g, rv_g = rm.to(DEV), rv.to(DEV)
+    yg = ops.BatchNormTrainFn.apply(xg, gg, bg, rm_g, rv_g, rg, act, slope, None)
+    assert rel_err(to_nchw(yg), yr.detach()) < TOL
+    assert rel_err(rm_g.cpu(), rm_r) < 1e-5 and rel_err(rv_g.cpu(), rv_r) < 1e-5
+    (yg * to_nhwc(proj)).sum().backward()
+    assert rel_err(to_nchw(xg.grad), xr.grad) < 1e-4
+    assert rel_err(gg.grad.cpu(), gr.grad) < 1e-4
+    assert rel_err(bg.grad.cpu(), br.grad) < 1e-4
+    if with_res:
+        assert rel_err(to_nchw(rg.grad), rr.grad) < TOL
+
+
+def test_batch_norm_large_mean_stability(ops):
+    """Shifted one-pass variance: mean >> std must not lose the variance."""
+    N, C, H, W = 2, 32, 64, 64
+    x = rnd(N, C, H, W, seed=1) * 0.01 + 100.0
+    ref = F.batch_norm(x, None, None, None, None, True)
+    y = ops.BatchNormTrainFn.apply(to_nhwc(x), torch.ones(C, device=DEV), torch.zeros(C, device=DEV), None, None, None, 0, 0.0, None)
+    assert rel_err(to_nchw(y), ref) < 2e-3
+
+
+def test_maxpool(ops):
+    x = rnd(2, 64, 12, 16, seed=1)
+    x[0, :, 0, 0] = x[0, :, 0, 1]  # a tie: first maximum wins
+    xr = x.clone().requires_grad_(True)
+    yr = F.max_pool2d(xr, 2, 2)
+    proj = rnd(*yr.shape, seed=2)
+    (yr * proj).sum().backward()
+    xg = to_nhwc(x).requires_grad_(True)
+    yg = ops.MaxPool2x2Fn.apply(xg)
+    assert torch.equal(to_nchw(yg), yr.detach())
+    (yg * to_nhwc(proj)).sum().backward()
+    assert torch.equal(to_nchw(xg.grad), xr.grad)
+
+
+def test_layout_roundtrip_and_grad(ops):
+    x = rnd(2, 3, 8, 12, seed=1)
+    xg = x.to(DEV).requires_grad_(True)
+    h = ops.ToNHWC.apply(xg, 32)
+    assert h.shape == (2, 8, 12, 32) and torch.equal(to_nchw(h, 3), x) and h[..., 3:].abs().max() == 0
+    back = ops.ToNCHW.apply(h, 3)
+    assert torch.equal(back.cpu(), x)
+    (back * 2).sum().backward()
+    assert torch.equal(xg.grad.cpu(), torch.full_like(x, 2.0))
+
+
+def _critic_like(ops, x, w1, b1, w2, b2, gam, bet, w3, b3, on_gpu):
+    """conv+leaky -> conv(s2)+BN+leaky -> conv(->1): the op sequence of the critic, both backends."""
+    if on_gpu:
+        h = ops.ToNHWC.apply(x, 32)
+        h = ops.ConvBiasActFn.apply(h, w1, b1, 1, ops.ACT_LEAKY, 0.2)
+        y = ops.Conv2dFn.apply(h, w2, b2, 2, None)
+        h = ops.BatchNormTrainFn.apply(y, gam, bet, None, None, None, ops.ACT_LEAKY, 0.2, None)
+        s = ops.Conv2dFn.apply(h, w3, b3, 1, None)
+        return s.reshape(s.shape[0], -1)
+    h = F.leaky_relu(F.conv2d(x, w1, b1, padding=1), 0.2)
+    h = F.leaky_relu(F.batch_norm(F.conv2d(h, w2, b2, stride=2, padding=1), None, None, gam, bet, True, 0.1, 1e-5), 0.2)
+    return F.conv2d(h, w3, b3, padding=1).flatten(1)
+
+
+def test_gradient_penalty_double_backward(ops):
+    """WGAN-GP: d/dtheta of (||d sum D(x)/dx|| - 1)^2 through conv, train-mode BN and LeakyReLU."""
+    g = torch.Generator().manual_seed(5)
+    x = torch.rand((2, 3, 16, 16), generator=g)
+    shapes = dict(w1=(32, 3, 3, 3), b1=(32,), w2=(64, 32, 3, 3), b2=(64,), gam=(64,), bet=(64,), w3=(1, 64, 3, 3), b3=(1,))
+    P = {k: (torch.rand(s, generator=g) - 0.5) * (0.4 if k.startswith("w") else 0.2) + (1.0 if k == "gam" else 0.0) for k, s in shapes.items()}
+
+    def run(on_gpu):
+        dev = DEV if on_gpu else "cpu"
+        p = {k: v.clone().to(dev).requires_grad_(True) for k, v in P.items()}
+        xi = x.clone().to(dev).requires_grad_(True)
+        score = _critic_like(ops, xi, on_gpu=on_gpu, **p)
+        (gx,) = torch.autograd.grad(score, xi, torch.ones_like(score), create_graph=True, retain_graph=True)
+        gp = ((gx.view(2, -1).norm(2, dim=1) - 1) ** 2).mean()
+        loss = score.mean() + 10 * gp
+        loss.backward()
+        return score.detach().cpu(), gx.detach().cpu(), gp.item(), {k: v.grad.cpu() for k, v in p.items()}
+
+    s_r, gx_r, gp_r, gr = run(False)
+    s_g, gx_g, gp_g, gg = run(True)
+    assert rel_err(s_g, s_r) < 1e-4
+    assert rel_err(gx_g, gx_r) < 1e-4
+    assert abs(gp_g - gp_r) <= 1e-4 * abs(gp_r)
+    for k in gr:
+        if k == "b2":  # bias feeding a train-mode BN: analytically zero gradient, noise on both sides
+            continue
+        assert rel_err(gg[k], gr[k]) < 5e-4, k
+
+
+def test_adam_matches_torch(ops):
+    g = torch.Generator().manual_seed(9)
+    p0 = torch.randn(1000, generator=g)
+    pr = p0.clone().requires_grad_(True)
+    opt = torch.optim.Adam([pr], lr=1e-3)
+    pg, m, v = p0.clone().to(DEV), torch.zeros(1000, device=DEV), torch.zeros(1000, device=DEV)
+    for step in range(1, 4):
+        grad = torch.randn(1000, generator=g)
+        pr.grad = grad.clone()
+        opt.step()
+        ops.adam_step_(pg, grad.to(DEV), m, v, 1e-3, 0.9, 0.999, 1e-8, step)
+        assert rel_err(pg.cpu(), pr.detach()) < 1e-6

@@ -1,0 +1,173 @@
+"""CPU-side checks of the product package: the C-ABI library loads and exports every declared
+symbol, host-built constants equal the reference's bit for bit, modules carry the reference's
+checkpoint schema, entry points keep their flags, and the ops refuse to run without the GPU
+(no compute is executed here)."""
+
+import ctypes
+import os
+import subprocess
+import sys
+
+import pytest
+import torch
+
+from conftest import REPO, rel_err
+
+WL = torch.tensor([638e-9, 520e-9, 450e-9])
+
+
+def test_library_exports_declared_abi():
+    from learned_hologram_gan_amd import native
+
+    declared = native.declared_symbols()
+    assert len(declared) >= 25 and set(declared) == set(native._SIGNATURES)
+    lib = native.load()
+    raw = ctypes.CDLL(native.LIB_PATH)
+    for name in declared:
+        assert hasattr(raw, name), name
+    assert lib.lhg_abi_version() == 1
+
+
+def test_library_is_gfx950_code_object():
+    from learned_hologram_gan_amd import native
+
+    blob = open(native.LIB_PATH, "rb").read()
+    assert b"gfx950" in blob
+
+
+def test_ops_refuse_cpu_tensors():
+    from learned_hologram_gan_amd import hip_ops, native
+    from learned_hologram_gan_amd.angular_spectrum_method import bandLimitedAngularSpectrumMethod_for_single_fixed_distance as Fx
+
+    with pytest.raises(native.NativeLibraryError):
+        hip_ops.ToNHWC.apply(torch.rand(1, 3, 4, 4), 32)
+    fx = Fx(48, 48, 8, 0.45, 3.74e-6, WL, False, False, torch.tensor([1e-3]))
+    with pytest.raises(native.NativeLibraryError):
+        fx.propagate_POH2AP_forward(torch.rand(1, 3, 48, 48))
+
+
+def test_missing_library_fails_loudly(monkeypatch, tmp_path):
+    from learned_hologram_gan_amd import native
+
+    monkeypatch.setattr(native, "_lib", None)
+    monkeypatch.setattr(native, "LIB_PATH", str(tmp_path / "nope.so"))
+    with pytest.raises(native.NativeLibraryError, match="no CPU"):
+        native.load()
+
+
+def test_constants_equal_reference_bits(golden):
+    from learned_hologram_gan_amd.angular_spectrum_method import (
+        bandLimitedAngularSpectrumMethod_for_multiple_distances as Mu,
+        bandLimitedAngularSpectrumMethod_for_single_fixed_distance as Fx,
+    )
+
+    for tag in ("sq48", "rect32x48"):
+        g = golden("constants.pt")[tag]
+        r0, c0, pad, coef = g["args"]
+        fx = Fx(r0, c0, pad, coef, 3.74e-6, WL, False, False, torch.tensor([1e-3]))
+        mu = Mu(r0, c0, g["distances"], pad, coef, 3.74e-6, WL, False, False)
+        assert (fx.samplingRowNum, fx.samplingColNum) == tuple(g["shape"])
+        assert torch.equal(fx.w_grid, g["w"]) and torch.equal(fx.diffraction_limited_mask, g["mask"])
+        assert torch.equal(fx.H, g["H_fixed"]) and torch.equal(mu.H, g["H_stack"])
+        assert torch.equal(fx._H_masked, g["H_fixed"] * g["mask"])
+    with pytest.raises(ValueError):
+        Fx(64, 64, 0, 0.6, 3.74e-6, WL, False, False, torch.tensor([1e-3]))
+
+
+def test_pad_crop_api():
+    from learned_hologram_gan_amd.angular_spectrum_method import bandLimitedAngularSpectrumMethod as Base
+
+    b = Base(32, 48, 8, 0.35, 3.74e-6, WL)
+    x = torch.rand(2, 3, 32, 48)
+    assert b.padding(x).shape == (2, 3, 48, 72) and torch.equal(b.cropping(b.padding(x)), x)
+
+
+def test_checkpoint_schema_matches_reference(golden):
+    from learned_hologram_gan_amd.watermelon_hologram.discriminator import WGANGPDiscriminator192
+    from learned_hologram_gan_amd.watermelon_hologram.generator import Generator
+    from oracle import seeded
+
+    g = golden("generator_small.pt")
+    G = Generator(32, 32, 16, 0.45, 3, 3.74e-6, WL, torch.tensor([1e-3]))
+    assert {k: tuple(v.shape) for k, v in G.state_dict().items()} == g["key_shapes"]
+    assert sum(p.numel() for p in G.parameters()) == g["n_params"] == 32440274
+    res = G.load_state_dict(seeded.generator_state_dict(), strict=True)
+    assert not res.missing_keys and not res.unexpected_keys
+    c = golden("critic_small.pt")
+    D = WGANGPDiscriminator192(None, 32, False)
+    assert {k: tuple(v.shape) for k, v in D.state_dict().items()} == c["key_shapes"]
+    assert sum(p.numel() for p in D.parameters()) == c["n_params"] == 6301377
+    # the trainer reaches into these attributes (ref: watermelon.py:219)
+    assert hasattr(G.part2.propagator, "propagate_POH2Freq_forward") and hasattr(G.part1, "part1")
+
+
+def test_reference_initialisation_statistics():
+    from learned_hologram_gan_amd.watermelon_hologram.generator import Generator
+
+    torch.manual_seed(0)
+    G = Generator(32, 32, 16)
+    sd = G.state_dict()
+    w = sd["part1.part1.encoder3.1.0.convolution_layer_1.weight"]  # xavier normal: std = sqrt(2/(fan_in+fan_out))
+    assert abs(w.std().item() / (2.0 / (128 * 9 + 256 * 9)) ** 0.5 - 1) < 0.02
+    assert sd["part1.part1.encoder3.1.0.convolution_layer_1.bias"].abs().max() == 0
+    assert (sd["part1.part1.decoder2.0.0.batch_norm_layer_1.weight"] == 1).all()
+    t = sd["part1.part1.decoder1.1.weight"]  # kaiming fan_out on (Cin, Cout, 2, 2): fan_out = Cin*4
+    assert abs(t.std().item() / (2.0 / (512 * 4)) ** 0.5 - 1) < 0.02
+    assert (sd["part2.part1.conv_r.params"] >= 0).all()
+
+
+def test_symmetric_conv_matches_conv2d():
+    from learned_hologram_gan_amd.neural_network_components import ChannelWiseSymmetricConv
+
+    m = ChannelWiseSymmetricConv()
+    x = torch.rand(2, 3, 9, 11)
+    ref = []
+    for c, conv in enumerate((m.conv_r, m.conv_g, m.conv_b)):
+        w = conv.params[conv.distance_map].view(1, 1, 3, 3)
+        ref.append(torch.nn.functional.conv2d(x[:, c:c + 1], w, conv.bias, padding=1))
+    assert rel_err(m(x), torch.cat(ref, 1)) < 1e-6
+
+
+def test_losses_match_oracle(golden):
+    from learned_hologram_gan_amd.watermelon_hologram import loss_func
+
+    g = golden("losses_small.pt")
+    assert abs(loss_func.focal_sincos_phase_gradient_loss(g["hat_phs"], g["tgt_phs"]).item() - g["focal"]) < 1e-6
+    assert abs(loss_func.total_variation_loss(g["hat_amp"], g["tgt_amp"]).item() - g["tv_loss"]) < 1e-6
+
+
+def test_cli_flags_kept():
+    for script, flags in (("generatePOH.py", ["--img_path", "--depth_path", "--index", "--model_path", "--poh_output_path", "--samplesNum",
+                                              "--sample_row_num", "--sample_col_num", "--pad_size", "--pixel_pitch", "--wave_length",
+                                              "--distance", "--filter_radius_coefficient", "--propagate", "--min_distance",
+                                              "--max_distance", "--num_intervals", "--output_image_dir"]),
+                          ("trainingModel.py", ["--train_img_path", "--train_depth_path", "--train_amp_path", "--train_phs_path",
+                                                "--validate_img_path", "--validate_depth_path", "--validate_amp_path",
+                                                "--validate_phs_path", "--samplesNum", "--channlesNum", "--height", "--width",
+                                                "--batch_size", "--lr_G", "--lr_D", "--epoch_num", "--save_path_G", "--save_path_D",
+                                                "--loss_metrics_file", "--save_path_img"])):
+        out = subprocess.run([sys.executable, os.path.join(REPO, script), "--help"], capture_output=True, text=True, timeout=120)
+        assert out.returncode == 0, out.stderr
+        for f in flags:
+            assert f in out.stdout, (script, f)
+
+
+def test_bin_datasets(tmp_path):
+    import numpy as np
+
+    from learned_hologram_gan_amd.watermelon_hologram.data_loader import dataloaderImgDepth, dataloaderImgDepthAmpPhs
+
+    shape = (3, 3, 8, 8)
+    paths = {}
+    for i, k in enumerate(("img", "depth", "amp", "phs")):
+        a = np.random.RandomState(i).rand(*shape).astype(np.float32)
+        paths[k] = str(tmp_path / f"{k}.bin")
+        a.tofile(paths[k])
+        paths[k + "_a"] = a
+    ds = dataloaderImgDepthAmpPhs(paths["img"], paths["depth"], paths["amp"], paths["phs"], 3, 3, 8, 8, cuda=False)
+    rgbd, amp, phs = ds[1]
+    assert rgbd.shape == (4, 8, 8) and torch.equal(rgbd[:3], torch.from_numpy(paths["img_a"][1]))
+    assert torch.equal(rgbd[3], torch.from_numpy(paths["depth_a"][1][0])) and torch.equal(phs, torch.from_numpy(paths["phs_a"][1]))
+    with pytest.raises(IndexError):
+        ds[3]
+    assert dataloaderImgDepth(paths["img"], paths["depth"], 3, 3, 8, 8)[2].shape == (4, 8, 8)
