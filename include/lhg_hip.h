@@ -45,6 +45,13 @@ typedef void* lhg_stream_t; /* hipStream_t */
 int lhg_abi_version(void);
 const char* lhg_last_error(void);
 
+/* Per-launch timing of the two GEMM kernels (0: gather-GEMM gg_kernel, 1: wgrad-GEMM wg_kernel) with HIP
+ * events recorded on the launch stream; used by bench.py for the roofline figures.  lhg_profile_read
+ * synchronises the recorded events and returns the summed duration, the launch count and the executed
+ * (padded-tile) flops since the last enable. */
+int lhg_profile_enable(int kernel, int on);
+int lhg_profile_read(int kernel, double* total_ms, long long* launches, double* executed_flops);
+
 /* ------------------------------------------------------------------ layout */
 /* NCHW (planar) -> NHWC with `ld` floats per pixel; channels C..ld-1 are zero-filled.
  * Entry of the UNet / critic (ref: neural_network_components.py:303, discriminator.py:44). */

@@ -140,6 +140,23 @@ class bandLimitedAngularSpectrumMethod:
             self._H_call_cache = (key, H.reshape(-1, self.samplingRowNum, self.samplingColNum).to(self.device))
         return self._H_call_cache[1]
 
+    def set_mask(self, mask):
+        """Install a recorded low-pass mask (its boundary pixels also depend on the host's sqrt)."""
+        self._mask_host = mask.detach().cpu().to(torch.float32)
+        self.diffraction_limited_mask = self._mask_host.to(self.device)
+        self._mask_slab = (self._mask_host + 0j).to(torch.complex64).unsqueeze(0).to(self.device)
+        if hasattr(self, "H"):
+            self.set_transfer_function(self.H)
+
+    def set_call_transfer_function(self, distances, H):
+        """Use a given H (D,3,R,C) for ``__call__(…, distances)`` instead of evaluating it on this host.
+        ATen's CPU sqrt (MKL VML) differs in the last bit between CPU models and one ulp of the w grid is
+        8e-4 rad of phase, so transfer functions are only reproducible on the host that built them; parity
+        tests against recorded reference outputs inject the recorded H."""
+        key = tuple(float(x) for x in torch.as_tensor(distances).reshape(-1).tolist())
+        Hm = (H.detach().cpu().to(torch.complex64) * self._mask_host).to(torch.complex64)
+        self._H_call_cache = (key, Hm.reshape(-1, self.samplingRowNum, self.samplingColNum).to(self.device))
+
     # ------------------------------------------------------------------ reference API
     def __call__(self, amplitute_tensor, phase_tensor, distances):
         """|crop(ifft2(fft2(pad(a e^{i phi})) * H(d) * mask))|; dim 0 is batch OR distances
@@ -183,6 +200,11 @@ class bandLimitedAngularSpectrumMethod_for_single_fixed_distance(bandLimitedAngu
             self.samplingRowNum, self.samplingColNum).to(self.device)
         self.band_limited_mask = self.generate_band_limited_mask().to(self.device)
         H_host = self._H_host(self.distance)[0].to(torch.complex64)
+        self.set_transfer_function(H_host)
+
+    def set_transfer_function(self, H):
+        """Install H (3,R,C) (see set_call_transfer_function for why this hook exists)."""
+        H_host = H.detach().cpu().to(torch.complex64)
         self.H = H_host.to(self.device)
         self._H_masked = (H_host * self._mask_host).to(torch.complex64).to(self.device)
 
@@ -253,9 +275,14 @@ class bandLimitedAngularSpectrumMethod_for_multiple_distances(bandLimitedAngular
         super().__init__(sample_row_num, sample_col_num, pad_size, filter_radius_coefficient, pixel_pitch, wave_length, band_limit, cuda)
         self.distances = distances.to(self.device)
         H_host = self._H_host(distances).to(torch.complex64)
+        self.set_transfer_function(H_host)
+        self.last_indices = None
+
+    def set_transfer_function(self, H):
+        """Install the stack H (D,3,R,C) (see set_call_transfer_function for why this hook exists)."""
+        H_host = H.detach().cpu().to(torch.complex64)
         self.H = H_host.to(self.device)
         self._H_masked = (H_host * self._mask_host).to(torch.complex64).reshape(-1, self.samplingRowNum, self.samplingColNum).to(self.device)
-        self.last_indices = None
 
     def __call__(self, amplitute_tensor, phase_tensor, distances):
         """(B,3,h,w) x D distances -> |g| (B*D,3,h,w), sample-major. ref: :503-522."""

@@ -22,6 +22,10 @@
 //   wg: block tile 64 x 64 channels, K = 32 pixels per step, LDS tiles [32 px][64 ch]; lanes read
 //       consecutive channels (conflict-free ds_read_b32).  K (pixels) is split over blockIdx.z
 //       into partial slabs that lhg_wgrad_reduce sums (deterministic, no float atomics).
+#include <algorithm>
+#include <utility>
+#include <vector>
+
 #include "common.h"
 
 namespace lhg {
@@ -326,6 +330,41 @@ __global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int S, int 
 }
 
 // ------------------------------------------------------------------------------------ host side
+// Optional per-launch timing of the two GEMM kernels with HIP events recorded on the launch stream
+// (bench.py's roofline leg).  Off by default; never enabled while a graph is being captured.
+struct KernelTimer {
+  bool on = false;
+  std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
+  size_t used = 0;
+  double executed_flops = 0;
+  std::pair<hipEvent_t, hipEvent_t>& next() {
+    if (used == pool.size()) {
+      hipEvent_t a, b;
+      (void)hipEventCreate(&a);
+      (void)hipEventCreate(&b);
+      pool.emplace_back(a, b);
+    }
+    return pool[used++];
+  }
+};
+static KernelTimer g_timer[2];  // 0: gg_kernel, 1: wg_kernel
+
+struct ScopedKernelTime {
+  KernelTimer& t;
+  hipStream_t st;
+  std::pair<hipEvent_t, hipEvent_t>* ev = nullptr;
+  ScopedKernelTime(int which, hipStream_t s, double flops) : t(g_timer[which]), st(s) {
+    if (t.on) {
+      ev = &t.next();
+      t.executed_flops += flops;
+      (void)hipEventRecord(ev->first, st);
+    }
+  }
+  ~ScopedKernelTime() {
+    if (ev) (void)hipEventRecord(ev->second, st);
+  }
+};
+
 static int launch_gg(GGParams& p, hipStream_t st) {
   const Geom& g = p.g;
   if (g.M <= 0) return LHG_OK;
@@ -335,6 +374,7 @@ static int launch_gg(GGParams& p, hipStream_t st) {
   LHG_REQUIRE(p.rows_pad % 64 == 0 && p.rows_pad >= g.Co, "gather-GEMM: rows_pad %d must be a multiple of 64 covering Co=%d", p.rows_pad, g.Co);
   LHG_REQUIRE((long long)g.N * g.Ho * g.Wo < (1ll << 31) && (long long)g.N * g.Hi * g.Wi < (1ll << 31), "gather-GEMM: more than 2^31 pixels");
   auto blocks = [&](int bm, int bn) { return (long long)((g.M + bm - 1) / bm) * (p.rows_pad / bn); };
+  ScopedKernelTime timed(0, st, 2.0 * g.M * (double)p.rows_pad * g.Ci * g.T);
   if (p.rows_pad % 128 == 0 && blocks(128, 128) >= 400) {
     hipLaunchKernelGGL((gg_kernel<128, 128, 2, 2>), dim3((unsigned)blocks(128, 128)), dim3(256), 0, st, p);
   } else if (blocks(256, 64) >= 400) {
@@ -354,6 +394,7 @@ static int launch_wg(WGParams& p, int S, hipStream_t st) {
   const int steps = (g.M + BK - 1) / BK;
   p.kchunk = ((steps + S - 1) / S) * BK;
   dim3 grid((p.m_pad / 64) * (p.n_pad / 64), g.T, S);
+  ScopedKernelTime timed(1, st, 2.0 * g.M * (double)p.m_pad * p.n_pad * g.T);
   hipLaunchKernelGGL(wg_kernel, grid, dim3(256), 0, st, p);
   return check_launch("wg_kernel");
 }
@@ -394,6 +435,30 @@ static bool conv_args_ok(int KH, int KW, int stride) {
 using namespace lhg;
 
 extern "C" {
+
+int lhg_profile_enable(int kernel, int on) {
+  LHG_REQUIRE(kernel == 0 || kernel == 1, "profile_enable: kernel must be 0 (gather-GEMM) or 1 (wgrad-GEMM)");
+  g_timer[kernel].on = on != 0;
+  if (on) { g_timer[kernel].used = 0; g_timer[kernel].executed_flops = 0; }
+  return LHG_OK;
+}
+
+int lhg_profile_read(int kernel, double* total_ms, long long* launches, double* executed_flops) {
+  LHG_REQUIRE(kernel == 0 || kernel == 1, "profile_read: kernel must be 0 or 1");
+  KernelTimer& t = g_timer[kernel];
+  double ms = 0;
+  for (size_t i = 0; i < t.used; ++i) {
+    hipError_t e = hipEventSynchronize(t.pool[i].second);
+    if (e != hipSuccess) return fail(LHG_E_LAUNCH, "profile_read: %s", hipGetErrorString(e));
+    float dt = 0;
+    (void)hipEventElapsedTime(&dt, t.pool[i].first, t.pool[i].second);
+    ms += dt;
+  }
+  *total_ms = ms;
+  *launches = (long long)t.used;
+  *executed_flops = t.executed_flops;
+  return LHG_OK;
+}
 
 int lhg_pack_weight(const float* w, int D0, int D1, int KH, int KW, int rows_from_d0, float* dst, int rows_pad, int k_pad, lhg_stream_t s) {
   const int rows = rows_from_d0 ? D0 : D1, K = rows_from_d0 ? D1 : D0;

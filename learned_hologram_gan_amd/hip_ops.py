@@ -92,27 +92,29 @@ def _dense(t):
 
 
 # --------------------------------------------------------------------------- weight packing
-_pack_cache: dict = {}
-
-
 def pack_weight(w: torch.Tensor, rows_from_d0: bool, k_pad_to: int = 32) -> torch.Tensor:
-    """OIHW / IOHW -> [KH*KW][rows_pad][k_pad] panels (lhg_pack_weight), cached per weight version."""
+    """OIHW / IOHW -> [KH*KW][rows_pad][k_pad] panels (lhg_pack_weight).
+
+    The packed copy is cached ON the weight tensor object (so it dies with it — an id()/data_ptr
+    keyed table would alias a freed temporary) and is reused while (data_ptr, _version) are
+    unchanged; raw-pointer updates must call bump_version()."""
     D0, D1, KH, KW = w.shape
     rows, K = (D0, D1) if rows_from_d0 else (D1, D0)
     rows_pad, k_pad = pad_to(rows, 64), pad_to(K, k_pad_to)
-    key = (w.data_ptr(), w._version, rows_from_d0, k_pad)
-    slot = (id(w), rows_from_d0, k_pad)
-    hit = _pack_cache.get(slot)
-    if hit is not None and hit[0] == key:
+    stamp = (w.data_ptr(), w._version, tuple(w.shape))
+    try:
+        cache = w.__dict__.setdefault("_lhg_packed", {})
+    except AttributeError:  # pragma: no cover
+        cache = {}
+    hit = cache.get((rows_from_d0, k_pad))
+    if hit is not None and hit[0] == stamp:
         return hit[1]
     wd = w.detach()
     if not wd.is_contiguous():
         wd = wd.contiguous()
     out = torch.empty((KH * KW, rows_pad, k_pad), dtype=torch.float32, device=w.device)
     call("lhg_pack_weight", ptr(wd), D0, D1, KH, KW, int(rows_from_d0), ptr(out), rows_pad, k_pad, stream_ptr())
-    if len(_pack_cache) > 512:
-        _pack_cache.clear()
-    _pack_cache[slot] = (key, out)
+    cache[(rows_from_d0, k_pad)] = (stamp, out)
     return out
 
 
@@ -182,6 +184,7 @@ def conv2d_forward_raw(x, w, bias, stride, act=ACT_NONE, slope=0.0, scale=None, 
     pres, ldres = (None, 0)
     if res is not None:
         pres, _, _, _, _, ldres = nhwc(res)
+    native.count_flops(0, 2.0 * N * Ho * Wo * Co * Ciw * KH * KW)
     call("lhg_conv2d_forward", px, N, H, W, Ci, ldx, ptr(wp), wp.shape[1], KH, KW, stride, py, Co, ldy,
          ptr(bias), ptr(scale), ptr(shift), pres, ldres, act, float(slope), int(planar), stream_ptr())
     return y
@@ -236,6 +239,7 @@ class Conv2dInputGradFn(Function):
         if Cx > Ci:
             gx[..., Ci:].zero_()
         pgx, _, _, _, _, ldgx = nhwc(gx)
+        native.count_flops(0, 2.0 * N * Ho * Wo * Co * Ci * KH * KW)
         call("lhg_conv2d_backward_input", pg, N, H, W, Cg, ldg, ptr(wp), wp.shape[1], KH, KW, stride, pgx, Ci, ldgx, stream_ptr())
         return gx
 
@@ -265,6 +269,7 @@ class Conv2dWeightGradFn(Function):
         S = lib.lhg_conv2d_wgrad_splits(N, H, W, Cx, Cg, KH, KW, stride)
         ci_pad, co_pad = pad_to(Cx, 64), pad_to(Cg, 64)
         slabs = torch.empty((S, KH * KW, ci_pad, co_pad), dtype=torch.float32, device=x.device)
+        native.count_flops(1, 2.0 * N * gy.shape[1] * gy.shape[2] * Co * Ci * KH * KW)
         call("lhg_conv2d_backward_weight", px, N, H, W, Cx, ldx, pg, Cg, ldg, KH, KW, stride, ptr(slabs), S, ci_pad, co_pad, stream_ptr())
         gw = torch.empty(ctx.wshape, dtype=torch.float32, device=x.device)
         call("lhg_wgrad_reduce", ptr(slabs), S, KH * KW, ci_pad, co_pad, ptr(gw), Co, Ci, 1, stream_ptr())
@@ -294,6 +299,7 @@ class ConvTranspose2x2Fn(Function):
         wp = pack_weight(w, False)  # rows = Cout, K = Cin
         y = _resolve_out(out, (N, 2 * H, 2 * W, Co), x.device)
         py, _, _, _, _, ldy = nhwc(y)
+        native.count_flops(0, 2.0 * N * H * W * 4 * Ci * Co)
         call("lhg_conv_transpose2x2_forward", px, N, H, W, Ci, ldx, ptr(wp), wp.shape[1], py, Co, ldy, ptr(bias), stream_ptr())
         return y
 
@@ -307,6 +313,7 @@ class ConvTranspose2x2Fn(Function):
             wp = pack_weight(w, True)  # rows = Cin, K = Cout
             gx = new_nhwc(N, H2 // 2, W2 // 2, Ci, gy.device)
             pgx, _, _, _, _, ldgx = nhwc(gx)
+            native.count_flops(0, 2.0 * N * (H2 // 2) * (W2 // 2) * 4 * Ci * Co)
             call("lhg_conv_transpose2x2_backward_input", pg, N, H2 // 2, W2 // 2, Cg, ldg, ptr(wp), wp.shape[1], pgx, Ci, ldgx, stream_ptr())
         if ctx.needs_input_grad[1]:
             px, N, H, W, Cx, ldx = nhwc(x)
@@ -315,6 +322,7 @@ class ConvTranspose2x2Fn(Function):
             S = lib.lhg_conv_transpose2x2_wgrad_splits(N, H, W, Cx, Cg)
             ci_pad, co_pad = pad_to(Cx, 64), pad_to(Cg, 64)
             slabs = torch.empty((S, 4, ci_pad, co_pad), dtype=torch.float32, device=x.device)
+            native.count_flops(1, 2.0 * N * H * W * 4 * Ci * Co)
             call("lhg_conv_transpose2x2_backward_weight", px, N, H, W, Cx, ldx, pg, Cg, ldg, ptr(slabs), S, ci_pad, co_pad, stream_ptr())
             gw = torch.empty_like(w)
             call("lhg_wgrad_reduce", ptr(slabs), S, 4, ci_pad, co_pad, ptr(gw), Ci, Co, 0, stream_ptr())
@@ -325,6 +333,8 @@ class ConvTranspose2x2Fn(Function):
 
 def channel_sum(t):
     """sum over (N,H,W) of an NHWC tensor -> (C,).  Used for bias gradients (linear in t)."""
+    if t.shape[-1] % 4:  # heads with 6 / 1 channels: a few hundred KB
+        return t.sum(dim=(0, 1, 2))
     return ChannelSumFn.apply(t)
 
 

@@ -33,6 +33,8 @@ class AsmFilter(C.Structure):
 _SIGNATURES = {
     "lhg_abi_version": [],
     "lhg_last_error": [],
+    "lhg_profile_enable": [_i, _i],
+    "lhg_profile_read": [_i, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)],
     "lhg_nchw_to_nhwc": [_p, _p, _i, _i, _i, _i, _i, _p],
     "lhg_nhwc_to_nchw": [_p, _i, _p, _i, _i, _i, _i, _p],
     "lhg_pack_weight": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _p],
@@ -124,3 +126,34 @@ def call(name: str, *args):
     if rc != 0:
         msg = lib.lhg_last_error().decode("utf-8", "replace")
         raise RuntimeError(f"{name} failed ({rc}): {msg}")
+
+
+class kernel_profile:
+    """Context manager: time every gather-GEMM (0) / wgrad-GEMM (1) launch with HIP events and count the
+    ALGORITHMIC flops (true channel counts, no padding) the Python op layer attributes to them."""
+
+    algorithmic = [0.0, 0.0]
+    active = False
+
+    def __enter__(self):
+        for k in (0, 1):
+            call("lhg_profile_enable", k, 1)
+        kernel_profile.algorithmic = [0.0, 0.0]
+        kernel_profile.active = True
+        return self
+
+    def __exit__(self, *exc):
+        kernel_profile.active = False
+        self.result = []
+        for k in (0, 1):
+            ms, n, fl = C.c_double(), C.c_longlong(), C.c_double()
+            call("lhg_profile_read", k, C.byref(ms), C.byref(n), C.byref(fl))
+            call("lhg_profile_enable", k, 0)
+            self.result.append(dict(total_ms=ms.value, launches=n.value, executed_flops=fl.value,
+                                    algorithmic_flops=kernel_profile.algorithmic[k]))
+        return False
+
+
+def count_flops(kernel: int, flops: float):
+    if kernel_profile.active:
+        kernel_profile.algorithmic[kernel] += flops

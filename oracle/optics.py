@@ -182,11 +182,11 @@ def spectrum_to_planes_all(o: Optics, H_stack: torch.Tensor, G: torch.Tensor):
     return torch.abs(g), torch.angle(g)
 
 
-def propagate_amplitudes(o: Optics, amp, phs, distances: torch.Tensor) -> torch.Tensor:
+def propagate_amplitudes(o: Optics, amp, phs, distances: torch.Tensor, H=None) -> torch.Tensor:
     """``__call__`` of the multi-distance class: |crop(ifft2(fft2(pad(a e^{i phs}))[:,None] * H(d) * mask))|,
     shape (B*D,3,h,w). ref: angular_spectrum_method.py:503-522 (used by generatePOH.py:51-70)."""
     G = torch.fft.fft2(pad_field(o, polar(amp, phs)))
-    H = transfer_function(o.w, distances) * o.mask
+    H = (transfer_function(o.w, distances) if H is None else H) * o.mask
     Gz = (G.unsqueeze(1) * H).view(-1, 3, o.rows, o.cols)
     return torch.abs(crop_field(o, torch.fft.ifft2(Gz)))
 

@@ -51,12 +51,14 @@ class TrainState:
 
 
 def make_state(rows0, cols0, pad, coefficient, distance_stack, sd_G, sd_D,
-               z_fixed=1e-3, pitch=optics.DEFAULT_PITCH, wave_length=None, lr_G=1e-3, lr_D=1e-3):
+               z_fixed=1e-3, pitch=optics.DEFAULT_PITCH, wave_length=None, lr_G=1e-3, lr_D=1e-3, consts=None):
     """Constants as ``watermelon.__init__`` builds them. ref: watermelon.py:46-82,
     trainingModel.py:59-67 (filter 0.45, pad 320, linspace(-4e-4,0,21)[:-1])."""
     o = optics.make_optics(rows0, cols0, pad, coefficient, pitch, wave_length)
     H_fixed = optics.transfer_function(o.w, torch.tensor([z_fixed]))[0]
     H_stack = optics.transfer_function(o.w, distance_stack)
+    if consts is not None:  # transfer functions recorded with a fixture (they are host-CPU dependent)
+        H_fixed, H_stack = consts["H_fixed"], consts["H_stack"]
     return TrainState(o, H_fixed, H_stack, nets.as_parameters(sd_G), nets.as_parameters(sd_D), lr_G, lr_D)
 
 
