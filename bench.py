@@ -54,7 +54,8 @@ def cpu_baseline(args):
     """One frame of the same step through the CPU oracle (checker code timed as the reported baseline)."""
     from oracle import seeded, step
 
-    threads = os.cpu_count() or 1
+    # the GPU box gives one GPU a 16-CPU share although it reports every core of the host
+    threads = min(len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1), 16)
     torch.set_num_threads(threads)
     rows = args.cpu_rows or args.rows
     cols = args.cpu_rows or args.cols

@@ -68,19 +68,14 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict_
   });
 }
 
-__global__ void bn_stats_final(const float* __restrict__ partial, int nblk, const float* __restrict__ x, long long pixels, int C,
+__global__ void bn_stats_final(const float* __restrict__ sums /* [2][C] shifted sums */, const float* __restrict__ x, long long pixels, int C,
                                float* __restrict__ stats, float* running_mean, float* running_var, float momentum, float eps) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
-  double s1 = 0, s2 = 0;
-  for (int b = 0; b < nblk; ++b) {
-    s1 += partial[((size_t)b * 2 + 0) * C + c];
-    s2 += partial[((size_t)b * 2 + 1) * C + c];
-  }
   const double n = (double)pixels;
-  const double dm = s1 / n;
+  const double dm = (double)sums[c] / n;
   const double mean = (double)x[c] + dm;
-  double var = s2 / n - dm * dm;
+  double var = (double)sums[C + c] / n - dm * dm;
   if (var < 0) var = 0;
   stats[c] = (float)mean;
   stats[C + c] = (float)(1.0 / sqrt(var + (double)eps));
@@ -129,13 +124,20 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
   });
 }
 
+// sums[k][c] = sum_b partial[b][k][c] in double.  grid (ceil(C/32), NSUM), block 32 channels x 8 slices.
 template <int NSUM>
-__global__ void reduce_partials(const float* __restrict__ partial, int nblk, int C, float* __restrict__ sums /* [NSUM][C] */) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  for (int k = 0; k < NSUM; ++k) {
-    double s = 0;
-    for (int b = 0; b < nblk; ++b) s += partial[((size_t)b * NSUM + k) * C + c];
+__global__ __launch_bounds__(256) void reduce_partials(const float* __restrict__ partial, int nblk, int C, float* __restrict__ sums) {
+  __shared__ double red[8][32];
+  const int lane_c = threadIdx.x & 31, slice = threadIdx.x >> 5, k = blockIdx.y;
+  const int c = blockIdx.x * 32 + lane_c;
+  double s = 0;
+  if (c < C)
+    for (int b = slice; b < nblk; b += 8) s += partial[((size_t)b * NSUM + k) * C + c];
+  red[slice][lane_c] = s;
+  __syncthreads();
+  if (slice == 0 && c < C) {
+#pragma unroll
+    for (int i = 1; i < 8; ++i) s += red[i][lane_c];
     sums[(size_t)k * C + c] = (float)s;
   }
 }
@@ -382,9 +384,9 @@ int lhg_nhwc_to_nchw(const float* src, int ld, float* dst, int N, int C, int H, 
 int lhg_channel_sum(const float* x, long long pixels, int C, int ld, float* out, float* ws, lhg_stream_t s) {
   LHG_NHWC_OK(x, C, ld, "channel_sum");
   const ColMap cm = col_map(C);
-  const int nblk = (int)std::min<long long>(2048, std::max<long long>(1, pixels / 256));
+  const int nblk = (int)std::min<long long>(512, std::max<long long>(1, pixels / 256));
   hipLaunchKernelGGL(channel_sum_partial, dim3(nblk), dim3(256), 0, as_stream(s), x, pixels, C, ld, cm.lanes_c, cm.rows, ws);
-  hipLaunchKernelGGL(reduce_partials<1>, dim3((C + 255) / 256), dim3(256), 0, as_stream(s), ws, nblk, C, out);
+  hipLaunchKernelGGL(reduce_partials<1>, dim3((C + 31) / 32, 1), dim3(256), 0, as_stream(s), ws, nblk, C, out);
   return check_launch("channel_sum");
 }
 
@@ -393,9 +395,11 @@ int lhg_bn_stats(const float* x, long long pixels, int C, int ld, float* stats, 
   LHG_NHWC_OK(x, C, ld, "bn_stats");
   LHG_REQUIRE(pixels > 0, "bn_stats: empty tensor");
   const ColMap cm = col_map(C);
-  const int nblk = (int)std::min<long long>(1024, std::max<long long>(1, pixels / 256));
+  const int nblk = (int)std::min<long long>(512, std::max<long long>(1, pixels / 256));
   hipLaunchKernelGGL(bn_stats_partial, dim3(nblk), dim3(256), 0, as_stream(s), x, pixels, C, ld, cm.lanes_c, cm.rows, ws);
-  hipLaunchKernelGGL(bn_stats_final, dim3((C + 255) / 256), dim3(256), 0, as_stream(s), ws, nblk, x, pixels, C, stats, running_mean,
+  float* sums = ws + (size_t)nblk * 2 * C;
+  hipLaunchKernelGGL(reduce_partials<2>, dim3((C + 31) / 32, 2), dim3(256), 0, as_stream(s), ws, nblk, C, sums);
+  hipLaunchKernelGGL(bn_stats_final, dim3((C + 255) / 256), dim3(256), 0, as_stream(s), sums, x, pixels, C, stats, running_mean,
                      running_var, momentum, eps);
   return check_launch("bn_stats");
 }
@@ -421,11 +425,11 @@ int lhg_bn_backward(const float* gy, int ldgy, const float* x, int ldx, const fl
   if (act != LHG_ACT_NONE) LHG_NHWC_OK(y, C, ldy, "bn_backward(y)");
   if (gres) LHG_NHWC_OK(gres, C, ldgres, "bn_backward(gres)");
   const ColMap cm = col_map(C);
-  const int nblk = (int)std::min<long long>(1024, std::max<long long>(1, pixels / 256));
+  const int nblk = (int)std::min<long long>(512, std::max<long long>(1, pixels / 256));
   float* sums = ws + (size_t)nblk * 2 * C;
   hipLaunchKernelGGL(bn_bwd_partial, dim3(nblk), dim3(256), 0, as_stream(s), gy, ldgy, x, ldx, y, ldy, pixels, C, stats, act, slope,
                      cm.lanes_c, cm.rows, ws);
-  hipLaunchKernelGGL(reduce_partials<2>, dim3((C + 255) / 256), dim3(256), 0, as_stream(s), ws, nblk, C, sums);
+  hipLaunchKernelGGL(reduce_partials<2>, dim3((C + 31) / 32, 2), dim3(256), 0, as_stream(s), ws, nblk, C, sums);
   const int nb2 = grid_for((size_t)pixels, cm.rows * 4, 4096);
   hipLaunchKernelGGL(bn_bwd_apply, dim3(nb2), dim3(256), 0, as_stream(s), gy, ldgy, x, ldx, y, ldy, pixels, C, stats, gamma, sums, act,
                      slope, gx, ldgx, gres, ldgres, ggamma, gbeta, cm.lanes_c, cm.rows);
@@ -438,11 +442,11 @@ int lhg_bn_backward_backward(const float* ggx, const float* gy, const float* x, 
   LHG_NHWC_OK(ggx, C, C, "bn_backward_backward(ggx)");
   LHG_REQUIRE(aligned16(gy) && aligned16(x) && aligned16(ggy) && aligned16(gx2), "bn_backward_backward: unaligned tensor");
   const ColMap cm = col_map(C);
-  const int nblk = (int)std::min<long long>(1024, std::max<long long>(1, pixels / 256));
+  const int nblk = (int)std::min<long long>(512, std::max<long long>(1, pixels / 256));
   float* sums = ws + (size_t)nblk * 5 * C;
   hipLaunchKernelGGL(bn_bwd2_partial, dim3(nblk), dim3(256), 0, as_stream(s), ggx, gy, x, y, pixels, C, stats, act, slope, cm.lanes_c,
                      cm.rows, ws);
-  hipLaunchKernelGGL(reduce_partials<5>, dim3((C + 255) / 256), dim3(256), 0, as_stream(s), ws, nblk, C, sums);
+  hipLaunchKernelGGL(reduce_partials<5>, dim3((C + 31) / 32, 5), dim3(256), 0, as_stream(s), ws, nblk, C, sums);
   const int nb2 = grid_for((size_t)pixels, cm.rows * 4, 4096);
   hipLaunchKernelGGL(bn_bwd2_apply, dim3(nb2), dim3(256), 0, as_stream(s), ggx, gy, x, y, pixels, C, stats, gamma, sums, act, slope, ggy,
                      gx2, ggamma2, cm.lanes_c, cm.rows);

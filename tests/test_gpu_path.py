@@ -171,7 +171,9 @@ def test_unet_and_generator_against_golden(golden):
     y = G.part1.part1(x)
     (y * g["unet_proj"].to(DEV)).sum().backward()
     assert rel_err(y.detach().cpu(), g["unet_train"]) < PARITY
-    assert rel_err(x.grad.cpu(), g["unet_train_dx"]) < 1e-3
+    # 18 train-mode BNs over as few as 8 samples (2x2 bottleneck, batch 2): ill-conditioned, fp32 summation order shows at
+    # the 1e-2 level; test_unet_train_gradients_vs_fp64_truth bounds the GPU error by the CPU fp32 error instead.
+    assert rel_err(x.grad.cpu(), g["unet_train_dx"]) < 5e-2
     named = dict(G.named_parameters())
     for k, ref in g["unet_train_param_grads"].items():
         if k.endswith("convolution_layer_2.bias"):
@@ -192,6 +194,40 @@ def test_unet_and_generator_against_golden(golden):
     named = dict(G.named_parameters())
     for k, ref in g["poh_train_param_grads"].items():
         assert rel_err(named[k].grad.cpu(), ref["full"]) < 2e-2, k
+
+
+@pytest.mark.parametrize("rows,batch", [(32, 2), (64, 4)])
+def test_unet_train_gradients_vs_fp64_truth(rows, batch):
+    """Train-mode UNet forward + backward: the fp32 GPU result must be as close to an fp64 evaluation of the same
+    maths as the fp32 CPU (reference-arithmetic) result is."""
+    from learned_hologram_gan_amd.neural_network_components import UNet
+
+    sd32 = {k[len("part1.part1."):]: v for k, v in seeded.generator_state_dict().items() if k.startswith("part1.part1.")}
+    rgbd, _, _ = seeded.smooth_batch(batch, rows, rows, seed=21)
+    proj = torch.randn((batch, 6, rows, rows), generator=torch.Generator().manual_seed(8))
+    keys = ("encoder1.0.0.convolution_layer_1.weight", "bottleneck.1.0.convolution_layer_2.weight", "decoder2.1.weight",
+            "decoder4.0.batch_norm_layer_2.weight", "final_layer.0.weight", "encoder3.1.0.convolution_layer_3.weight")
+
+    def run_oracle(dtype):
+        sd = nets.as_parameters({k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd32.items()})
+        x = rgbd.to(dtype).requires_grad_(True)
+        y = nets.unet(sd, "", x, True)
+        (y * proj.to(dtype)).sum().backward()
+        return y.detach().double(), x.grad.double(), {k: sd[k].grad.double() for k in keys}
+
+    y64, dx64, gw64 = run_oracle(torch.float64)
+    y32, dx32, gw32 = run_oracle(torch.float32)
+    net = UNet(6, 4)
+    net.load_state_dict(sd32)
+    net.to(DEV).train()
+    x = rgbd.to(DEV).requires_grad_(True)
+    y = net(x)
+    (y * proj.to(DEV)).sum().backward()
+    named = dict(net.named_parameters())
+    assert rel_err(y.detach().cpu().double(), y64) <= max(4 * rel_err(y32, y64), 2e-6)
+    assert rel_err(x.grad.cpu().double(), dx64) <= max(4 * rel_err(dx32, dx64), 1e-5)
+    for k in keys:
+        assert rel_err(named[k].grad.cpu().double(), gw64[k]) <= max(4 * rel_err(gw32[k], gw64[k]), 1e-5), k
 
 
 @pytest.mark.parametrize("rows,cols,pad,batch", [(64, 64, 32, 2), (96, 96, 16, 1)])
@@ -284,7 +320,7 @@ def test_train_step_against_reference_loop(golden):
             if k in ("block2.0.bias", "block3.0.bias", "block4.0.bias", "block5.0.bias", "block6.0.bias"):
                 continue
             bad = ((sd[k].cpu() - v).abs() > 2e-4 + 1e-3 * v.abs()).float().mean().item()
-            assert bad < 5e-3, (k, bad)  # a sign flip of a near-zero gradient moves a weight by 2*lr
+            assert bad <= max(5e-3, 3.0 / v.numel()), (k, bad)  # a sign flip of a near-zero gradient moves a weight by 2*lr
 
 
 def test_train_step_vs_oracle_fresh_inputs():
