@@ -1,0 +1,102 @@
+"""world_size-2 gloo test of the data-parallel layer (distributed.GradSynchronizer + optim.FlatParams):
+bucketed, hook-driven all-reduce of a flat gradient buffer must equal the average of the per-rank gradients,
+including parameters that receive no gradient in a pass and repeated backward passes.  CPU only — the layer is
+device agnostic; on the GPU box the same code runs over RCCL."""
+
+import os
+import socket
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+class _Net(torch.nn.Module):
+    def __init__(self):
+        super().__init__()
+        self.a = torch.nn.Linear(8, 16)
+        self.b = torch.nn.Linear(16, 16)
+        self.unused = torch.nn.Linear(4, 4)  # never gets a gradient
+        self.c = torch.nn.Linear(16, 2)
+
+    def forward(self, x):
+        return self.c(torch.tanh(self.b(torch.tanh(self.a(x)))))
+
+
+def _worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from learned_hologram_gan_amd import distributed
+    from learned_hologram_gan_amd.optim import FlatParams
+
+    r, w, _ = distributed.init_from_env("gloo")
+    assert (r, w) == (rank, world) and distributed.world_size() == world
+    torch.manual_seed(0)
+    net = _Net()
+    flat = FlatParams(net)
+    assert all(p.data_ptr() == flat.data.data_ptr() + 4 * o for p, o in zip(flat.params, flat.offsets))
+    sync = distributed.GradSynchronizer(flat.params, flat.offsets, flat.grad, n_buckets=3)
+    assert len(sync.ranges) >= 2 and sum(sync.expected) == len(flat.params)
+    assert sorted(sync.ranges)[0][0] == 0 and max(hi for _, hi in sync.ranges) == flat.grad.numel()
+
+    data = [torch.randn(5, 8, generator=torch.Generator().manual_seed(100 + k)) for k in range(world)]
+    ok = True
+    for it in range(2):  # repeated passes: counters must re-arm
+        # expected: average over ranks of the local gradients (every rank can compute all of them)
+        expect = torch.zeros_like(flat.grad)
+        for k in range(world):
+            ref = _Net()
+            ref.load_state_dict(net.state_dict())
+            ((ref(data[k]) ** 2).mean() * (it + 1)).backward()
+            for p_ref, p, o in zip([q_ for q_ in ref.parameters()], flat.params, flat.offsets):
+                if p_ref.grad is not None:
+                    expect[o:o + p.numel()] += p_ref.grad.reshape(-1) / world
+        flat.zero_grad()
+        sync.start()
+        ((net(data[rank]) ** 2).mean() * (it + 1)).backward()
+        sync.finish()
+        ok = ok and torch.allclose(flat.grad, expect, rtol=1e-5, atol=1e-7)
+        ok = ok and all(sync._launched)
+    # outside start()/finish() the hooks must be inert (G backward also reaches the critic's parameters)
+    flat.zero_grad()
+    (net(data[rank]) ** 2).mean().backward()
+    ok = ok and sync._work == [] or not sync._armed
+    dist.barrier()
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_bucketed_grad_allreduce_world2():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(results) == [(0, True), (1, True)]
+
+
+def test_single_process_sync_is_a_noop():
+    from learned_hologram_gan_amd.distributed import GradSynchronizer
+    from learned_hologram_gan_amd.optim import FlatParams
+
+    net = _Net()
+    flat = FlatParams(net)
+    sync = GradSynchronizer(flat.params, flat.offsets, flat.grad, 4)
+    assert not sync.enabled
+    flat.zero_grad()
+    sync.start()
+    net(torch.randn(3, 8)).sum().backward()
+    sync.finish()
+    assert flat.grad.abs().sum() > 0 and net.unused.weight.grad.abs().sum() == 0
