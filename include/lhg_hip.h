@@ -49,6 +49,10 @@ const char* lhg_last_error(void);
  * events recorded on the launch stream; used by bench.py for the roofline figures.  lhg_profile_read
  * synchronises the recorded events and returns the summed duration, the launch count and the executed
  * (padded-tile) flops since the last enable. */
+/* The GEMM launcher times its tiling variants once per new geometry (HIP events on the caller's stream, skipped
+ * while the stream is being captured) and caches the fastest; every variant gives identical values.
+ * lhg_autotune(0) turns this off (a fixed heuristic is used instead); env LHG_AUTOTUNE=0 does the same. */
+int lhg_autotune(int on);
 int lhg_profile_enable(int kernel, int on);
 int lhg_profile_read(int kernel, double* total_ms, long long* launches, double* executed_flops);
 

@@ -23,6 +23,9 @@
 //       consecutive channels (conflict-free ds_read_b32).  K (pixels) is split over blockIdx.z
 //       into partial slabs that lhg_wgrad_reduce sums (deterministic, no float atomics).
 #include <algorithm>
+#include <array>
+#include <cstdlib>
+#include <map>
 #include <utility>
 #include <vector>
 
@@ -209,6 +212,8 @@ __global__ __launch_bounds__(256, 2) void gg_kernel(const GGParams p) {
   }
 }
 
+#include "gg2_kernel.inc"
+
 // ------------------------------------------------------------------------------------ wg_kernel
 constexpr int WG_TILE = 64;
 constexpr int WG_LDS_ROW = WG_TILE + 4;
@@ -294,6 +299,8 @@ __global__ __launch_bounds__(256, 2) void wg_kernel(const WGParams p) {
   }
 }
 
+#include "wg2_kernel.inc"
+
 // ------------------------------------------------------------------------------------ small kernels
 __global__ void pack_weight_kernel(const float* __restrict__ w, int D0, int D1, int T, int rows_from_d0,
                                    float* __restrict__ dst, int rows_pad, int k_pad) {
@@ -348,6 +355,8 @@ struct KernelTimer {
   }
 };
 static KernelTimer g_timer[2];  // 0: gg_kernel, 1: wg_kernel
+static bool g_autotune_enabled = true;
+static std::map<std::array<int, 12>, int> g_gg_choice, g_wg_choice;
 
 struct ScopedKernelTime {
   KernelTimer& t;
@@ -373,15 +382,73 @@ static int launch_gg(GGParams& p, hipStream_t st) {
   LHG_REQUIRE((reinterpret_cast<uintptr_t>(p.wp) & 15) == 0, "gather-GEMM: packed weights must be 16-byte aligned");
   LHG_REQUIRE(p.rows_pad % 64 == 0 && p.rows_pad >= g.Co, "gather-GEMM: rows_pad %d must be a multiple of 64 covering Co=%d", p.rows_pad, g.Co);
   LHG_REQUIRE((long long)g.N * g.Ho * g.Wo < (1ll << 31) && (long long)g.N * g.Hi * g.Wi < (1ll << 31), "gather-GEMM: more than 2^31 pixels");
-  auto blocks = [&](int bm, int bn) { return (long long)((g.M + bm - 1) / bm) * (p.rows_pad / bn); };
-  ScopedKernelTime timed(0, st, 2.0 * g.M * (double)p.rows_pad * g.Ci * g.T);
-  if (p.rows_pad % 128 == 0 && blocks(128, 128) >= 400) {
-    hipLaunchKernelGGL((gg_kernel<128, 128, 2, 2>), dim3((unsigned)blocks(128, 128)), dim3(256), 0, st, p);
-  } else if (blocks(256, 64) >= 400) {
-    hipLaunchKernelGGL((gg_kernel<256, 64, 4, 1>), dim3((unsigned)blocks(256, 64)), dim3(256), 0, st, p);
-  } else {
-    hipLaunchKernelGGL((gg_kernel<64, 64, 2, 2>), dim3((unsigned)blocks(64, 64)), dim3(256), 0, st, p);
+  // extents addressed through 32-bit buffer descriptors by the pipelined kernels
+  int max_ws = 0;
+  for (int t = 0; t < g.T; ++t) max_ws = std::max(max_ws, g.ws[t]);
+  const unsigned long long in_bytes = (((unsigned long long)g.N * g.Hi * g.Wi - 1) * g.ldi + g.Ci) * 4ull;
+  const unsigned long long wp_bytes = (unsigned long long)(max_ws + 1) * p.rows_pad * g.Ci * 4ull;
+  const bool small = in_bytes < (1ull << 32) - 64 && wp_bytes < (1ull << 32) - 64;
+  const unsigned ib = (unsigned)in_bytes, wb = (unsigned)wp_bytes;
+  auto blocks = [&](int bm, int bn) { return (unsigned)(((g.M + bm - 1) / bm) * (p.rows_pad / bn)); };
+  const bool n128 = p.rows_pad % 128 == 0;
+
+  // tiling variants; every variant produces the same values (the K order is identical)
+  constexpr int NV = 6;
+  auto valid = [&](int v) { return (v < 3 ? small : true) && ((v == 0 || v == 3) ? n128 : true); };
+  auto run = [&](int v) {
+    switch (v) {
+      case 0: hipLaunchKernelGGL((gg2_kernel<128, 128, 2, 2>), dim3(blocks(128, 128)), dim3(256), 0, st, p, ib, wb); break;
+      case 1: hipLaunchKernelGGL((gg2_kernel<128, 64, 2, 2>), dim3(blocks(128, 64)), dim3(256), 0, st, p, ib, wb); break;
+      case 2: hipLaunchKernelGGL((gg2_kernel<64, 64, 2, 2>), dim3(blocks(64, 64)), dim3(256), 0, st, p, ib, wb); break;
+      case 3: hipLaunchKernelGGL((gg_kernel<128, 128, 2, 2>), dim3(blocks(128, 128)), dim3(256), 0, st, p); break;
+      case 4: hipLaunchKernelGGL((gg_kernel<256, 64, 4, 1>), dim3(blocks(256, 64)), dim3(256), 0, st, p); break;
+      default: hipLaunchKernelGGL((gg_kernel<64, 64, 2, 2>), dim3(blocks(64, 64)), dim3(256), 0, st, p); break;
+    }
+  };
+  auto heuristic = [&]() {
+    if (small) return n128 && blocks(128, 128) >= 400 ? 0 : (blocks(128, 64) >= 400 ? 1 : 2);
+    return n128 && blocks(128, 128) >= 400 ? 3 : (blocks(256, 64) >= 400 ? 4 : 5);
+  };
+
+  static const int forced = [] { const char* e = getenv("LHG_GG_VARIANT"); return e ? atoi(e) : -1; }();
+  static const bool tune = [] { const char* e = getenv("LHG_AUTOTUNE"); return e ? atoi(e) != 0 : true; }();
+  int choice = -1;
+  if (forced >= 0 && forced < NV && valid(forced)) choice = forced;
+  if (choice < 0 && tune && g_autotune_enabled) {
+    // One-time timing of the valid variants for a geometry not seen before (HIP events on `st`; this is the
+    // only place the library synchronises, and it is skipped while the stream is being captured).
+    const std::array<int, 12> key = {g.M, p.rows_pad, g.Ci, g.Co, g.T, g.istep, g.ostep, g.Hi, g.Wi, g.ldi, g.ldo, p.planar_out};
+    auto it = g_gg_choice.find(key);
+    if (it != g_gg_choice.end()) {
+      choice = it->second;
+    } else {
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        float best = 1e30f;
+        for (int v = 0; v < NV; ++v) {
+          if (!valid(v)) continue;
+          run(v);  // warm-up (code object load, caches)
+          (void)hipEventRecord(e0, st);
+          run(v);
+          run(v);
+          (void)hipEventRecord(e1, st);
+          if (hipEventSynchronize(e1) != hipSuccess || hipGetLastError() != hipSuccess) continue;
+          float ms = 0;
+          (void)hipEventElapsedTime(&ms, e0, e1);
+          if (ms < best) { best = ms; choice = v; }
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        if (choice >= 0) g_gg_choice[key] = choice;
+      }
+    }
   }
+  if (choice < 0) choice = heuristic();
+  ScopedKernelTime timed(0, st, 2.0 * g.M * (double)p.rows_pad * g.Ci * g.T);
+  run(choice);
   return check_launch("gg_kernel");
 }
 
@@ -393,13 +460,68 @@ static int launch_wg(WGParams& p, int S, hipStream_t st) {
   LHG_REQUIRE(S >= 1 && S <= 65535, "wgrad: bad split count %d", S);
   const int steps = (g.M + BK - 1) / BK;
   p.kchunk = ((steps + S - 1) / S) * BK;
-  dim3 grid((p.m_pad / 64) * (p.n_pad / 64), g.T, S);
+  const unsigned long long in_bytes = (((unsigned long long)g.N * g.Hi * g.Wi - 1) * g.ldi + g.Ci) * 4ull;
+  const unsigned long long go_bytes = (((unsigned long long)g.N * g.Ho * g.Wo - 1) * g.ldo + g.Co) * 4ull;
+  const bool small = in_bytes < (1ull << 32) - 64 && go_bytes < (1ull << 32) - 64;
+  const unsigned ib = (unsigned)in_bytes, gb = (unsigned)go_bytes;
+  const bool m128 = p.m_pad % 128 == 0, n128 = p.n_pad % 128 == 0;
+  constexpr int NV = 5;
+  auto valid = [&](int v) { return v == 4 || (small && (v == 0 ? m128 && n128 : v == 1 ? m128 : v == 2 ? n128 : true)); };
+  auto run = [&](int v) {
+    auto grid = [&](int bm, int bn) { return dim3((p.m_pad / bm) * (p.n_pad / bn), g.T, S); };
+    switch (v) {
+      case 0: hipLaunchKernelGGL((wg2_kernel<128, 128>), grid(128, 128), dim3(256), 0, st, p, ib, gb); break;
+      case 1: hipLaunchKernelGGL((wg2_kernel<128, 64>), grid(128, 64), dim3(256), 0, st, p, ib, gb); break;
+      case 2: hipLaunchKernelGGL((wg2_kernel<64, 128>), grid(64, 128), dim3(256), 0, st, p, ib, gb); break;
+      case 3: hipLaunchKernelGGL((wg2_kernel<64, 64>), grid(64, 64), dim3(256), 0, st, p, ib, gb); break;
+      default: hipLaunchKernelGGL(wg_kernel, grid(64, 64), dim3(256), 0, st, p); break;
+    }
+  };
+  static const int forced = [] { const char* e = getenv("LHG_WG_VARIANT"); return e ? atoi(e) : -1; }();
+  static const bool tune = [] { const char* e = getenv("LHG_AUTOTUNE"); return e ? atoi(e) != 0 : true; }();
+  int choice = -1;
+  if (forced >= 0 && forced < NV && valid(forced)) choice = forced;
+  if (choice < 0 && tune && g_autotune_enabled) {
+    const std::array<int, 12> key = {g.M, p.m_pad, p.n_pad, g.T, S, g.istep, g.ostep, g.Hi, g.Wi, g.ldi, g.ldo, g.ws[0]};
+    auto it = g_wg_choice.find(key);
+    if (it != g_wg_choice.end()) {
+      choice = it->second;
+    } else {
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        float best = 1e30f;
+        for (int v = 0; v < NV; ++v) {
+          if (!valid(v)) continue;
+          run(v);
+          (void)hipEventRecord(e0, st);
+          run(v);
+          run(v);
+          (void)hipEventRecord(e1, st);
+          if (hipEventSynchronize(e1) != hipSuccess || hipGetLastError() != hipSuccess) continue;
+          float ms = 0;
+          (void)hipEventElapsedTime(&ms, e0, e1);
+          if (ms < best) { best = ms; choice = v; }
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        if (choice >= 0) g_wg_choice[key] = choice;
+      }
+    }
+  }
+  if (choice < 0) choice = small ? (m128 && n128 && (p.m_pad / 128) * (p.n_pad / 128) * g.T * S >= 400 ? 0 : 3) : 4;
   ScopedKernelTime timed(1, st, 2.0 * g.M * (double)p.m_pad * p.n_pad * g.T);
-  hipLaunchKernelGGL(wg_kernel, grid, dim3(256), 0, st, p);
+  run(choice);
   return check_launch("wg_kernel");
 }
 
-static int pick_splits(long long pixels, int tiles) {
+// Split count for the pixel (K) axis of a weight gradient: enough workgroups to fill 256 CUs x 2-3 resident blocks a
+// few times over, assuming the largest tile the padded extents allow (the launcher autotunes the tile for that S).
+static int pick_splits(long long pixels, int m_pad, int n_pad, int taps) {
+  const int bm = m_pad % 128 == 0 ? 128 : 64, bn = n_pad % 128 == 0 ? 128 : 64;
+  const long long tiles = (long long)(m_pad / bm) * (n_pad / bn) * taps;
   const long long steps = (pixels + BK - 1) / BK;
   long long s = (1536 + tiles - 1) / tiles;
   const long long cap = steps / 8 > 1 ? steps / 8 : 1;
@@ -435,6 +557,11 @@ static bool conv_args_ok(int KH, int KW, int stride) {
 using namespace lhg;
 
 extern "C" {
+
+int lhg_autotune(int on) {
+  g_autotune_enabled = on != 0;
+  return LHG_OK;
+}
 
 int lhg_profile_enable(int kernel, int on) {
   LHG_REQUIRE(kernel == 0 || kernel == 1, "profile_enable: kernel must be 0 (gather-GEMM) or 1 (wgrad-GEMM)");
@@ -527,7 +654,7 @@ int lhg_conv2d_backward_input(const float* gy, int N, int H, int W, int Co, int 
 
 int lhg_conv2d_wgrad_splits(int N, int H, int W, int Ci, int Co, int KH, int KW, int stride) {
   const int Ho = (H + 2 * (KH / 2) - KH) / stride + 1, Wo = (W + 2 * (KW / 2) - KW) / stride + 1;
-  return pick_splits((long long)N * Ho * Wo, (pad64(Ci) / 64) * (pad64(Co) / 64) * KH * KW);
+  return pick_splits((long long)N * Ho * Wo, pad64(Ci), pad64(Co), KH * KW);
 }
 
 int lhg_conv2d_backward_weight(const float* x, int N, int H, int W, int Ci, int ldx, const float* gy, int Co, int ldgy,
@@ -575,7 +702,7 @@ int lhg_conv_transpose2x2_backward_input(const float* gy, int N, int H, int W, i
 }
 
 int lhg_conv_transpose2x2_wgrad_splits(int N, int H, int W, int Ci, int Co) {
-  return pick_splits((long long)N * H * W, (pad64(Ci) / 64) * (pad64(Co) / 64));
+  return pick_splits((long long)N * H * W, pad64(Ci), pad64(Co), 1);
 }
 
 int lhg_conv_transpose2x2_backward_weight(const float* x, int N, int H, int W, int Ci, int ldx, const float* gy, int Co, int ldgy,

@@ -33,6 +33,7 @@ class AsmFilter(C.Structure):
 _SIGNATURES = {
     "lhg_abi_version": [],
     "lhg_last_error": [],
+    "lhg_autotune": [_i],
     "lhg_profile_enable": [_i, _i],
     "lhg_profile_read": [_i, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)],
     "lhg_nchw_to_nhwc": [_p, _p, _i, _i, _i, _i, _i, _p],
