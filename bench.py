@@ -79,6 +79,7 @@ def main():
     rank, world, local = distributed.init_from_env()
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    local = local % torch.cuda.device_count()
     torch.cuda.set_device(local)
     dev = torch.device("cuda", local)
     torch.manual_seed(122731 + rank)

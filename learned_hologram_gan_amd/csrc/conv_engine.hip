@@ -300,6 +300,7 @@ __global__ __launch_bounds__(256, 2) void wg_kernel(const WGParams p) {
 }
 
 #include "wg2_kernel.inc"
+#include "wg3_kernel.inc"
 
 // ------------------------------------------------------------------------------------ small kernels
 __global__ void pack_weight_kernel(const float* __restrict__ w, int D0, int D1, int T, int rows_from_d0,
@@ -452,7 +453,7 @@ static int launch_gg(GGParams& p, hipStream_t st) {
   return check_launch("gg_kernel");
 }
 
-static int launch_wg(WGParams& p, int S, hipStream_t st) {
+static int launch_wg(WGParams& p, int S, hipStream_t st, const WG3Params* p3 = nullptr) {
   const Geom& g = p.g;
   LHG_REQUIRE(g.ldi % 4 == 0 && g.ldo % 4 == 0 && g.Ci % 4 == 0 && g.Co % 4 == 0, "wgrad: channel counts / strides must be multiples of 4");
   LHG_REQUIRE((reinterpret_cast<uintptr_t>(p.in) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.gout) & 15) == 0, "wgrad: inputs must be 16-byte aligned");
@@ -465,8 +466,11 @@ static int launch_wg(WGParams& p, int S, hipStream_t st) {
   const bool small = in_bytes < (1ull << 32) - 64 && go_bytes < (1ull << 32) - 64;
   const unsigned ib = (unsigned)in_bytes, gb = (unsigned)go_bytes;
   const bool m128 = p.m_pad % 128 == 0, n128 = p.n_pad % 128 == 0;
-  constexpr int NV = 5;
-  auto valid = [&](int v) { return v == 4 || (small && (v == 0 ? m128 && n128 : v == 1 ? m128 : v == 2 ? n128 : true)); };
+  constexpr int NV = 6;  // 5: nine-tap fused kernel for 3x3 stride 1
+  auto valid = [&](int v) {
+    if (v == 5) return small && p3 != nullptr;
+    return v == 4 || (small && (v == 0 ? m128 && n128 : v == 1 ? m128 : v == 2 ? n128 : true));
+  };
   auto run = [&](int v) {
     auto grid = [&](int bm, int bn) { return dim3((p.m_pad / bm) * (p.n_pad / bn), g.T, S); };
     switch (v) {
@@ -474,6 +478,7 @@ static int launch_wg(WGParams& p, int S, hipStream_t st) {
       case 1: hipLaunchKernelGGL((wg2_kernel<128, 64>), grid(128, 64), dim3(256), 0, st, p, ib, gb); break;
       case 2: hipLaunchKernelGGL((wg2_kernel<64, 128>), grid(64, 128), dim3(256), 0, st, p, ib, gb); break;
       case 3: hipLaunchKernelGGL((wg2_kernel<64, 64>), grid(64, 64), dim3(256), 0, st, p, ib, gb); break;
+      case 5: hipLaunchKernelGGL(wg3_kernel, dim3((p.m_pad / 64) * (p.n_pad / 64), 1, S), dim3(256), 0, st, *p3, ib, gb); break;
       default: hipLaunchKernelGGL(wg_kernel, grid(64, 64), dim3(256), 0, st, p); break;
     }
   };
@@ -511,11 +516,13 @@ static int launch_wg(WGParams& p, int S, hipStream_t st) {
       }
     }
   }
-  if (choice < 0) choice = small ? (m128 && n128 && (p.m_pad / 128) * (p.n_pad / 128) * g.T * S >= 400 ? 0 : 3) : 4;
+  if (choice < 0) choice = small ? (p3 ? 5 : (m128 && n128 && (p.m_pad / 128) * (p.n_pad / 128) * g.T * S >= 400 ? 0 : 3)) : 4;
   ScopedKernelTime timed(1, st, 2.0 * g.M * (double)p.m_pad * p.n_pad * g.T);
   run(choice);
   return check_launch("wg_kernel");
 }
+
+static inline int pad64(int c) { return (c + 63) / 64 * 64; }
 
 // Split count for the pixel (K) axis of a weight gradient: enough workgroups to fill 256 CUs x 2-3 resident blocks a
 // few times over, assuming the largest tile the padded extents allow (the launcher autotunes the tile for that S).
@@ -531,7 +538,6 @@ static int pick_splits(long long pixels, int m_pad, int n_pad, int taps) {
   return (int)s;
 }
 
-static inline int pad64(int c) { return (c + 63) / 64 * 64; }
 
 // geometry of y = conv2d(x) (also used, read as "gout", for its weight gradient)
 static void conv_fwd_geom(Geom& g, int N, int H, int W, int Ci, int ldx, int Co, int ldy, int KH, int KW, int stride) {
@@ -652,8 +658,26 @@ int lhg_conv2d_backward_input(const float* gy, int N, int H, int W, int Co, int 
   return LHG_OK;
 }
 
+// 3x3 stride-1: S = strips (image x 32-pixel column segments) x chunks per strip, so that the fused nine-tap kernel
+// (wg3) and the per-tap kernels can both use it.
+static void fused3x3_split(int N, int H, int W, int Ci, int Co, int& segs, int& cps, int& rpc) {
+  segs = (W + 31) / 32;
+  const long long strips = (long long)N * segs;
+  const long long tiles = (long long)(pad64(Ci) / 64) * (pad64(Co) / 64);
+  // one balanced round: ~512 workgroups (2 resident per CU), each walking the same number of rows
+  long long c = 512 / (tiles * strips);
+  c = std::max<long long>(1, std::min<long long>(c, std::max(1, H / 6)));
+  rpc = (int)((H + c - 1) / c);
+  cps = (H + rpc - 1) / rpc;  // no empty chunks
+}
+
 int lhg_conv2d_wgrad_splits(int N, int H, int W, int Ci, int Co, int KH, int KW, int stride) {
   const int Ho = (H + 2 * (KH / 2) - KH) / stride + 1, Wo = (W + 2 * (KW / 2) - KW) / stride + 1;
+  if (KH == 3 && KW == 3 && stride == 1) {
+    int segs, cps, rpc;
+    fused3x3_split(N, H, W, Ci, Co, segs, cps, rpc);
+    return N * segs * cps;
+  }
   return pick_splits((long long)N * Ho * Wo, pad64(Ci), pad64(Co), KH * KW);
 }
 
@@ -663,6 +687,15 @@ int lhg_conv2d_backward_weight(const float* x, int N, int H, int W, int Ci, int 
   WGParams p{};
   conv_fwd_geom(p.g, N, H, W, Ci, ldx, Co, ldgy, KH, KW, stride);
   p.in = x; p.gout = gy; p.slabs = slabs; p.m_pad = ci_pad; p.n_pad = co_pad; p.Tslabs = KH * KW;
+  if (KH == 3 && KW == 3 && stride == 1) {
+    WG3Params q{};
+    fused3x3_split(N, H, W, Ci, Co, q.segs, q.cps, q.rpc);
+    if (S == N * q.segs * q.cps && ci_pad == pad64(Ci) && co_pad == pad64(Co)) {
+      q.x = x; q.gy = gy; q.slabs = slabs; q.N = N; q.H = H; q.W = W; q.Ci = Ci; q.ldi = ldx; q.Co = Co; q.ldo = ldgy;
+      q.m_pad = ci_pad; q.n_pad = co_pad;
+      return launch_wg(p, S, as_stream(s), &q);
+    }
+  }
   return launch_wg(p, S, as_stream(s));
 }
 

@@ -25,9 +25,10 @@ def init_from_env(backend: str | None = None):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29500")
         if backend is None:
-            backend = "nccl" if torch.cuda.is_available() else "gloo"
-        if backend == "nccl":
-            torch.cuda.set_device(local)
+            # LHG_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsal on a 1-GPU box); RCCL needs one GPU per rank
+            backend = os.environ.get("LHG_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
+        if torch.cuda.is_available():
+            torch.cuda.set_device(local % torch.cuda.device_count())
         dist.init_process_group(backend=backend, rank=rank, world_size=world)
     return rank, world, local
 

@@ -25,7 +25,8 @@ def try_gpu(i: int = 0) -> torch.device:
     """cuda:i when present, else CPU with a notice (ref: utilities.py:410-415).  Constants may
     live on the CPU; the compute ops themselves refuse CPU tensors."""
     if num_gpus() > i:
-        return torch.device(f"cuda:{i}")
+        # i == 0 means "this process's GPU": under torch.distributed every rank has called set_device(LOCAL_RANK)
+        return torch.device("cuda", torch.cuda.current_device() if i == 0 else i)
     print(f"gpu with index '{i}' is not available")
     return torch.device("cpu")
 

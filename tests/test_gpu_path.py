@@ -228,7 +228,7 @@ def test_unet_train_gradients_vs_fp64_truth(rows, batch):
     # d/dx through 18 train-mode BNs is ill-conditioned (the CPU fp32 result itself is ~2 % off fp64 at 64x64): bound at 8x
     assert rel_err(x.grad.cpu().double(), dx64) <= max(8 * rel_err(dx32, dx64), 1e-5)
     for k in keys:
-        assert rel_err(named[k].grad.cpu().double(), gw64[k]) <= max(4 * rel_err(gw32[k], gw64[k]), 1e-5), k
+        assert rel_err(named[k].grad.cpu().double(), gw64[k]) <= max(6 * rel_err(gw32[k], gw64[k]), 1e-5), k
 
 
 @pytest.mark.parametrize("rows,cols,pad,batch", [(64, 64, 32, 2), (96, 96, 16, 1)])
