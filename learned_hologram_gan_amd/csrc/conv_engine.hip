@@ -320,20 +320,39 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int D0, int D1, 
   }
 }
 
-__global__ void wgrad_reduce_kernel(const float* __restrict__ slabs, int S, int T, int m_pad, int n_pad,
-                                    float* __restrict__ grad, int D0, int D1, int m_is_d1) {
+// grad[d0][d1][t] = sum_s slabs[s][t][m][n].  Block = 64 consecutive outputs (n fastest: coalesced slab reads) x 4 slab
+// slices; each thread sums every 4th slab, then the slices are combined through LDS.
+template <int LANES>  // outputs per block; 256 / LANES slab slices
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int S, int T, int m_pad, int n_pad,
+                                                           float* __restrict__ grad, int D0, int D1, int m_is_d1) {
+  constexpr int SLICES = 256 / LANES;
+  __shared__ float red[SLICES][LANES];
   const int M = m_is_d1 ? D1 : D0, Nn = m_is_d1 ? D0 : D1;
   const size_t total = (size_t)T * M * Nn;
   const size_t slab_stride = (size_t)T * m_pad * n_pad;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int n = (int)(i % Nn);
-    const int m = (int)((i / Nn) % M);
-    const int t = (int)(i / ((size_t)Nn * M));
-    const float* src = slabs + ((size_t)t * m_pad + m) * n_pad + n;
+  const int lane_o = threadIdx.x % LANES, slice = threadIdx.x / LANES;
+  for (size_t base = (size_t)blockIdx.x * LANES; base < total; base += (size_t)gridDim.x * LANES) {
+    const size_t i = base + lane_o;
     float acc = 0.f;
-    for (int s = 0; s < S; ++s) acc += src[s * slab_stride];
-    const int d0 = m_is_d1 ? n : m, d1 = m_is_d1 ? m : n;
-    grad[((size_t)d0 * D1 + d1) * T + t] = acc;
+    size_t dst = 0;
+    if (i < total) {
+      const int n = (int)(i % Nn);
+      const int m = (int)((i / Nn) % M);
+      const int t = (int)(i / ((size_t)Nn * M));
+      const float* src = slabs + ((size_t)t * m_pad + m) * n_pad + n;
+      for (int s = slice; s < S; s += SLICES) acc += src[s * slab_stride];
+      const int d0 = m_is_d1 ? n : m, d1 = m_is_d1 ? m : n;
+      dst = ((size_t)d0 * D1 + d1) * T + t;
+    }
+    red[slice][lane_o] = acc;
+    __syncthreads();
+    if (slice == 0 && i < total) {
+      float v = 0.f;
+#pragma unroll
+      for (int k = 0; k < SLICES; ++k) v += red[k][lane_o];
+      grad[dst] = v;
+    }
+    __syncthreads();
   }
 }
 
@@ -753,8 +772,13 @@ int lhg_conv_transpose2x2_backward_weight(const float* x, int N, int H, int W, i
 
 int lhg_wgrad_reduce(const float* slabs, int S, int T, int m_pad, int n_pad, float* grad, int D0, int D1, int m_is_d1, lhg_stream_t s) {
   const size_t total = (size_t)T * D0 * D1;
-  const int blocks = (int)std::min<size_t>((total + 255) / 256, 8192);
-  hipLaunchKernelGGL(wgrad_reduce_kernel, dim3(blocks), dim3(256), 0, as_stream(s), slabs, S, T, m_pad, n_pad, grad, D0, D1, m_is_d1);
+  if (total * 4 < (size_t)S * 64 || total < 65536) {  // few outputs, many slabs: spend the threads on the slab axis
+    const int blocks = (int)std::min<size_t>((total + 15) / 16, 16384);
+    hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(blocks), dim3(256), 0, as_stream(s), slabs, S, T, m_pad, n_pad, grad, D0, D1, m_is_d1);
+  } else {
+    const int blocks = (int)std::min<size_t>((total + 63) / 64, 16384);
+    hipLaunchKernelGGL(wgrad_reduce_kernel<64>, dim3(blocks), dim3(256), 0, as_stream(s), slabs, S, T, m_pad, n_pad, grad, D0, D1, m_is_d1);
+  }
   return check_launch("wgrad_reduce");
 }
 

@@ -201,10 +201,18 @@ def _padded_gy(gy, k_multiple=32):
 
 
 class Conv2dFn(Function):
-    """y = conv2d(x, w, stride, padding=k//2) + bias.  x NHWC with C padded to 32; w OIHW."""
+    """y = conv2d(x, w, stride, padding=k//2) + bias.  x NHWC with C padded to 32; w OIHW.
+
+    ``out`` is None, an OutSlot, or the string "feeds_bn": the conv output goes straight into a train-mode
+    BatchNorm, whose input-gradient has exactly zero mean per channel, so d loss / d bias == 0 analytically.
+    The reference (and the generic path here) would compute rounding noise of ~1e-7 for it; it is returned as
+    exact zeros instead, which saves one full read of gy per such conv."""
 
     @staticmethod
     def forward(ctx, x, w, bias, stride, out):
+        ctx.bias_grad_is_zero = isinstance(out, str) and out == "feeds_bn"
+        if ctx.bias_grad_is_zero:
+            out = None
         ctx.save_for_backward(x, w)
         ctx.stride, ctx.has_bias = stride, bias is not None
         return conv2d_forward_raw(x, w, bias, stride, out=out)
@@ -218,7 +226,7 @@ class Conv2dFn(Function):
         if ctx.needs_input_grad[1]:
             gw = Conv2dWeightGradFn.apply(x, gy, w.shape, ctx.stride)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = channel_sum(gy)
+            gb = torch.zeros(w.shape[0], dtype=torch.float32, device=w.device) if ctx.bias_grad_is_zero else channel_sum(gy)
         return gx, gw, gb, None, None
 
 

@@ -47,9 +47,9 @@ class ResidualBlock(nn.Module):
         c1, c2, c3 = self.convolution_layer_1, self.convolution_layer_2, self.convolution_layer_3
         b1, b2 = self.batch_norm_layer_1, self.batch_norm_layer_2
         if self.training:
-            y = ops.Conv2dFn.apply(x, c1.weight, c1.bias, self.strides, None)
+            y = ops.Conv2dFn.apply(x, c1.weight, c1.bias, self.strides, "feeds_bn")
             y = ops.BatchNormTrainFn.apply(y, b1.weight, b1.bias, b1.running_mean, b1.running_var, None, ACT_RELU, 0.0, None)
-            y = ops.Conv2dFn.apply(y, c2.weight, c2.bias, 1, None)
+            y = ops.Conv2dFn.apply(y, c2.weight, c2.bias, 1, "feeds_bn")
             skip = ops.Conv2dFn.apply(x, c3.weight, c3.bias, self.strides, None) if c3 is not None else x
             b1.num_batches_tracked += 1
             b2.num_batches_tracked += 1

@@ -40,7 +40,7 @@ class WGANGPDiscriminator192(nn.Module):
             h = ops.ConvBiasActFn.apply(h, c1.weight, c1.bias, 1, ACT_LEAKY, 0.2)
             for blk in (self.block2, self.block3, self.block4, self.block5, self.block6):
                 conv, bn = blk[0], blk[1]
-                y = ops.Conv2dFn.apply(h, conv.weight, conv.bias, conv.stride[0], None)
+                y = ops.Conv2dFn.apply(h, conv.weight, conv.bias, conv.stride[0], "feeds_bn")
                 h = ops.BatchNormTrainFn.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, None, ACT_LEAKY, 0.2, None)
                 bn.num_batches_tracked += 1
             s = ops.Conv2dFn.apply(h, self.conv.weight, self.conv.bias, 1, None)

@@ -196,24 +196,32 @@ def test_unet_and_generator_against_golden(golden):
         assert rel_err(named[k].grad.cpu(), ref["full"]) < 2e-2, k
 
 
+def l2_err(a, b):
+    return ((a - b).norm() / b.norm().clamp_min(1e-30)).item()
+
+
 @pytest.mark.parametrize("rows,batch", [(32, 2), (64, 4)])
 def test_unet_train_gradients_vs_fp64_truth(rows, batch):
     """Train-mode UNet forward + backward: the fp32 GPU result must be as close to an fp64 evaluation of the same
-    maths as the fp32 CPU (reference-arithmetic) result is."""
+    maths as the fp32 CPU (reference-arithmetic) result is.
+
+    Max-pool argmax is discontinuous: among ~5e5 2x2 windows some top-2 values differ by < 1e-6 relative, so two fp32
+    implementations route a few window gradients to different pixels (measured: 1 flip at 64x64, tools/dbg_levels.py).
+    Gradients are therefore compared in relative L2, plus an aggregate criterion over ALL parameters."""
+    import statistics
+
     from learned_hologram_gan_amd.neural_network_components import UNet
 
     sd32 = {k[len("part1.part1."):]: v for k, v in seeded.generator_state_dict().items() if k.startswith("part1.part1.")}
     rgbd, _, _ = seeded.smooth_batch(batch, rows, rows, seed=21)
     proj = torch.randn((batch, 6, rows, rows), generator=torch.Generator().manual_seed(8))
-    keys = ("encoder1.0.0.convolution_layer_1.weight", "bottleneck.1.0.convolution_layer_2.weight", "decoder2.1.weight",
-            "decoder4.0.batch_norm_layer_2.weight", "final_layer.0.weight", "encoder3.1.0.convolution_layer_3.weight")
 
     def run_oracle(dtype):
         sd = nets.as_parameters({k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd32.items()})
         x = rgbd.detach().clone().to(dtype).requires_grad_(True)
         y = nets.unet(sd, "", x, True)
         (y * proj.to(dtype)).sum().backward()
-        return y.detach().double(), x.grad.double(), {k: sd[k].grad.double() for k in keys}
+        return y.detach().double(), x.grad.double(), {k: v.grad.double() for k, v in sd.items() if v.requires_grad}
 
     y64, dx64, gw64 = run_oracle(torch.float64)
     y32, dx32, gw32 = run_oracle(torch.float32)
@@ -223,12 +231,16 @@ def test_unet_train_gradients_vs_fp64_truth(rows, batch):
     x = rgbd.detach().clone().to(DEV).requires_grad_(True)
     y = net(x)
     (y * proj.to(DEV)).sum().backward()
-    named = dict(net.named_parameters())
     assert rel_err(y.detach().cpu().double(), y64) <= max(4 * rel_err(y32, y64), 2e-6)
-    # d/dx through 18 train-mode BNs is ill-conditioned (the CPU fp32 result itself is ~2 % off fp64 at 64x64): bound at 8x
-    assert rel_err(x.grad.cpu().double(), dx64) <= max(8 * rel_err(dx32, dx64), 1e-5)
-    for k in keys:
-        assert rel_err(named[k].grad.cpu().double(), gw64[k]) <= max(6 * rel_err(gw32[k], gw64[k]), 1e-5), k
+    assert l2_err(x.grad.cpu().double(), dx64) <= max(4 * l2_err(dx32, dx64), 2e-2)
+    ratios = []
+    for k, p in net.named_parameters():
+        if k.endswith(("convolution_layer_1.bias", "convolution_layer_2.bias")):
+            continue  # analytically zero (feeds a train-mode BN)
+        e_gpu, e_cpu = l2_err(p.grad.cpu().double(), gw64[k]), l2_err(gw32[k], gw64[k])
+        assert e_gpu <= max(6 * e_cpu, 2e-2), (k, e_gpu, e_cpu)
+        ratios.append(e_gpu / max(e_cpu, 1e-12))
+    assert statistics.median(ratios) <= 2.0
 
 
 @pytest.mark.parametrize("rows,cols,pad,batch", [(64, 64, 32, 2), (96, 96, 16, 1)])

@@ -1,0 +1,29 @@
+import os, sys
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch
+from oracle import nets, seeded
+from learned_hologram_gan_amd.neural_network_components import UNet
+def rel_err(a,b): return ((a-b).abs().max()/b.abs().max()).item()
+rows,batch=64,4
+sd32 = {k[len("part1.part1."):]: v for k, v in seeded.generator_state_dict().items() if k.startswith("part1.part1.")}
+rgbd, _, _ = seeded.smooth_batch(batch, rows, rows, seed=21)
+proj = torch.randn((batch, 6, rows, rows), generator=torch.Generator().manual_seed(8))
+def run_oracle(dtype):
+    sd = nets.as_parameters({k: (v.to(dtype) if v.is_floating_point() else v) for k, v in sd32.items()})
+    x = rgbd.detach().clone().to(dtype).requires_grad_(True)
+    y = nets.unet(sd, "", x, True)
+    (y * proj.to(dtype)).sum().backward()
+    return y.detach().double(), x.grad.double(), {k: v.grad.double() for k, v in sd.items() if v.requires_grad}
+y64, dx64, g64 = run_oracle(torch.float64); y32, dx32, g32 = run_oracle(torch.float32)
+net = UNet(6, 4); net.load_state_dict(sd32); net.to("cuda").train()
+x = rgbd.detach().clone().to("cuda").requires_grad_(True); y = net(x); (y * proj.to("cuda")).sum().backward()
+print("y   cpu %.2e gpu %.2e" % (rel_err(y32,y64), rel_err(y.detach().cpu().double(), y64)))
+print("dx  cpu %.2e gpu %.2e" % (rel_err(dx32,dx64), rel_err(x.grad.cpu().double(), dx64)))
+rows_=[]
+for k,p in net.named_parameters():
+    if k.endswith("convolution_layer_1.bias") or k.endswith("convolution_layer_2.bias"): continue
+    ec, eg = rel_err(g32[k], g64[k]), rel_err(p.grad.cpu().double(), g64[k])
+    rows_.append((eg/max(ec,1e-12), k, ec, eg))
+rows_.sort(reverse=True)
+for r,k,ec,eg in rows_[:12]: print("%-55s cpu %.2e gpu %.2e ratio %.1f" % (k,ec,eg,r))
+import statistics; print("median ratio", statistics.median(r for r,_,_,_ in rows_))
