@@ -195,13 +195,35 @@ int lhg_asm_from_spectrum(const float* spectrum, int planes, int rows0, int cols
 /* twiddle[k] = exp(-2 pi i k / n), k < n, computed in double on the device. */
 int lhg_fft_twiddles(float* twiddle, int n, lhg_stream_t s);
 
-/* ------------------------------------------------------------------ AP2POH tail (A6 A7)
+/* ------------------------------------------------------------------ AP2POH tail (A6 A7), forward and backward
  * field (planes,rows,cols) complex64 -> POH.  ref: AP2POH.py:105-116, utilities.py:53-66,
- * neural_network_components.py:68-75.  taps[plane%3][3] = (centre, edge, corner), bias[plane%3]. */
+ * neural_network_components.py:68-75.  taps[plane%3][3] = (centre, edge, corner), bias[plane%3].
+ *   mod = stencil(field) + bias;  a = |mod| / (1.01 max_plane |mod|);  POH = angle(mod) +/- acos(a) on a checkerboard.
+ * plane_peak[planes] (uint64, ZERO it first) receives (float bits of the peak) << 32 | (0xFFFFFFFF - argmax index). */
 int lhg_symconv_field(const float* field, int planes, int rows, int cols, const float* taps, const float* bias,
-                      float* mod, float* plane_max /* [planes], atomically maxed; zero it first */, lhg_stream_t s);
-int lhg_double_phase_encode(const float* mod, const float* plane_max, int planes, int rows, int cols,
+                      float* mod, unsigned long long* plane_peak, lhg_stream_t s);
+int lhg_double_phase_encode(const float* mod, const unsigned long long* plane_peak, int planes, int rows, int cols,
                             float* poh, lhg_stream_t s);
+/* g_mod (complex) from g_poh, including the gradient through the per-plane max (routed to the arg-max pixel).
+ * ws: planes * lhg_poh_partial_blocks(rows, cols) floats. */
+int lhg_poh_partial_blocks(int rows, int cols);
+int lhg_double_phase_encode_backward(const float* g_poh, const float* mod, const unsigned long long* plane_peak,
+                                     int planes, int rows, int cols, float* g_mod, float* ws, lhg_stream_t s);
+/* g_field = stencil(g_mod); partial[planes][blocks][4] = per-block sums for d(centre, edge, corner, bias) of the
+ * plane's colour (sum them over planes of one colour and blocks). */
+int lhg_symconv_field_backward(const float* g_mod, const float* field, int planes, int rows, int cols, const float* taps,
+                               float* g_field, float* partial, lhg_stream_t s);
+
+/* ------------------------------------------------------------------ reconstruction losses (A13), fused
+ * (focal sin/cos phase-gradient, pixel MSE, |TV(hat) - TV(target)|) of (planes,H,W) fp32 amplitudes / phases.
+ * ref: loss_func.py:66-98, 135-163; watermelon.py:418-445.  sums9: the nine global reductions (kept for backward),
+ * losses3 = (focal, pixel, tv).  ws: lhg_recon_loss_blocks(...) * 9 floats.  Backward takes d(loss)/d(losses3). */
+int lhg_recon_loss_blocks(int planes, int H, int W);
+int lhg_recon_loss_forward(const float* hat_amp, const float* tgt_amp, const float* hat_phs, const float* tgt_phs,
+                           int planes, int H, int W, float* sums9, float* losses3, float* ws, lhg_stream_t s);
+int lhg_recon_loss_backward(const float* hat_amp, const float* tgt_amp, const float* hat_phs, const float* tgt_phs,
+                            int planes, int H, int W, const float* sums9, const float* upstream3,
+                            float* g_hat_amp, float* g_hat_phs, lhg_stream_t s);
 
 /* ------------------------------------------------------------------ optimiser
  * torch.optim.Adam (no weight decay, no amsgrad) on one flat tensor.  ref: watermelon.py:137-138. */

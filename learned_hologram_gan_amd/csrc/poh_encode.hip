@@ -1,54 +1,73 @@
 // AP2POH tail: per-colour radially symmetric 3x3 stencil on Re and Im of the
 // back-propagated field, amplitude normalisation by 1.01 * per-plane max, double-phase encoding
-// on a unit checkerboard.  ref: AP2POH.py:105-116, utilities.py:53-66,
+// on a unit checkerboard — forward and backward.  ref: AP2POH.py:105-116, utilities.py:53-66,
 // neural_network_components.py:68-75.  Streaming kernels, 8-byte lanes on interleaved complex64.
+//
+//   mod = stencil_c(field) + bias_c (same real stencil on Re and Im)       c = plane % 3
+//   A = |mod|, M = max_plane A, a = A / (1.01 M), phi = angle(mod)
+//   POH = phi + s * acos(a),  s = +1 where (x+y) even, -1 where odd
+#include <algorithm>
+
 #include "common.h"
 
 namespace lhg {
 
-__device__ __forceinline__ void atomic_max_nonneg(float* addr, float v) {
-  // non-negative floats order like their bit patterns
-  atomicMax(reinterpret_cast<unsigned int*>(addr), __float_as_uint(v));
+// per-plane peak packed as (float bits of A) << 32 | (0xFFFFFFFF - pixel index): a 64-bit atomicMax keeps the
+// largest amplitude and, among equal amplitudes, the smallest index (what two successive torch.max calls select).
+__device__ __forceinline__ unsigned long long pack_peak(float a, unsigned idx) {
+  return ((unsigned long long)__float_as_uint(a) << 32) | (unsigned long long)(0xFFFFFFFFu - idx);
+}
+__device__ __forceinline__ float peak_value(unsigned long long p) { return __uint_as_float((unsigned)(p >> 32)); }
+__device__ __forceinline__ unsigned peak_index(unsigned long long p) { return 0xFFFFFFFFu - (unsigned)(p & 0xFFFFFFFFull); }
+
+__device__ __forceinline__ float stencil_weight(int dy, int dx, float w0, float w1, float w2) {
+  return (dy == 0 && dx == 0) ? w0 : ((dy == 0 || dx == 0) ? w1 : w2);
+}
+
+__device__ __forceinline__ float2 stencil_at(const float2* __restrict__ f, int y, int x, int rows, int cols, float w0, float w1, float w2) {
+  float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy) {
+    const int yy = y + dy;
+    if ((unsigned)yy >= (unsigned)rows) continue;
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      const int xx = x + dx;
+      if ((unsigned)xx >= (unsigned)cols) continue;
+      const float w = stencil_weight(dy, dx, w0, w1, w2);
+      const float2 v = f[(size_t)yy * cols + xx];
+      acc.x += w * v.x;
+      acc.y += w * v.y;
+    }
+  }
+  return acc;
 }
 
 __global__ __launch_bounds__(256) void symconv_field_kernel(const float2* __restrict__ field, int planes, int rows, int cols,
                                                             const float* __restrict__ taps, const float* __restrict__ bias,
-                                                            float2* __restrict__ mod, float* __restrict__ plane_max) {
+                                                            float2* __restrict__ mod, unsigned long long* __restrict__ peak) {
   const int plane = blockIdx.y;
   const int colour = plane % 3;
   const float w0 = taps[colour * 3 + 0], w1 = taps[colour * 3 + 1], w2 = taps[colour * 3 + 2], b = bias[colour];
   const float2* f = field + (size_t)plane * rows * cols;
-  float local_max = 0.f;
+  unsigned long long best = 0;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rows * cols; i += gridDim.x * blockDim.x) {
     const int y = i / cols, x = i - y * cols;
-    float2 acc = make_float2(b, b);
-#pragma unroll
-    for (int dy = -1; dy <= 1; ++dy) {
-      const int yy = y + dy;
-      if ((unsigned)yy >= (unsigned)rows) continue;
-#pragma unroll
-      for (int dx = -1; dx <= 1; ++dx) {
-        const int xx = x + dx;
-        if ((unsigned)xx >= (unsigned)cols) continue;
-        const float w = (dy == 0 && dx == 0) ? w0 : ((dy == 0 || dx == 0) ? w1 : w2);
-        const float2 v = f[(size_t)yy * cols + xx];
-        acc.x += w * v.x;
-        acc.y += w * v.y;
-      }
-    }
+    float2 acc = stencil_at(f, y, x, rows, cols, w0, w1, w2);
+    acc.x += b;
+    acc.y += b;
     mod[(size_t)plane * rows * cols + i] = acc;
-    local_max = fmaxf(local_max, hypotf(acc.x, acc.y));
+    best = max(best, pack_peak(hypotf(acc.x, acc.y), (unsigned)i));
   }
-  // wave reduction then one atomic per wave
 #pragma unroll
-  for (int off = 32; off > 0; off >>= 1) local_max = fmaxf(local_max, __shfl_down(local_max, off, 64));
-  if ((threadIdx.x & 63) == 0) atomic_max_nonneg(plane_max + plane, local_max);
+  for (int off = 32; off > 0; off >>= 1) best = max(best, (unsigned long long)__shfl_down((long long)best, off, 64));
+  if ((threadIdx.x & 63) == 0) atomicMax(peak + plane, best);
 }
 
-__global__ __launch_bounds__(256) void double_phase_kernel(const float2* __restrict__ mod, const float* __restrict__ plane_max, int planes,
-                                                           int rows, int cols, float* __restrict__ poh) {
+__global__ __launch_bounds__(256) void double_phase_kernel(const float2* __restrict__ mod, const unsigned long long* __restrict__ peak,
+                                                           int planes, int rows, int cols, float* __restrict__ poh) {
   const int plane = blockIdx.y;
-  const float denom = plane_max[plane] * 1.01f;
+  const float denom = peak_value(peak[plane]) * 1.01f;
   for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rows * cols; i += gridDim.x * blockDim.x) {
     const int y = i / cols, x = i - y * cols;
     const float2 z = mod[(size_t)plane * rows * cols + i];
@@ -59,27 +78,139 @@ __global__ __launch_bounds__(256) void double_phase_kernel(const float2* __restr
   }
 }
 
+// ---- backward, stage 1: d POH -> d mod without the max term; per-block partial of S = sum g_a * a
+__global__ __launch_bounds__(256) void poh_bwd_stage1(const float* __restrict__ g_poh, const float2* __restrict__ mod,
+                                                      const unsigned long long* __restrict__ peak, int planes, int rows, int cols,
+                                                      float2* __restrict__ g_mod, float* __restrict__ partial /* [planes][gridDim.x] */) {
+  __shared__ float red[4];
+  const int plane = blockIdx.y;
+  const float M = peak_value(peak[plane]);
+  const float denom = M * 1.01f;
+  float s_acc = 0.f;
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rows * cols; i += gridDim.x * blockDim.x) {
+    const int y = i / cols, x = i - y * cols;
+    const size_t o = (size_t)plane * rows * cols + i;
+    const float2 z = mod[o];
+    const float g = g_poh[o];
+    const float A2 = z.x * z.x + z.y * z.y;
+    float2 out = make_float2(0.f, 0.f);
+    if (A2 > 0.f) {
+      const float A = sqrtf(A2);
+      const float a = A / denom;
+      const float sgn = ((x + y) & 1) ? -1.f : 1.f;
+      const float g_a = -sgn * g / sqrtf(fmaxf(1.f - a * a, 1e-30f));  // d acos
+      const float g_A = g_a / denom;
+      s_acc += g_a * a;
+      // d|z| -> z/|z| ; d angle -> (-im, re)/|z|^2
+      out.x = g_A * z.x / A - g * z.y / A2;
+      out.y = g_A * z.y / A + g * z.x / A2;
+    }
+    g_mod[o] = out;
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) s_acc += __shfl_down(s_acc, off, 64);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s_acc;
+  __syncthreads();
+  if (threadIdx.x == 0) partial[(size_t)plane * gridDim.x + blockIdx.x] = (red[0] + red[1]) + (red[2] + red[3]);
+}
+
+// ---- stage 2: the max term.  a = A/(1.01 M) => dL/dM = -sum(g_a a)/M, routed to the arg-max pixel along z/|z|
+__global__ void poh_bwd_stage2(const float2* __restrict__ mod, const unsigned long long* __restrict__ peak, const float* __restrict__ partial,
+                               int nblk, int planes, int rows, int cols, float2* __restrict__ g_mod) {
+  const int plane = blockIdx.x * blockDim.x + threadIdx.x;
+  if (plane >= planes) return;
+  double S = 0;
+  for (int b = 0; b < nblk; ++b) S += partial[(size_t)plane * nblk + b];
+  const float M = peak_value(peak[plane]);
+  if (!(M > 0.f)) return;
+  const size_t o = (size_t)plane * rows * cols + peak_index(peak[plane]);
+  const float2 z = mod[o];
+  const float gM = (float)(-S / (double)M);
+  g_mod[o].x += gM * z.x / M;
+  g_mod[o].y += gM * z.y / M;
+}
+
+// ---- stage 3: stencil backward.  g_field = stencil_c(g_mod) (the kernel is symmetric); per-block partials of the
+//      four parameter gradients of this plane's colour: centre / edge / corner taps and the bias.
+__global__ __launch_bounds__(256) void symconv_bwd_kernel(const float2* __restrict__ g_mod, const float2* __restrict__ field, int planes,
+                                                          int rows, int cols, const float* __restrict__ taps,
+                                                          float2* __restrict__ g_field, float* __restrict__ partial /* [planes][gridDim.x][4] */) {
+  __shared__ float red[4][4];
+  const int plane = blockIdx.y;
+  const int colour = plane % 3;
+  const float w0 = taps[colour * 3 + 0], w1 = taps[colour * 3 + 1], w2 = taps[colour * 3 + 2];
+  const float2* gm = g_mod + (size_t)plane * rows * cols;
+  const float2* f = field + (size_t)plane * rows * cols;
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < rows * cols; i += gridDim.x * blockDim.x) {
+    const int y = i / cols, x = i - y * cols;
+    g_field[(size_t)plane * rows * cols + i] = stencil_at(gm, y, x, rows, cols, w0, w1, w2);
+    const float2 g = gm[i];
+    const float2 c = stencil_at(f, y, x, rows, cols, 1.f, 0.f, 0.f);
+    const float2 e = stencil_at(f, y, x, rows, cols, 0.f, 1.f, 0.f);
+    const float2 k = stencil_at(f, y, x, rows, cols, 0.f, 0.f, 1.f);
+    acc[0] += g.x * c.x + g.y * c.y;
+    acc[1] += g.x * e.x + g.y * e.y;
+    acc[2] += g.x * k.x + g.y * k.y;
+    acc[3] += g.x + g.y;
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) acc[q] += __shfl_down(acc[q], off, 64);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6][q] = acc[q];
+  }
+  __syncthreads();
+  if (threadIdx.x < 4) {
+    const int q = threadIdx.x;
+    partial[((size_t)plane * gridDim.x + blockIdx.x) * 4 + q] = (red[0][q] + red[1][q]) + (red[2][q] + red[3][q]);
+  }
+}
+
+static int plane_blocks(int rows, int cols) { return std::min(64, (rows * cols + 255) / 256); }
+
 }  // namespace lhg
 
 using namespace lhg;
 
 extern "C" {
 
+int lhg_poh_partial_blocks(int rows, int cols) { return plane_blocks(rows, cols); }
+
 int lhg_symconv_field(const float* field, int planes, int rows, int cols, const float* taps, const float* bias, float* mod,
-                      float* plane_max, lhg_stream_t s) {
+                      unsigned long long* plane_peak, lhg_stream_t s) {
   LHG_REQUIRE(planes > 0 && rows > 0 && cols > 0, "symconv_field: bad extents");
-  const int bx = std::min(64, (rows * cols + 255) / 256);
-  hipLaunchKernelGGL(symconv_field_kernel, dim3(bx, planes), dim3(256), 0, as_stream(s), reinterpret_cast<const float2*>(field), planes,
-                     rows, cols, taps, bias, reinterpret_cast<float2*>(mod), plane_max);
+  hipLaunchKernelGGL(symconv_field_kernel, dim3(plane_blocks(rows, cols), planes), dim3(256), 0, as_stream(s),
+                     reinterpret_cast<const float2*>(field), planes, rows, cols, taps, bias, reinterpret_cast<float2*>(mod), plane_peak);
   return check_launch("symconv_field");
 }
 
-int lhg_double_phase_encode(const float* mod, const float* plane_max, int planes, int rows, int cols, float* poh, lhg_stream_t s) {
+int lhg_double_phase_encode(const float* mod, const unsigned long long* plane_peak, int planes, int rows, int cols, float* poh,
+                            lhg_stream_t s) {
   LHG_REQUIRE(planes > 0 && rows > 0 && cols > 0, "double_phase_encode: bad extents");
-  const int bx = std::min(64, (rows * cols + 255) / 256);
-  hipLaunchKernelGGL(double_phase_kernel, dim3(bx, planes), dim3(256), 0, as_stream(s), reinterpret_cast<const float2*>(mod), plane_max,
-                     planes, rows, cols, poh);
+  hipLaunchKernelGGL(double_phase_kernel, dim3(plane_blocks(rows, cols), planes), dim3(256), 0, as_stream(s),
+                     reinterpret_cast<const float2*>(mod), plane_peak, planes, rows, cols, poh);
   return check_launch("double_phase_encode");
+}
+
+int lhg_double_phase_encode_backward(const float* g_poh, const float* mod, const unsigned long long* plane_peak, int planes, int rows,
+                                     int cols, float* g_mod, float* ws, lhg_stream_t s) {
+  LHG_REQUIRE(planes > 0 && rows > 0 && cols > 0, "double_phase_encode_backward: bad extents");
+  const int nblk = plane_blocks(rows, cols);
+  hipLaunchKernelGGL(poh_bwd_stage1, dim3(nblk, planes), dim3(256), 0, as_stream(s), g_poh, reinterpret_cast<const float2*>(mod),
+                     plane_peak, planes, rows, cols, reinterpret_cast<float2*>(g_mod), ws);
+  hipLaunchKernelGGL(poh_bwd_stage2, dim3((planes + 63) / 64), dim3(64), 0, as_stream(s), reinterpret_cast<const float2*>(mod), plane_peak,
+                     ws, nblk, planes, rows, cols, reinterpret_cast<float2*>(g_mod));
+  return check_launch("double_phase_encode_backward");
+}
+
+int lhg_symconv_field_backward(const float* g_mod, const float* field, int planes, int rows, int cols, const float* taps, float* g_field,
+                               float* partial, lhg_stream_t s) {
+  LHG_REQUIRE(planes > 0 && rows > 0 && cols > 0, "symconv_field_backward: bad extents");
+  hipLaunchKernelGGL(symconv_bwd_kernel, dim3(plane_blocks(rows, cols), planes), dim3(256), 0, as_stream(s),
+                     reinterpret_cast<const float2*>(g_mod), reinterpret_cast<const float2*>(field), planes, rows, cols, taps,
+                     reinterpret_cast<float2*>(g_field), partial);
+  return check_launch("symconv_field_backward");
 }
 
 }  // extern "C"

@@ -62,6 +62,12 @@ _SIGNATURES = {
     "lhg_fft_twiddles": [_p, _i, _p],
     "lhg_symconv_field": [_p, _i, _i, _i, _p, _p, _p, _p, _p],
     "lhg_double_phase_encode": [_p, _p, _i, _i, _i, _p, _p],
+    "lhg_poh_partial_blocks": [_i, _i],
+    "lhg_double_phase_encode_backward": [_p, _p, _p, _i, _i, _i, _p, _p, _p],
+    "lhg_symconv_field_backward": [_p, _p, _i, _i, _i, _p, _p, _p, _p],
+    "lhg_recon_loss_blocks": [_i, _i, _i],
+    "lhg_recon_loss_forward": [_p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p],
+    "lhg_recon_loss_backward": [_p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p],
     "lhg_adam_step": [_p, _p, _p, _p, _ll, _f, _f, _f, _f, _i, _p],
 }
 _RESTYPE = {"lhg_last_error": C.c_char_p}

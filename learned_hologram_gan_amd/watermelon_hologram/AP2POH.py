@@ -7,7 +7,7 @@ from __future__ import annotations
 import torch
 from torch import nn
 
-from .. import native
+from ..poh_ops import PohEncodeFn
 from ..angular_spectrum_method import bandLimitedAngularSpectrumMethod_for_single_fixed_distance as fixed_distance_propogator
 from ..neural_network_components import ChannelWiseSymmetricConv
 from ..utilities import amplitude_normalizor, generate_checkerboard_mask, try_gpu
@@ -44,23 +44,14 @@ class AP2POH(nn.Module):
         return torch.cat((torch.sin(phs), torch.cos(phs)), dim=-3)
 
     def _encode_fused(self, field):
-        """Inference tail in two HIP kernels (symmetric stencil + per-plane max, then the
-        normalise / angle / acos / checkerboard encode)."""
-        B, Cc, H, W = field.shape
-        taps, bias = self.part1.taps_and_bias()
-        mod = torch.empty_like(field)
-        peak = torch.zeros((B * Cc,), dtype=torch.float32, device=field.device)
-        poh = torch.empty((B, Cc, H, W), dtype=torch.float32, device=field.device)
-        f = torch.view_as_real(field.contiguous())
-        native.call("lhg_symconv_field", native.ptr(f), B * Cc, H, W, native.ptr(taps), native.ptr(bias),
-                    native.ptr(torch.view_as_real(mod)), native.ptr(peak), native.stream_ptr())
-        native.call("lhg_double_phase_encode", native.ptr(torch.view_as_real(mod)), native.ptr(peak), B * Cc, H, W,
-                    native.ptr(poh), native.stream_ptr())
-        return poh
+        """Stencil + per-plane max, then normalise / angle / acos / checkerboard encode: two HIP kernels forward,
+        three backward (poh_ops.PohEncodeFn)."""
+        taps, bias = self.part1.taps_and_bias()  # torch.stack / cat of the six parameters: differentiable
+        return PohEncodeFn.apply(field, taps, bias)
 
     def forward(self, amp_z, phs_z):
         field = self.propagator.propagate_AP2C_backward(amp_z, phs_z)
-        if not torch.is_grad_enabled() and isinstance(self.part1, ChannelWiseSymmetricConv) and field.shape[1] == 3:
+        if isinstance(self.part1, ChannelWiseSymmetricConv) and field.shape[1] == 3 and field.is_cuda:
             return self._encode_fused(field)
         mod = torch.complex(self.part1(torch.real(field)), self.part1(torch.imag(field)))
         return self.double_phase_method(amplitude_normalizor(torch.abs(mod)), torch.angle(mod))

@@ -22,6 +22,7 @@ import torch.nn.functional as F
 from ..angular_spectrum_method import bandLimitedAngularSpectrumMethod_for_multiple_distances
 from ..distributed import GradSynchronizer
 from ..optim import FlatParams, FusedAdam
+from ..poh_ops import ReconLossFn
 from ..utilities import try_gpu
 from .discriminator import WGANGPDiscriminator192, fakeDiscriminator
 from .generator import Generator
@@ -121,10 +122,15 @@ class watermelon:
 
     def G_loss(self, hat_amps, target_amps, hat_phs, target_phs, loss_from_discriminator, recorder=None):
         """ref: watermelon.py:418-445."""
-        phs_loss = focal_sincos_phase_gradient_loss(hat_phs, target_phs) * self.phs_gradient_loss_weight
+        if hat_amps.is_cuda:  # fused HIP kernels (csrc/losses.hip)
+            focal, mse, tv_diff = ReconLossFn.apply(hat_amps, target_amps, hat_phs, target_phs).unbind(0)
+        else:  # host-side evaluation of the same definitions (loss_func.py)
+            focal = focal_sincos_phase_gradient_loss(hat_phs, target_phs)
+            mse, tv_diff = F.mse_loss(hat_amps, target_amps), total_variation_loss(hat_amps, target_amps)
+        phs_loss = focal * self.phs_gradient_loss_weight
         perceptual = self.perceptual_loss(hat_amps, target_amps) * self.perceptual_loss_weight
-        pixel = F.mse_loss(hat_amps, target_amps) * self.pixel_loss_weight
-        tv = total_variation_loss(hat_amps, target_amps) * self.TV_loss_weight
+        pixel = mse * self.pixel_loss_weight
+        tv = tv_diff * self.TV_loss_weight
         gan = loss_from_discriminator * self.discriminator_loss_weight
         loss = phs_loss + perceptual + pixel + tv + gan
         if recorder is not None:

@@ -239,3 +239,50 @@ def test_adam_matches_torch(ops):
         opt.step()
         ops.adam_step_(pg, grad.to(DEV), m, v, 1e-3, 0.9, 0.999, 1e-8, step)
         assert rel_err(pg.cpu(), pr.detach()) < 1e-6
+
+
+def test_poh_encode_forward_backward_matches_composite():
+    """AP2POH tail (stencil, per-plane max normalisation, angle, acos, checkerboard) vs the tensor-op composite."""
+    from learned_hologram_gan_amd.poh_ops import PohEncodeFn
+    from oracle import nets
+
+    g = torch.Generator().manual_seed(3)
+    B, H, W = 2, 20, 28
+    field = torch.complex(torch.randn((B, 3, H, W), generator=g), torch.randn((B, 3, H, W), generator=g))
+    taps = torch.rand((3, 3), generator=g) + 0.2
+    bias = torch.randn((3,), generator=g) * 0.1
+    proj = torch.randn((B, 3, H, W), generator=g)
+
+    fr, tr, br = field.clone().requires_grad_(True), taps.clone().requires_grad_(True), bias.clone().requires_grad_(True)
+    sd = {f"p.conv_{c}.params": tr[i] for i, c in enumerate("rgb")}
+    sd.update({f"p.conv_{c}.bias": br[i:i + 1] for i, c in enumerate("rgb")})
+    mod = torch.complex(nets.channelwise_symmetric_conv(sd, "p.", fr.real), nets.channelwise_symmetric_conv(sd, "p.", fr.imag))
+    poh_r = nets.double_phase_encode(nets.normalize_amplitude(mod.abs()), mod.angle())
+    (torch.cos(poh_r) * proj).sum().backward()
+
+    fg, tg, bg = field.to(DEV).requires_grad_(True), taps.to(DEV).requires_grad_(True), bias.to(DEV).requires_grad_(True)
+    poh_g = PohEncodeFn.apply(fg, tg, bg)
+    assert (torch.exp(1j * poh_g.detach().cpu()) - torch.exp(1j * poh_r.detach())).abs().max() < 1e-4
+    (torch.cos(poh_g) * proj.to(DEV)).sum().backward()
+    assert rel_err(torch.view_as_real(fg.grad.cpu()), torch.view_as_real(fr.grad)) < 2e-4
+    assert rel_err(tg.grad.cpu(), tr.grad) < 2e-4 and rel_err(bg.grad.cpu(), br.grad) < 2e-4
+
+
+def test_recon_losses_match_reference_definitions():
+    from learned_hologram_gan_amd.poh_ops import ReconLossFn
+    from oracle import losses as L
+
+    g = torch.Generator().manual_seed(5)
+    B, H, W = 2, 24, 20
+    ha, ta = torch.rand((B, 3, H, W), generator=g), torch.rand((B, 3, H, W), generator=g)
+    hp, tp = torch.rand((B, 3, H, W), generator=g) * 6.28 - 3.14, torch.rand((B, 3, H, W), generator=g) * 6.28 - 3.14
+    wts = torch.tensor([1.0, 5.0, 3.0])
+    har, hpr = ha.clone().requires_grad_(True), hp.clone().requires_grad_(True)
+    ref = torch.stack((L.focal_sincos_phase_gradient_loss(hpr, tp), L.pixel_loss(har, ta), L.total_variation_loss(har, ta)))
+    (ref * wts).sum().backward()
+    hag, hpg = ha.to(DEV).requires_grad_(True), hp.to(DEV).requires_grad_(True)
+    out = ReconLossFn.apply(hag, ta.to(DEV), hpg, tp.to(DEV))
+    assert rel_err(out.detach().cpu(), ref.detach()) < 1e-5
+    (out * wts.to(DEV)).sum().backward()
+    assert rel_err(hag.grad.cpu(), har.grad) < 1e-4
+    assert rel_err(hpg.grad.cpu(), hpr.grad) < 1e-4
