@@ -117,6 +117,12 @@ def main():
 
     if rank == 0:
         gg, wg = prof.result
+        traffic = None  # HBM bytes per gather-GEMM launch from the committed PMC passes (profiles/r01_pmc_traffic.json)
+        try:
+            with open(os.path.join(REPO, "profiles", "r01_pmc_traffic.json")) as f:
+                traffic = json.load(f)["kernels"]["gg"]["hbm_bytes_per_launch_corrected"]
+        except (OSError, KeyError, ValueError):
+            pass
         achieved = gg["algorithmic_flops"] / (gg["total_ms"] * 1e-3) / 1e12 if gg["total_ms"] > 0 else 0.0
         out = {
             "metric": "RGBD->POH frames/sec at 384x384 bs=4 (GAN train step)",
@@ -137,7 +143,8 @@ def main():
             "roofline": {
                 "kernel": "lhg::gg_kernel (MFMA fp32 gather-GEMM: conv forward / input-gradient / conv-transpose)",
                 "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "algorithmic_flop_per_launch": round(gg["algorithmic_flops"] / max(gg["launches"], 1)),
                 "launches_per_step": gg["launches"] / args.steps,
                 "avg_launch_us": round(gg["total_ms"] * 1e3 / max(gg["launches"], 1), 2),
                 "algorithmic_gflop_per_step": round(gg["algorithmic_flops"] / args.steps / 1e9, 2),
