@@ -360,6 +360,66 @@ def test_train_step_vs_oracle_fresh_inputs():
     assert abs(out["D_loss"].item() - ref["D_loss"]) <= 1e-3 * abs(ref["D_loss"])
 
 
+def test_config1_192_inference_and_one_plane_propagation():
+    """BASELINE configs[0]: 192x192 single-sample generatePOH forward + 1-plane propagate (pad 160 -> 512^2 FFTs)."""
+    from learned_hologram_gan_amd.angular_spectrum_method import bandLimitedAngularSpectrumMethod_for_multiple_distances as Mu
+
+    G = _generator(192, 192, 160).eval()
+    rgbd, _, _ = seeded.smooth_batch(1, 192, 192, seed=31)
+    d = torch.tensor([4e-4])
+    prop = Mu(192, 192, d, 160, 0.35, PITCH, WL, False, True)
+    with torch.no_grad():
+        poh = G(rgbd.to(DEV))
+        amp = prop(torch.ones_like(poh), poh, d)
+    o = optics.make_optics(192, 192, 160, 0.45, PITCH, WL)
+    o35 = optics.make_optics(192, 192, 160, 0.35, PITCH, WL)
+    Hf = optics.transfer_function(o.w, torch.tensor([1e-3]))[0]
+    with torch.no_grad():
+        poh_ref = nets.generator(nets.as_parameters(seeded.generator_state_dict()), o, Hf, rgbd, False)
+        amp_ref = optics.propagate_amplitudes(o35, torch.ones_like(poh_ref), poh_ref, d)
+    assert phase_err(poh.cpu(), poh_ref) < 1e-3
+    assert rel_err(amp.cpu(), amp_ref) < 1e-3
+    assert rel_err(prop(torch.ones_like(poh), poh_ref.to(DEV), d).cpu(), amp_ref) < PARITY  # propagation alone: 1e-4
+
+
+def test_config4_4k_frame_unet_locality():
+    """BASELINE configs[3] geometry (3840x2160, batch 1): the eval-mode UNet is a local operator (BN is a per-channel
+    affine map), so the centre of the 4K output must equal the oracle evaluated on a crop with >= 192 px of margin.
+    Also exercises the > 4 GiB tensors (the pipelined kernels' 32-bit descriptors fall back to the 64-bit kernel)."""
+    from learned_hologram_gan_amd.neural_network_components import UNet
+
+    H, W = 2160, 3840
+    sd = {k[len("part1.part1."):]: v for k, v in seeded.generator_state_dict().items() if k.startswith("part1.part1.")}
+    net = UNet(6, 4)
+    net.load_state_dict(sd)
+    net.to(DEV).eval()
+    g = torch.Generator().manual_seed(41)
+    small = torch.rand((1, 4, H // 8, W // 8), generator=g)
+    rgbd = torch.nn.functional.interpolate(small, size=(H, W), mode="bilinear", align_corners=False)
+    with torch.no_grad():
+        y = net(rgbd.to(DEV))
+    assert y.shape == (1, 6, H, W) and torch.isfinite(y).all()
+    cy, cx, half, margin = 1088, 1920, 64, 192  # multiples of 16 keep the pooling grid aligned
+    crop = rgbd[:, :, cy - half - margin: cy + half + margin, cx - half - margin: cx + half + margin]
+    with torch.no_grad():
+        ref = nets.unet(nets.as_parameters(sd), "", crop, False)
+    got = y[:, :, cy - half: cy + half, cx - half: cx + half].cpu()
+    assert rel_err(got, ref[:, :, margin: margin + 2 * half, margin: margin + 2 * half]) < PARITY
+
+
+def test_non_power_of_two_extent_uses_rocfft_route():
+    """192 + 2*320 = 832 = 2^6 * 13 (the reference CLI default for 192^2 frames): served by torch.fft on the GPU."""
+    fx = _fixed(192, 192, 320, 0.45)
+    assert not fx._geom.supported()
+    g = torch.Generator().manual_seed(4)
+    amp, phs = torch.rand((1, 3, 192, 192), generator=g), torch.rand((1, 3, 192, 192), generator=g) * 6
+    o = optics.make_optics(192, 192, 320, 0.45, PITCH, WL)
+    Hf = optics.transfer_function(o.w, torch.tensor([1e-3]))[0]
+    assert cplx_err(fx.propagate_AP2C_backward(amp.to(DEV), phs.to(DEV)), optics.backpropagate_to_slm(o, Hf, amp, phs)) < PARITY
+    a, _ = fx.propagate_POH2AP_forward(phs.to(DEV))
+    assert rel_err(a.cpu(), optics.poh_to_amp_phase(o, Hf, phs)[0]) < PARITY
+
+
 def test_product_has_no_cpu_fallback():
     from learned_hologram_gan_amd import hip_ops, native
 
