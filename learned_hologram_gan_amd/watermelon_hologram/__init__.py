@@ -1,1 +1,1 @@
-from . import AP2POH, RGBD2AP, data_loader, discriminator, generator, loss_func, watermelon  # noqa: F401
+from . import AP2POH, RGBD2AP, data_loader, discriminator, generator, loss_func, perceptual, watermelon  # noqa: F401

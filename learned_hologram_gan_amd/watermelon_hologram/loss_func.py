@@ -72,6 +72,13 @@ def plain_phase_loss(fake_phase, real_phase):
     return torch.mean(torch.abs(fake_phase - real_phase))
 
 
+def perceptualLoss(feature_map_layers=(3, 8, 13, 22, 31), cuda=True, weights_path=None):
+    """VGG19 perceptual loss (ref: loss_func.py:12-51) — implemented in perceptual.py on the HIP ops."""
+    from .perceptual import perceptualLoss as _impl
+
+    return _impl(feature_map_layers, cuda, weights_path)
+
+
 class fakePerceptualLoss(torch.nn.Module):
     """Zero perceptual term (the VGG19 loss of loss_func.py:12-51 is SURVEY §8f N1)."""
 

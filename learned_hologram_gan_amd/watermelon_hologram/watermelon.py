@@ -7,8 +7,8 @@ the parity tests drive exactly what ``train`` runs.  Differences that are delibe
   * both Adam updates are single fused launches over flat parameter buffers;
   * with torch.distributed initialised, gradients are averaged across ranks (RCCL) with
     bucketed all-reduces overlapped with backward; BN / loss normalisers stay per replica.
-The VGG19 perceptual term (loss_func.py:12-51) is SURVEY §8f N1: ``perceptual_loss_weight`` must be 0
-unless a perceptual module is supplied.
+The VGG19 perceptual term (loss_func.py:12-51) is ``perceptual.perceptualLoss``; it needs a local weights
+file, so the trainer takes it as a constructor argument and ``perceptual_loss_weight`` must be 0 without one.
 """
 
 from __future__ import annotations
@@ -88,8 +88,8 @@ class watermelon:
                   discriminator_loss_weight=1.0, lr_G=1e-3, lr_D=1e-3, discriminator_train_ratio=2, discriminator_lambda=10,
                   grad_buckets=4):
         if perceptual_loss_weight and not self._has_perceptual:
-            raise NotImplementedError("the VGG19 perceptual loss is not built yet (SURVEY §8f N1): pass perceptual_loss_weight=0 "
-                                      "or supply a perceptual module")
+            raise ValueError("perceptual_loss_weight != 0 needs a perceptual module: construct the trainer with "
+                             "perceptual_loss=perceptualLoss(weights_path=...) (watermelon_hologram/perceptual.py)")
         self.phs_gradient_loss_weight, self.perceptual_loss_weight = phs_gradient_loss_weight, perceptual_loss_weight
         self.pixel_loss_weight, self.TV_loss_weight = pixel_loss_weight, TV_loss_weight
         self.discriminator_loss_weight = discriminator_loss_weight

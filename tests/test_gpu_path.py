@@ -459,6 +459,67 @@ def test_full_size_train_step_vs_oracle():
     assert 10 * torch.log10(ref["hat_amps"].max() ** 2 / mse) > 70.0
 
 
+def test_perceptual_loss_vs_oracle(tmp_path):
+    """VGG19 features[:32] perceptual loss on the HIP conv/pool ops vs the CPU restatement, same seeded
+    weights (loaded through the weights-file path, torchvision key names)."""
+    from learned_hologram_gan_amd.watermelon_hologram.perceptual import perceptualLoss
+    from oracle import perceptual as P
+
+    sd = P.vgg19_feature_state_dict()
+    path = tmp_path / "vgg19_features.pth"
+    torch.save({"features." + k: v for k, v in sd.items()}, path)
+    mod = perceptualLoss(weights_path=str(path))
+    assert mod.pretrained and all(not p.requires_grad for p in mod.parameters())
+    g = torch.Generator().manual_seed(2)
+    hat, tgt = torch.rand((2, 3, 64, 64), generator=g), torch.rand((2, 3, 64, 64), generator=g)
+    hr = hat.clone().requires_grad_(True)
+    ref = P.perceptual_loss(sd, hr, tgt)
+    ref.backward()
+    hg = hat.to(DEV).requires_grad_(True)
+    out = mod(hg, tgt.to(DEV))
+    out.backward()
+    assert abs(out.item() - ref.item()) <= 1e-4 * abs(ref.item())
+    assert ((hg.grad.cpu() - hr.grad).norm() / hr.grad.norm()).item() < 1e-3
+
+
+def test_train_loop_validation_checkpoints_and_metrics_json(tmp_path):
+    """The reference's loop contract (watermelon.py:92-416, 479-631): per-interval validation over ALL planes, the losses /
+    metrics JSON schema, `<path>_epoch{n}.pth` + final checkpoints that load back into fresh modules."""
+    import json
+
+    from learned_hologram_gan_amd.watermelon_hologram.discriminator import WGANGPDiscriminator192
+    from learned_hologram_gan_amd.watermelon_hologram.generator import Generator
+    from learned_hologram_gan_amd.watermelon_hologram.watermelon import LOSS_NAMES, watermelon
+
+    rows = cols = 32
+    stack = torch.linspace(-4e-4, 0.0, 21)[:-1][:6]
+    W = watermelon(filter_radius_coefficient=0.45, pad_size=16, distance_stack=stack, input_shape=(1, 4, rows, cols))
+    W.generator.load_state_dict(seeded.generator_state_dict())
+    W.discriminator.load_state_dict(seeded.critic_state_dict())
+    batches = [tuple(t.to(DEV) for t in seeded.smooth_batch(2, rows, cols, seed=60 + i)) for i in range(2)]
+    val = [tuple(t.to(DEV) for t in seeded.smooth_batch(1, rows, cols, seed=70))]
+    pG, pD, pJ = str(tmp_path / "G.pth"), str(tmp_path / "D.pth"), str(tmp_path / "metrics.csv")
+    torch.manual_seed(5)
+    W.train(batches, val, phs_gradient_loss_weight=1, perceptual_loss_weight=0.0, pixel_loss_weight=1, TV_loss_weight=1e-3,
+            discriminator_loss_weight=1e-1, epoch_num=1, lr_G=1e-3, lr_D=1e-3, save_path_G=pG, save_path_D=pD, info_print_interval=1,
+            info_plot_interval=10**9, loss_metrics_file=pJ, save_path_img=None, checkpoint_iterval=1, discriminator_train_ratio=1,
+            discriminator_lambda=10)
+    rec = json.load(open(pJ))  # the reference writes JSON under a .csv name (README.md:65)
+    assert rec["n_batch"] == [1, 2] and rec["n_train"] == [2, 4] and rec["epoch"] == [0, 0]
+    for section in ("train_losses_tensor", "validate_losses_tensor"):
+        assert set(rec[section]) == set(LOSS_NAMES) and all(len(v) == 2 for v in rec[section].values())
+        assert all(torch.isfinite(torch.tensor(v)).all() for k, v in rec[section].items())
+    assert set(rec["train_metrics_tensor"]) == {"PSNR", "SSIM"} and rec["validate_losses_tensor"]["D_loss"] == [0.0, 0.0]
+    for f in ("G.pth", "G_epoch0.pth", "D.pth", "D_epoch0.pth"):
+        assert (tmp_path / f).exists(), f
+    G2 = Generator(rows, cols, 16, 0.45, 3, PITCH, WL, torch.tensor([1e-3]), pretrained_model_path=pG)
+    D2 = WGANGPDiscriminator192(pretrained_model_path=pD, cuda=True)
+    for k, v in W.generator.state_dict().items():
+        assert torch.equal(G2.state_dict()[k].cpu(), v.cpu()), k
+    assert int(D2.state_dict()["block2.1.num_batches_tracked"]) == 2 * 4  # 3 critic + 1 generator-side forwards per step
+    assert W.generator.training and W.discriminator.training  # validation restores train mode
+
+
 def test_product_has_no_cpu_fallback():
     from learned_hologram_gan_amd import hip_ops, native
 

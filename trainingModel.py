@@ -56,14 +56,24 @@ def train_gan(a):
                                                num_workers=0, drop_last=True)
     val_loader = torch.utils.data.DataLoader(val_set, batch_size=max(1, a.batch_size // 2), shuffle=False, num_workers=0)
 
+    # The reference weighs a VGG19 perceptual term with 0.1 (trainingModel.py:78) using downloaded ImageNet weights; here the
+    # weights must come from a local file ($LHG_VGG19_WEIGHTS), otherwise the term is switched off.
+    perceptual, perceptual_weight = None, 0.0
+    if os.environ.get("LHG_VGG19_WEIGHTS"):
+        from learned_hologram_gan_amd.watermelon_hologram.perceptual import perceptualLoss
+
+        perceptual, perceptual_weight = perceptualLoss(), 1e-1
+    elif rank == 0:
+        print("LHG_VGG19_WEIGHTS is not set: training without the VGG19 perceptual term (reference weight 0.1)")
     GAN = watermelon(filter_radius_coefficient=0.45, pad_size=320, distance_stack=torch.linspace(-4e-4, 0.0, 21)[:-1],
-                     pretrained_model_path_G=None, pretrained_model_path_D=None, input_shape=(1, 4, a.height, a.width), cuda=True)
+                     pretrained_model_path_G=None, pretrained_model_path_D=None, input_shape=(1, 4, a.height, a.width), cuda=True,
+                     perceptual_loss=perceptual)
     if rank == 0:
         for p in (os.path.dirname(a.save_path_G), os.path.dirname(a.save_path_D), os.path.dirname(a.loss_metrics_file), a.save_path_img):
             check_and_create_folder(p)
     only0 = (lambda p: p if rank == 0 else None)
     GAN.train(data_loader_train=train_loader, data_loader_val=val_loader, phs_gradient_loss_weight=1,
-              perceptual_loss_weight=float(os.environ.get("LHG_PERCEPTUAL_WEIGHT", "0")),  # reference: 1e-1 (VGG19, not built yet)
+              perceptual_loss_weight=perceptual_weight,
               pixel_loss_weight=1, TV_loss_weight=1e-3, discriminator_loss_weight=1e-1, epoch_num=a.epoch_num, lr_G=a.lr_G, lr_D=a.lr_D,
               save_path_G=only0(a.save_path_G), save_path_D=only0(a.save_path_D), info_print_interval=50, info_plot_interval=50,
               loss_metrics_file=only0(a.loss_metrics_file), save_path_img=a.save_path_img, checkpoint_iterval=1,
