@@ -47,6 +47,7 @@ def parse():
     ap.add_argument("--d-ratio", type=int, default=1, help="critic updates per generator update (BASELINE.md assembled step: 1)")
     ap.add_argument("--cpu-baseline", type=int, default=1, help="0 skips the CPU oracle timing")
     ap.add_argument("--cpu-rows", type=int, default=0, help="frame size of the CPU sample (0 = same as --rows)")
+    ap.add_argument("--graph", type=int, default=0, help="infer mode: replay a captured hipGraph instead of eager launches")
     ap.add_argument("--mode", choices=("train", "infer"), default="train",
                     help="train: the GAN step (the benchmark metric); infer: eval-mode generator forward RGBD->POH only (informational)")
     return ap.parse_args()
@@ -105,13 +106,19 @@ def main():
 
     if args.mode == "infer":
         W.generator.eval()
+        run = W.generator
+        if args.graph:
+            from learned_hologram_gan_amd.graph import GraphedGenerator
+
+            graphed = GraphedGenerator(W.generator, rgbd)
+            run = lambda x: graphed(x, clone=False)  # noqa: E731
         with torch.no_grad():
             for _ in range(args.warmup):
-                W.generator(rgbd)
+                run(rgbd)
             sync()
             t0 = time.perf_counter()
             for _ in range(args.steps):
-                W.generator(rgbd)
+                run(rgbd)
             sync()
             dt = time.perf_counter() - t0
         if rank == 0:
@@ -119,7 +126,8 @@ def main():
                               "value": round(B * world * args.steps / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
                               "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
                               "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                              "config": {"workload": f"{args.rows}x{args.cols}x3 bs={B} generator forward (UNet + ASM back-propagation + POH encode)"}}))
+                              "config": {"workload": f"{args.rows}x{args.cols}x3 bs={B} generator forward (UNet + ASM back-propagation + POH encode)"
+                                                     + (", hipGraph replay" if args.graph else "")}}))
         return
 
     for _ in range(args.warmup):

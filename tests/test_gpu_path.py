@@ -520,6 +520,20 @@ def test_train_loop_validation_checkpoints_and_metrics_json(tmp_path):
     assert W.generator.training and W.discriminator.training  # validation restores train mode
 
 
+def test_hipgraph_inference_matches_eager():
+    from learned_hologram_gan_amd.graph import GraphedGenerator
+
+    G = _generator(64, 64, 32).eval()
+    a, _, _ = seeded.smooth_batch(1, 64, 64, seed=81)
+    b, _, _ = seeded.smooth_batch(1, 64, 64, seed=82)
+    with torch.no_grad():
+        ea, eb = G(a.to(DEV)).clone(), G(b.to(DEV)).clone()
+    graphed = GraphedGenerator(G, a.to(DEV))
+    assert torch.equal(graphed(b.to(DEV)), eb) and torch.equal(graphed(a.to(DEV)), ea)  # bit-identical replays, new inputs honoured
+    with pytest.raises(ValueError):
+        graphed(torch.zeros(2, 4, 64, 64, device=DEV))
+
+
 def test_product_has_no_cpu_fallback():
     from learned_hologram_gan_amd import hip_ops, native
 
