@@ -130,7 +130,7 @@ int lhg_channel_sum(const float* x, long long pixels, int C, int ld, float* out,
  * ref: nn.LazyBatchNorm2d neural_network_components.py:23-24, nn.BatchNorm2d discriminator.py:39.
  * eps 1e-5.  stats[0..C) = batch mean, stats[C..2C) = 1/sqrt(biased var + eps).
  * running_* (may be NULL) are updated with `momentum` using the unbiased variance.
- * ws: >= 4096*C floats (partial sums, reduced in double). */
+ * ws: >= 4104*C floats (2048 partial blocks x 2 sums + the reduced sums; reduced in double). */
 int lhg_bn_stats(const float* x, long long pixels, int C, int ld, float* stats,
                  float* running_mean, float* running_var, float momentum, float eps,
                  float* ws, lhg_stream_t s);
@@ -172,7 +172,7 @@ int lhg_act_backward(const float* g, int ldg, const float* y, int ldy, long long
  *   out_mode: 0 complex   1 |z| and angle(z) (+ optional complex copy)   2 |z| only
  *   filter op per factor: 0 none, 1 multiply, 2 multiply by conj, 3 divide, 4 divide by conj
  *   f_index[p] selects the (rows x cols) slab of the factor used by plane p.
- * rows, cols (padded extents) must be powers of two in [16, 4096].
+ * rows, cols (padded extents) must be of the form 2^a * 3^b in [16, 4608] (Stockham radix 4 / 2 / 3 in LDS).
  * ws: 2 * planes * rows0 * cols complex64.                                             */
 typedef struct lhg_asm_filter {
   const float* f1; const int32_t* f1_index; int f1_op;  /* device pointers */

@@ -36,7 +36,14 @@ def twiddles(n: int, device) -> torch.Tensor:
 
 
 def supported_extent(n: int) -> bool:
-    return 16 <= n <= 4096 and (n & (n - 1)) == 0
+    """Lengths the LDS FFT handles: 2^a * 3^b in [16, 4608] (radix 4 / 2 / 3 stages); 4K frames use 2304 x 4096."""
+    if not 16 <= n <= 4608:
+        return False
+    while n % 2 == 0:
+        n //= 2
+    while n % 3 == 0:
+        n //= 3
+    return n == 1
 
 
 @dataclass

@@ -15,6 +15,8 @@
 // dense fft2 calls (DESIGN.md has the accounting).  The 1-D transforms are Stockham autosort
 // radix-4 (+ one radix-2 stage for odd log2 n) in LDS with a host-exact twiddle table
 // (computed in double), in place with register staging (read-all / barrier / write-all).
+#include <algorithm>
+
 #include "common.h"
 
 namespace lhg {
@@ -35,7 +37,9 @@ template <bool INV>
 __device__ void lds_fft(float2* buf, int n, int nf, int stride, const float2* tw) {
   const int nthreads = blockDim.x, tid = threadIdx.x;
   for (int p = 1; p < n;) {
-    const int R = (n / p >= 4) ? 4 : 2;
+    const int rem = n / p;                                   // n = 2^a * 3^b: radix 4 while possible, then 2, then 3
+    const int R = (rem % 4 == 0) ? 4 : ((rem % 2 == 0) ? 2 : 3);
+    const bool p_pow2 = (p & (p - 1)) == 0;
     const int T = n / R;
     const int total = nf * T;
     const int twstep = n / (p * R);
@@ -46,7 +50,7 @@ __device__ void lds_fft(float2* buf, int n, int nf, int stride, const float2* tw
         const int b = tid + it * nthreads;
         if (b < total) {
           const int f = b / T, i = b - f * T;
-          const int k = i & (p - 1);
+          const int k = p_pow2 ? (i & (p - 1)) : (i % p);
           const float2* x = buf + f * stride + i;
           float2 u0 = x[0], u1 = x[T], u2 = x[2 * T], u3 = x[3 * T];
           if (p > 1) {
@@ -65,20 +69,20 @@ __device__ void lds_fft(float2* buf, int n, int nf, int stride, const float2* tw
         const int b = tid + it * nthreads;
         if (b < total) {
           const int f = b / T, i = b - f * T;
-          const int k = i & (p - 1);
+          const int k = p_pow2 ? (i & (p - 1)) : (i % p);
           float2* y = buf + f * stride + ((i - k) << 2) + k;
           y[0] = u[it][0]; y[p] = u[it][1]; y[2 * p] = u[it][2]; y[3 * p] = u[it][3];
         }
       }
       __syncthreads();
-    } else {
-      // radix-2 tail: 2*T == n, so up to 2*MAX_IT butterflies per thread
+    } else if (R == 2) {
+      // radix-2 stage: 2*T == n, so up to 2*MAX_IT butterflies per thread
 #pragma unroll
       for (int it = 0; it < 2 * MAX_IT; ++it) {
         const int b = tid + it * nthreads;
         if (b < total) {
           const int f = b / T, i = b - f * T;
-          const int k = i & (p - 1);
+          const int k = p_pow2 ? (i & (p - 1)) : (i % p);
           const float2* x = buf + f * stride + i;
           float2 u0 = x[0], u1 = x[T];
           float2 w = tw[k * twstep];
@@ -94,10 +98,45 @@ __device__ void lds_fft(float2* buf, int n, int nf, int stride, const float2* tw
         const int b = tid + it * nthreads;
         if (b < total) {
           const int f = b / T, i = b - f * T;
-          const int k = i & (p - 1);
+          const int k = p_pow2 ? (i & (p - 1)) : (i % p);
           float2* y = buf + f * stride + ((i - k) << 1) + k;
           y[0] = u[it >> 1][(it & 1) * 2];
           y[p] = u[it >> 1][(it & 1) * 2 + 1];
+        }
+      }
+      __syncthreads();
+    } else {
+      // radix-3 stage (2304 = 2^8 * 3^2 for the 4K geometry): w3 = -1/2 -+ i*sqrt(3)/2
+      const float c3 = 0.8660254037844386f;
+#pragma unroll
+      for (int it = 0; it < MAX_IT; ++it) {
+        const int b = tid + it * nthreads;
+        if (b < total) {
+          const int f = b / T, i = b - f * T;
+          const int k = i % p;
+          const float2* x = buf + f * stride + i;
+          float2 u0 = x[0], u1 = x[T], u2 = x[2 * T];
+          if (p > 1) {
+            float2 w1 = tw[k * twstep], w2 = tw[2 * k * twstep];
+            if (INV) { w1.y = -w1.y; w2.y = -w2.y; }
+            u1 = cmul(u1, w1); u2 = cmul(u2, w2);
+          }
+          const float2 t1 = cadd(u1, u2);
+          const float2 t2 = make_float2(u0.x - 0.5f * t1.x, u0.y - 0.5f * t1.y);
+          const float2 d = csub(u1, u2);
+          const float2 t3 = INV ? make_float2(-c3 * d.y, c3 * d.x) : make_float2(c3 * d.y, -c3 * d.x);
+          u[it][0] = cadd(u0, t1); u[it][1] = cadd(t2, t3); u[it][2] = csub(t2, t3);
+        }
+      }
+      __syncthreads();
+#pragma unroll
+      for (int it = 0; it < MAX_IT; ++it) {
+        const int b = tid + it * nthreads;
+        if (b < total) {
+          const int f = b / T, i = b - f * T;
+          const int k = i % p;
+          float2* y = buf + f * stride + (i - k) * 3 + k;
+          y[0] = u[it][0]; y[p] = u[it][1]; y[2 * p] = u[it][2];
         }
       }
       __syncthreads();
@@ -256,12 +295,24 @@ __global__ void twiddle_kernel(float2* tw, int n) {
 }
 
 // ---------------------------------------------------------------------------------------- host
-static bool pow2_in_range(int n) { return n >= 16 && n <= 4096 && (n & (n - 1)) == 0; }
+// supported transform lengths: 2^a * 3^b in [16, 4608] (radix 4 / 2 / 3 Stockham stages)
+static bool smooth_in_range(int n) {
+  if (n < 16 || n > 4608) return false;
+  while (n % 2 == 0) n /= 2;
+  while (n % 3 == 0) n /= 3;
+  return n == 1;
+}
+// butterflies per thread per stage are capped at MAX_IT: n*nf <= 16*threads (radix 4 / 2) or 12*threads (radix 3)
+static int fft_budget(int n) { return n % 3 == 0 ? 12 : 16; }
 
-static int rows_nf(int n) { return n >= 4096 ? 1 : 4096 / n > 64 ? 64 : 4096 / n; }
+static int rows_nf(int n) {
+  const int cap = fft_budget(n) * 256;
+  return std::max(1, std::min(64, cap / n));
+}
 
 static int set_dyn_lds(const void* fn, size_t bytes) {
   if (bytes > 160 * 1024) return fail(LHG_E_ARG, "asm: LDS request %zu exceeds 160 KiB", bytes);
+  static_assert(MAX_IT == 4, "fft_budget assumes 4 butterflies per thread per stage");
   if (bytes > 48 * 1024) {
     hipError_t e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)bytes);
     if (e != hipSuccess) return fail(LHG_E_LAUNCH, "hipFuncSetAttribute: %s", hipGetErrorString(e));
@@ -298,8 +349,10 @@ static int run_cols(ColsParams& p, hipStream_t st) {
   int G = 16;
   while (G > 1 && (size_t)G * (p.R + 1) * sizeof(float2) + (size_t)p.R * sizeof(float2) > 150 * 1024) G >>= 1;
   int threads = 1024;
-  while (G > 1 && (long long)G * p.R > 16ll * threads) G >>= 1;
-  if ((long long)G * p.R > 16ll * threads) return fail(LHG_E_ARG, "asm: column length %d unsupported", p.R);
+  const long long budget = fft_budget(p.R);
+  while (G > 1 && (long long)G * p.R > budget * threads) G >>= 1;
+  if ((long long)G * p.R > budget * threads) return fail(LHG_E_ARG, "asm: column length %d unsupported", p.R);
+  while (G > 1 && p.C % G != 0) G >>= 1;
   while (threads > 64 && (long long)G * p.R <= 2ll * threads) threads >>= 1;  // small transforms: fewer idle waves
   p.G = G;
   const size_t lds = ((size_t)G * (p.R + 1) + p.R) * sizeof(float2);
@@ -312,7 +365,7 @@ static int run_cols(ColsParams& p, hipStream_t st) {
 static int check_geometry(int planes, int rows0, int cols0, int pad_r, int pad_c, const char* what) {
   const int R = rows0 + 2 * pad_r, C = cols0 + 2 * pad_c;
   LHG_REQUIRE(planes > 0 && rows0 > 0 && cols0 > 0 && pad_r >= 0 && pad_c >= 0, "%s: bad extents", what);
-  LHG_REQUIRE(pow2_in_range(R) && pow2_in_range(C), "%s: padded extents %dx%d must be powers of two in [16,4096]", what, R, C);
+  LHG_REQUIRE(smooth_in_range(R) && smooth_in_range(C), "%s: padded extents %dx%d must be 2^a*3^b in [16,4608]", what, R, C);
   return LHG_OK;
 }
 

@@ -467,7 +467,7 @@ class BatchNormTrainFn(Function):
         pixels = N * H * W
         stats = torch.empty((2 * Cc,), dtype=torch.float32, device=x.device)
         call("lhg_bn_stats", px, pixels, Cc, ldx, ptr(stats), ptr(running_mean), ptr(running_var), BN_MOMENTUM, BN_EPS,
-             ptr(_bn_ws(Cc, x.device, 4096)), stream_ptr())
+             ptr(_bn_ws(Cc, x.device, 4104)), stream_ptr())
         y = _resolve_out(out, (N, H, W, Cc), x.device)
         py, _, _, _, _, ldy = nhwc(y)
         pres, ldres = (None, 0)
