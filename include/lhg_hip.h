@@ -172,7 +172,7 @@ int lhg_act_backward(const float* g, int ldg, const float* y, int ldy, long long
  *   out_mode: 0 complex   1 |z| and angle(z) (+ optional complex copy)   2 |z| only
  *   filter op per factor: 0 none, 1 multiply, 2 multiply by conj, 3 divide, 4 divide by conj
  *   f_index[p] selects the (rows x cols) slab of the factor used by plane p.
- * rows, cols (padded extents) must be of the form 2^a * 3^b in [16, 4608] (Stockham radix 4 / 2 / 3 in LDS).
+ * rows, cols (padded extents) must be of the form 2^a * 3^b in [16, 4096], at most 3072 when divisible by 3 (Stockham radix 4 / 2 / 3 in LDS).
  * ws: 2 * planes * rows0 * cols complex64.                                             */
 typedef struct lhg_asm_filter {
   const float* f1; const int32_t* f1_index; int f1_op;  /* device pointers */

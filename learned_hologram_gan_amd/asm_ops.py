@@ -36,8 +36,9 @@ def twiddles(n: int, device) -> torch.Tensor:
 
 
 def supported_extent(n: int) -> bool:
-    """Lengths the LDS FFT handles: 2^a * 3^b in [16, 4608] (radix 4 / 2 / 3 stages); 4K frames use 2304 x 4096."""
-    if not 16 <= n <= 4608:
+    """Lengths the LDS FFT handles: 2^a * 3^b in [16, 4096], at most 3072 with a factor 3 (radix 4 / 2 / 3
+    stages); 4K frames use 2304 x 4096."""
+    if not 16 <= n <= (3072 if n % 3 == 0 else 4096):
         return False
     while n % 2 == 0:
         n //= 2

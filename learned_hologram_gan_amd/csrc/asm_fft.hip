@@ -295,9 +295,10 @@ __global__ void twiddle_kernel(float2* tw, int n) {
 }
 
 // ---------------------------------------------------------------------------------------- host
-// supported transform lengths: 2^a * 3^b in [16, 4608] (radix 4 / 2 / 3 Stockham stages)
+// supported transform lengths: 2^a * 3^b in [16, 4096] (radix 4 / 2 / 3 Stockham stages); one 256-thread
+// workgroup must hold a whole row transform, so lengths with a factor 3 stop at 3072
 static bool smooth_in_range(int n) {
-  if (n < 16 || n > 4608) return false;
+  if (n < 16 || n > (n % 3 == 0 ? 3072 : 4096)) return false;
   while (n % 2 == 0) n /= 2;
   while (n % 3 == 0) n /= 3;
   return n == 1;
@@ -365,7 +366,7 @@ static int run_cols(ColsParams& p, hipStream_t st) {
 static int check_geometry(int planes, int rows0, int cols0, int pad_r, int pad_c, const char* what) {
   const int R = rows0 + 2 * pad_r, C = cols0 + 2 * pad_c;
   LHG_REQUIRE(planes > 0 && rows0 > 0 && cols0 > 0 && pad_r >= 0 && pad_c >= 0, "%s: bad extents", what);
-  LHG_REQUIRE(smooth_in_range(R) && smooth_in_range(C), "%s: padded extents %dx%d must be 2^a*3^b in [16,4608]", what, R, C);
+  LHG_REQUIRE(smooth_in_range(R) && smooth_in_range(C), "%s: padded extents %dx%d must be 2^a*3^b in [16,4096] (<=3072 with a factor 3)", what, R, C);
   return LHG_OK;
 }
 

@@ -77,9 +77,10 @@ def test_asm_against_golden(golden):
     assert rel_err(amp.cpu(), g["call_amp"]) < PARITY
 
 
-def test_asm_gradients_match_oracle():
-    r0 = c0 = 48
-    pad, coef = 8, 0.45
+@pytest.mark.parametrize("r0,c0,pad", [(48, 48, 8), (40, 64, 4), (18, 90, 3)])
+def test_asm_gradients_match_oracle(r0, c0, pad):
+    """Padded extents 64x64 (radix 4), 48x72 and 24x96 (radix 4/2/3 mixed: 2^a * 3^b)."""
+    coef = 0.45
     stack = torch.linspace(-4e-4, 0.0, 21)[:-1][:5]
     fx, mu = _fixed(r0, c0, pad, coef), _multi(r0, c0, stack, pad, coef)
     o = optics.make_optics(r0, c0, pad, coef, PITCH, WL)
@@ -405,6 +406,27 @@ def test_config4_4k_frame_unet_locality():
         ref = nets.unet(nets.as_parameters(sd), "", crop, False)
     got = y[:, :, cy - half: cy + half, cx - half: cx + half].cpu()
     assert rel_err(got, ref[:, :, margin: margin + 2 * half, margin: margin + 2 * half]) < PARITY
+
+
+def test_asm_4k_geometry_radix3():
+    """BASELINE configs[4]: 2160x3840 frames, pad 72 -> 2304 x 4096 transforms (2304 = 2^8 * 3^2) on the LDS FFT."""
+    r0, c0, pad = 2160, 3840, 72
+    stack = torch.linspace(-4e-4, 0.0, 21)[:-1]
+    fx, mu = _fixed(r0, c0, pad, 0.45), _multi(r0, c0, stack, pad, 0.45)
+    assert fx._geom.supported()
+    o = optics.make_optics(r0, c0, pad, 0.45, PITCH, WL)
+    Hf = optics.transfer_function(o.w, torch.tensor([1e-3]))[0]
+    g = torch.Generator().manual_seed(12)
+    small = torch.rand((3, 1, 3, r0 // 8, c0 // 8), generator=g)
+    amp, phs, poh = (torch.nn.functional.interpolate(t, size=(r0, c0), mode="bilinear") for t in small)
+    ref_field = optics.backpropagate_to_slm(o, Hf, amp + 0.1, phs * 6.28)
+    assert cplx_err(fx.propagate_AP2C_backward((amp + 0.1).to(DEV), (phs * 6.28).to(DEV)), ref_field) < PARITY
+    idx = torch.tensor([13])
+    S = optics.poh_to_filtered_spectrum(o, Hf, (poh - 0.5) * 9)
+    T = optics.target_to_filtered_spectrum(o, amp, phs)
+    a, _ = optics.spectrum_to_planes_indexed(o, optics.transfer_function(o.w, stack), torch.cat((S, T)), idx)
+    ha, _, ta, _ = mu.reconstruct_planes(fx, ((poh - 0.5) * 9).to(DEV), amp.to(DEV), phs.to(DEV), idx)
+    assert rel_err(torch.cat((ha, ta)).cpu(), a) < PARITY
 
 
 def test_non_power_of_two_extent_uses_rocfft_route():
