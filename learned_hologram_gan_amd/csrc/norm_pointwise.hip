@@ -124,20 +124,33 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
   });
 }
 
-// sums[k][c] = sum_b partial[b][k][c] in double.  grid (ceil(C/32), NSUM), block 32 channels x 8 slices.
+// sums[k][c] = sum_b partial[b][k][c] in double.  grid (ceil(C/32), NSUM), block 32 channels x 32 slices; four independent
+// accumulators per thread keep several loads in flight (the kernel is latency-bound: 2048 partial rows, few workgroups).
+constexpr int RP_SLICES = 32;
 template <int NSUM>
-__global__ __launch_bounds__(256) void reduce_partials(const float* __restrict__ partial, int nblk, int C, float* __restrict__ sums) {
-  __shared__ double red[8][32];
+__global__ __launch_bounds__(1024) void reduce_partials(const float* __restrict__ partial, int nblk, int C, float* __restrict__ sums) {
+  __shared__ double red[RP_SLICES][32];
   const int lane_c = threadIdx.x & 31, slice = threadIdx.x >> 5, k = blockIdx.y;
   const int c = blockIdx.x * 32 + lane_c;
-  double s = 0;
-  if (c < C)
-    for (int b = slice; b < nblk; b += 8) s += partial[((size_t)b * NSUM + k) * C + c];
-  red[slice][lane_c] = s;
+  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+  if (c < C) {
+    const float* src = partial + (size_t)k * C + c;
+    const size_t stride = (size_t)NSUM * C;
+    int b = slice;
+    for (; b + 3 * RP_SLICES < nblk; b += 4 * RP_SLICES) {
+      s0 += src[(size_t)b * stride];
+      s1 += src[(size_t)(b + RP_SLICES) * stride];
+      s2 += src[(size_t)(b + 2 * RP_SLICES) * stride];
+      s3 += src[(size_t)(b + 3 * RP_SLICES) * stride];
+    }
+    for (; b < nblk; b += RP_SLICES) s0 += src[(size_t)b * stride];
+  }
+  red[slice][lane_c] = (s0 + s1) + (s2 + s3);
   __syncthreads();
   if (slice == 0 && c < C) {
+    double s = 0;
 #pragma unroll
-    for (int i = 1; i < 8; ++i) s += red[i][lane_c];
+    for (int i = 0; i < RP_SLICES; ++i) s += red[i][lane_c];
     sums[(size_t)k * C + c] = (float)s;
   }
 }
@@ -446,7 +459,7 @@ int lhg_channel_sum(const float* x, long long pixels, int C, int ld, float* out,
   const ColMap cm = col_map(C);
   const int nblk = partial_blocks(pixels);
   hipLaunchKernelGGL(channel_sum_partial, dim3(nblk), dim3(256), 0, as_stream(s), x, pixels, C, ld, cm.lanes_c, cm.rows, ws);
-  hipLaunchKernelGGL(reduce_partials<1>, dim3((C + 31) / 32, 1), dim3(256), 0, as_stream(s), ws, nblk, C, out);
+  hipLaunchKernelGGL(reduce_partials<1>, dim3((C + 31) / 32, 1), dim3(1024), 0, as_stream(s), ws, nblk, C, out);
   return check_launch("channel_sum");
 }
 
@@ -458,7 +471,7 @@ int lhg_bn_stats(const float* x, long long pixels, int C, int ld, float* stats, 
   const int nblk = partial_blocks(pixels);
   hipLaunchKernelGGL(bn_stats_partial, dim3(nblk), dim3(256), 0, as_stream(s), x, pixels, C, ld, cm.lanes_c, cm.rows, ws);
   float* sums = ws + (size_t)nblk * 2 * C;
-  hipLaunchKernelGGL(reduce_partials<2>, dim3((C + 31) / 32, 2), dim3(256), 0, as_stream(s), ws, nblk, C, sums);
+  hipLaunchKernelGGL(reduce_partials<2>, dim3((C + 31) / 32, 2), dim3(1024), 0, as_stream(s), ws, nblk, C, sums);
   hipLaunchKernelGGL(bn_stats_final, dim3((C + 255) / 256), dim3(256), 0, as_stream(s), sums, x, pixels, C, stats, running_mean,
                      running_var, momentum, eps);
   return check_launch("bn_stats");
@@ -489,7 +502,7 @@ int lhg_bn_backward(const float* gy, int ldgy, const float* x, int ldx, const fl
   float* sums = ws + (size_t)nblk * 2 * C;
   hipLaunchKernelGGL(bn_bwd_partial, dim3(nblk), dim3(256), 0, as_stream(s), gy, ldgy, x, ldx, y, ldy, pixels, C, stats, act, slope,
                      cm.lanes_c, cm.rows, ws);
-  hipLaunchKernelGGL(reduce_partials<2>, dim3((C + 31) / 32, 2), dim3(256), 0, as_stream(s), ws, nblk, C, sums);
+  hipLaunchKernelGGL(reduce_partials<2>, dim3((C + 31) / 32, 2), dim3(1024), 0, as_stream(s), ws, nblk, C, sums);
   const int nb2 = grid_for((size_t)pixels, cm.rows * 4, 4096);
   hipLaunchKernelGGL(bn_bwd_apply, dim3(nb2), dim3(256), 0, as_stream(s), gy, ldgy, x, ldx, y, ldy, pixels, C, stats, gamma, sums, act,
                      slope, gx, ldgx, gres, ldgres, ggamma, gbeta, cm.lanes_c, cm.rows);
@@ -506,7 +519,7 @@ int lhg_bn_backward_backward(const float* ggx, const float* gy, const float* x, 
   float* sums = ws + (size_t)nblk * 5 * C;
   hipLaunchKernelGGL(bn_bwd2_partial, dim3(nblk), dim3(256), 0, as_stream(s), ggx, gy, x, y, pixels, C, stats, act, slope, cm.lanes_c,
                      cm.rows, ws);
-  hipLaunchKernelGGL(reduce_partials<5>, dim3((C + 31) / 32, 5), dim3(256), 0, as_stream(s), ws, nblk, C, sums);
+  hipLaunchKernelGGL(reduce_partials<5>, dim3((C + 31) / 32, 5), dim3(1024), 0, as_stream(s), ws, nblk, C, sums);
   const int nb2 = grid_for((size_t)pixels, cm.rows * 4, 4096);
   hipLaunchKernelGGL(bn_bwd2_apply, dim3(nb2), dim3(256), 0, as_stream(s), ggx, gy, x, y, pixels, C, stats, gamma, sums, act, slope, ggy,
                      gx2, ggamma2, cm.lanes_c, cm.rows);

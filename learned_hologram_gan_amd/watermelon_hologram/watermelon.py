@@ -31,6 +31,22 @@ from .loss_func import fakePerceptualLoss, focal_sincos_phase_gradient_loss, tot
 LOSS_NAMES = ("focal_phase_gradient_loss", "perceptual_loss", "pixel_loss", "TV_loss", "gan_loss", "G_loss", "D_loss")
 
 
+class _frozen:
+    """Context manager: parameters of `module` do not require grad while a forward pass is recorded."""
+
+    def __init__(self, module, enabled=True):
+        self.params = [p for p in module.parameters() if p.requires_grad] if enabled else []
+
+    def __enter__(self):
+        for p in self.params:
+            p.requires_grad_(False)
+
+    def __exit__(self, *exc):
+        for p in self.params:
+            p.requires_grad_(True)
+        return False
+
+
 def psnr(hat, target):
     """torchmetrics PeakSignalNoiseRatio() defaults: data_range = max(target) - min(target)."""
     rng = target.max() - target.min()
@@ -79,6 +95,7 @@ class watermelon:
         if pretrained_model_path_D is not None:
             print(f"Discriminator loaded from {pretrained_model_path_D}")
         self._opt_G = self._opt_D = self._sync_G = self._sync_D = None
+        self.skip_unused_critic_grads = True  # see train_step: critic weight gradients of the generator pass are dead values
 
     def _make_discriminator(self, path):
         return WGANGPDiscriminator192(pretrained_model_path=path, cuda=True)
@@ -171,7 +188,11 @@ class watermelon:
             self._sync_D.finish()
             self._opt_D.step()
             d_total = d_total + d_loss.detach() / ratio
-        loss_from_discriminator = -torch.mean(self.discriminator(hat_amps))
+        # The critic's weight gradients of this pass are never read: the reference zeroes them (watermelon.py:252) before the
+        # next critic backward and optimizer_G does not own them.  Recording the pass with frozen critic weights drops those
+        # weight-gradient GEMMs; every tensor the step produces (losses, generator gradients, both Adam updates) is unchanged.
+        with _frozen(self.discriminator, self.skip_unused_critic_grads):
+            loss_from_discriminator = -torch.mean(self.discriminator(hat_amps))
         g_loss = self.G_loss(hat_amps, target_amps, hat_phases, target_phases, loss_from_discriminator, self.train_losses_tensor)
         self._opt_G.zero_grad()
         self._sync_G.start()
