@@ -73,3 +73,67 @@ class FusedAdam:
         self.step_count = sd["step"]
         self.exp_avg.copy_(sd["exp_avg"])
         self.exp_avg_sq.copy_(sd["exp_avg_sq"])
+
+
+class ReduceOnPlateau:
+    """``torch.optim.lr_scheduler.ReduceLROnPlateau(opt, "min", factor, patience, threshold, "rel", min_lr=...)`` for
+    FusedAdam (which is not a ``torch.optim.Optimizer``).  ref: RGBD2AP.py:86-95, AP2POH.py:154-163."""
+
+    def __init__(self, optimizer: FusedAdam, factor=0.1, patience=4, threshold=1e-3, min_lr=1e-6, eps=1e-8):
+        if factor >= 1.0:
+            raise ValueError("Factor should be < 1.0.")
+        self.optimizer, self.factor, self.patience, self.threshold, self.min_lr, self.eps = optimizer, factor, patience, threshold, min_lr, eps
+        self.best, self.num_bad_epochs = float("inf"), 0
+
+    def step(self, metric):
+        metric = float(metric)
+        if metric < self.best * (1.0 - self.threshold):
+            self.best, self.num_bad_epochs = metric, 0
+        else:
+            self.num_bad_epochs += 1
+        if self.num_bad_epochs > self.patience:
+            new_lr = max(self.optimizer.lr * self.factor, self.min_lr)
+            if self.optimizer.lr - new_lr > self.eps:
+                self.optimizer.lr = new_lr
+            self.num_bad_epochs = 0
+        return self.optimizer.lr
+
+
+def run_pretraining(model, batch_loss, train_loader, val_loader, epochs, lr, gamma, save_path, checkpoint_iterval):
+    """The epoch loop shared by ``RGBD2AP.train_model`` and ``AP2POH.train_model`` (ref: RGBD2AP.py:97-137, AP2POH.py:165-218):
+    Adam on every parameter, per-epoch train / validation loss = sum of batch losses / number of samples, plateau schedule on the
+    validation loss, ``_epoch{n}`` checkpoints.  ``batch_loss(batch) -> (loss, samples)``."""
+    if model.freeze:
+        raise ValueError("The model is frozen, cannot be trained")
+    if save_path is None:
+        print("!!!!!!The save path is not specified, the model will not be saved!!!!!!")
+    if model.pretrained_model_path is not None:
+        print("The model is pretrained, will be fine-tuned or continued training")
+    model.train_loss, model.test_loss = [], []
+    model.optimizer = FusedAdam(FlatParams(model), lr=lr)
+    model.scheduler = ReduceOnPlateau(model.optimizer, factor=gamma, patience=4, threshold=1e-3, min_lr=1e-6)
+    for epoch in range(epochs):
+        model.train()
+        total, n = torch.zeros((), device=model.optimizer.flat.data.device), 0
+        for batch in train_loader:
+            loss, samples = batch_loss(batch)
+            model.optimizer.zero_grad()
+            loss.backward()
+            model.optimizer.step()
+            total, n = total + loss.detach(), n + samples
+        train_loss = total.item() / n
+        model.eval()
+        total, n = torch.zeros_like(total), 0
+        for batch in val_loader:
+            with torch.no_grad():
+                loss, samples = batch_loss(batch)
+            total, n = total + loss, n + samples
+        test_loss = total.item() / n
+        model.train_loss.append(train_loss)
+        model.test_loss.append(test_loss)
+        print(f"epoch {epoch + 1}, train loss {train_loss:.7f}, test loss {test_loss:.7f}")
+        model.scheduler.step(test_loss)
+        if epoch % checkpoint_iterval == 0 and epoch != 0 and save_path is not None:
+            torch.save(model.state_dict(), save_path.replace(".pth", f"_epoch{epoch}.pth"))
+    if save_path is not None:
+        torch.save(model.state_dict(), save_path)

@@ -1,6 +1,5 @@
 """(amplitude, phase) at z -> phase-only hologram at the SLM plane.
-ref: learnedMethodForHologram/watermelon_hologram/AP2POH.py:16-116.
-(The stand-alone pre-training loop ``train_model`` of the reference is SURVEY §8f N4.)"""
+ref: learnedMethodForHologram/watermelon_hologram/AP2POH.py:16-230 (incl. the stand-alone pre-training loop)."""
 
 from __future__ import annotations
 
@@ -10,7 +9,10 @@ from torch import nn
 from ..poh_ops import PohEncodeFn
 from ..angular_spectrum_method import bandLimitedAngularSpectrumMethod_for_single_fixed_distance as fixed_distance_propogator
 from ..neural_network_components import ChannelWiseSymmetricConv
+from ..asm_ops import F_MUL, Factor, IN_POLAR, OUT_ABS_ANGLE
+from ..optim import run_pretraining
 from ..utilities import amplitude_normalizor, generate_checkerboard_mask, try_gpu
+from .loss_func import amp_loss
 from .RGBD2AP import initialize_like_reference
 
 
@@ -34,6 +36,32 @@ class AP2POH(nn.Module):
             if freeze:
                 self.eval()
                 self.requires_grad_(False)
+
+    def dataloader_filter(self, amp, phs, filter_radius_coefficient):
+        """Low-pass the targets with the differentiable sigmoid mask: (abs, angle) of crop(ifft2(fft2(pad(a e^{i phs})) * mask)).
+        ref: AP2POH.py:75-84.  One fused angular-spectrum launch with the (real) mask as its only spectral factor."""
+        pr = self.propagator
+        mask = pr.generate_circular_frequency_mask_differentiable(filter_radius_coefficient)
+        slab = torch.complex(mask, torch.zeros_like(mask)).unsqueeze(0).contiguous()
+        index = torch.zeros(amp.shape[0] * 3, dtype=torch.int32, device=amp.device)
+        a, p, _ = pr._run(amp, phs, IN_POLAR, OUT_ABS_ANGLE, [Factor(slab, F_MUL, index)])
+        return a, p
+
+    def train_model(self, train_loader, val_loader, filter_radius_coefficient=0.45, epochs=30, lr=1e-3, alpha=1e-3, beta=1e-5,
+                    hyperparameter_gamma=0.1, save_path=None, checkpoint_iterval=10):
+        """Pre-train the symmetric stencils on (amplitude, phase) batches through the propagator.  ref: AP2POH.py:118-218."""
+
+        def batch_loss(batch):
+            amp, phs = self.dataloader_filter(batch[0], batch[1], filter_radius_coefficient)
+            poh = self(amp, phs)
+            amp_hat, _, spectrum_loss = self.propagator.propagate_POH2AP_forward_with_spectrum_loss(poh, filter_radius_coefficient)
+            return self.loss(amp_hat, amp, alpha) + beta * spectrum_loss, poh.size(0)
+
+        run_pretraining(self, batch_loss, train_loader, val_loader, epochs, lr, hyperparameter_gamma, save_path, checkpoint_iterval)
+
+    def loss(self, amp_hat, amp, alpha):
+        """ref: AP2POH.py:220-230."""
+        return amp_loss(amp_hat, amp, alpha)
 
     def double_phase_method(self, amp, phs):
         """POH = m1*(phs + acos a) + m2*(phs - acos a). ref: AP2POH.py:86-96."""

@@ -1,6 +1,5 @@
 """RGBD -> (amplitude, phase) stage of the generator.
-ref: learnedMethodForHologram/watermelon_hologram/RGBD2AP.py:15-50, 155-176.
-(The stand-alone pre-training loop ``train_model`` of the reference is SURVEY §8f N4.)"""
+ref: learnedMethodForHologram/watermelon_hologram/RGBD2AP.py:15-176 (incl. the stand-alone pre-training loop)."""
 
 from __future__ import annotations
 
@@ -8,7 +7,9 @@ import torch
 from torch import nn
 
 from ..neural_network_components import UNet
+from ..optim import run_pretraining
 from ..utilities import try_gpu
+from .loss_func import amp_phs_loss
 
 
 def initialize_like_reference(module: nn.Module) -> None:
@@ -44,3 +45,18 @@ class RGBD2AP(nn.Module):
     def forward(self, RGBD):
         y = self.part1(RGBD)
         return self.amplitude_scaler * y[:, :3, :, :], 2 * torch.pi * y[:, 3:, :, :]
+
+    def train_model(self, train_loader, val_loader, epochs=30, lr=1e-3, alpha=1e-3, hyperparameter_gamma=0.1, save_path=None,
+                    checkpoint_iterval=10):
+        """Pre-train the UNet on (RGBD, amplitude, phase in [0,1)) batches.  ref: RGBD2AP.py:52-137."""
+
+        def batch_loss(batch):
+            img_depth, amp, phs = batch
+            amp_hat, phs_hat = self(img_depth)
+            return self.loss(amp_hat, phs_hat, amp, 2 * torch.pi * phs, alpha), img_depth.size(0)
+
+        run_pretraining(self, batch_loss, train_loader, val_loader, epochs, lr, hyperparameter_gamma, save_path, checkpoint_iterval)
+
+    def loss(self, amp_hat, phs_hat, amp, phs, alpha):
+        """ref: RGBD2AP.py:139-153 — the target phase is scaled by 2*pi here as well as by the caller in ``train_model``."""
+        return amp_phs_loss(amp_hat, phs_hat, amp, 2 * torch.pi * phs, alpha)

@@ -19,10 +19,11 @@ Layout
     optics.py   A1 A2 A5 A8 A9  constants, pad/crop, angular-spectrum propagation
     nets.py     A3 A4 A6 A7 A10 functional UNet / generator / critic on a state_dict
     losses.py   A13             focal sin/cos phase-gradient, TV, pixel losses
-    step.py     A11 A12         gradient penalty, D/G step sequence, Adam
+    step.py     A11 A12 A14     gradient penalty, D/G step sequence, Adam, all-planes validation
+    pretrain.py     N4          stand-alone pre-training loops of the two generator halves
     perceptual.py   N1          VGG19 perceptual loss (parity unpinned: the reference downloads its weights)
     seeded.py                   deterministic per-key weights with the reference's
                                 state_dict names and shapes
 """
 
-from . import optics, nets, losses, step, seeded, perceptual  # noqa: F401
+from . import optics, nets, losses, step, seeded, perceptual, pretrain  # noqa: F401

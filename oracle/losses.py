@@ -52,3 +52,34 @@ def psnr(hat, target):
     (torchmetrics is not installed here: parity of this metric is unpinned)."""
     rng = target.max() - target.min()
     return 10.0 * torch.log10(rng**2 / F.mse_loss(hat, target))
+
+
+def ssim(hat, target, kernel_size=11, sigma=1.5, k1=0.01, k2=0.03):
+    """torchmetrics StructuralSimilarityIndexMeasure() defaults, restated from its published algorithm
+    (functional/image/ssim.py, v1.x): 11x11 Gaussian window (sigma 1.5, taps exp(-(d/sigma)^2/2) normalised, d = -5..5),
+    data_range = max(range(hat), range(target)), c = (k*range)^2, inputs reflect-padded by 5, the five windowed moments
+    E[x] E[y] E[xx] E[yy] E[xy], the SSIM map cropped by 5 on every side, mean over all remaining pixels.
+    ref: watermelon.py:135, 447-456.  torchmetrics is neither vendored in /root/reference nor installed: parity unpinned.
+    Written with explicit separable sums in float64 so that it shares no code with the implementation under test."""
+    x, y = hat.double(), target.double()
+    rng = max((x.max() - x.min()).item(), (y.max() - y.min()).item())
+    c1, c2 = (k1 * rng) ** 2, (k2 * rng) ** 2
+    half = (kernel_size - 1) // 2
+    taps = [pow(2.718281828459045, -((d / sigma) ** 2) / 2) for d in range(-half, half + 1)]
+    taps = [t / sum(taps) for t in taps]
+
+    def reflect(t, dim):
+        n = t.shape[dim]
+        idx = [half - i for i in range(half)] + list(range(n)) + [n - 2 - i for i in range(half)]
+        return t.index_select(dim, torch.tensor(idx))
+
+    def window(t):
+        t = reflect(reflect(t, -1), -2)
+        h, w = t.shape[-2] - 2 * half, t.shape[-1] - 2 * half
+        rows = sum(taps[i] * t[..., i : i + h, :] for i in range(kernel_size))
+        return sum(taps[j] * rows[..., :, j : j + w] for j in range(kernel_size))
+
+    mx, my, sxx, syy, sxy = window(x), window(y), window(x * x), window(y * y), window(x * y)
+    vx, vy, cxy = sxx - mx * mx, syy - my * my, sxy - mx * my
+    s = ((2 * mx * my + c1) * (2 * cxy + c2)) / ((mx * mx + my * my + c1) * (vx + vy + c2))
+    return s[..., half:-half, half:-half].mean().float()

@@ -77,6 +77,8 @@ def import_reference():
         discriminator=m("watermelon_hologram.discriminator"),
         loss=m("watermelon_hologram.loss_func"),
         watermelon=m("watermelon_hologram.watermelon"),
+        rgbd2ap=m("watermelon_hologram.RGBD2AP"),
+        ap2poh=m("watermelon_hologram.AP2POH"),
     )
 
 
@@ -300,6 +302,90 @@ def golden_step(R):
     save("step_small.pt", out)
 
 
+def _assemble(R, rows, cols, pad, coef, stack, sdG, sdD):
+    """A reference ``watermelon`` object without ``__init__`` (which needs VGG19 weights + cuda)."""
+    W = object.__new__(R.watermelon.watermelon)
+    W.device = torch.device("cpu")
+    W.distance_stack, W.distance_num = stack, stack.size(0)
+    W.generator = R.generator.Generator(rows, cols, pad, coef, 3, PITCH, WL, torch.tensor([1e-3]))
+    W.generator.load_state_dict(sdG, strict=True)
+    W.discriminator = R.discriminator.WGANGPDiscriminator192(None, 32, False)
+    W.discriminator.load_state_dict(sdD, strict=True)
+    W.perceptual_loss = lambda a, b: torch.zeros(())  # VGG19 term: SURVEY §8f N1
+    W.propagator = R.asm.bandLimitedAngularSpectrumMethod_for_multiple_distances(
+        rows, cols, stack, pad, coef, PITCH, WL, False, False)
+    return W
+
+
+def golden_validate(R):
+    """The reference's own ``_validate_generator`` (watermelon.py:479-552) on one batch: eval-mode G and D over ALL planes
+    of the stack, the five loss terms and PSNR (SSIM is outside the fixture: torchmetrics is absent)."""
+    rows = cols = 32
+    pad, coef = 16, 0.45
+    stack = STACK20[:5]
+    sdG, sdD = seeded.generator_state_dict(), seeded.critic_state_dict()
+    W = _assemble(R, rows, cols, pad, coef, stack, sdG, sdD)
+    W.phs_gradient_loss_weight, W.perceptual_loss_weight, W.pixel_loss_weight = 1, 0.0, 1
+    W.TV_loss_weight, W.discriminator_loss_weight = 1e-3, 1e-1
+    W.PSNR_metric = R.watermelon.PSNR()
+    W.SSIM_metric = R.watermelon.SSIM()
+    batches = [seeded.smooth_batch(2, rows, cols, seed=21), seeded.smooth_batch(2, rows, cols, seed=22)]
+    v_losses, v_metrics = W._validate_generator(batches)
+    names = ("focal_phase_gradient_loss", "perceptual_loss", "pixel_loss", "TV_loss", "gan_loss", "G_loss", "D_loss")
+    save("validate_small.pt", dict(
+        args=(rows, cols, pad, coef), stack=stack.clone(), batches=batches, losses=dict(zip(names, v_losses.tolist())),
+        psnr=v_metrics[0].item(),
+        consts=dict(H_fixed=W.generator.part2.propagator.H.clone(), H_stack=W.propagator.H.clone(),
+                    mask=W.propagator.diffraction_limited_mask.clone())))
+
+
+def _weights_summary(post, pre):
+    return {k: dict(sum=v.double().sum().item(), norm=v.double().norm().item(), delta=(v.double() - pre[k].double()).norm().item())
+            for k, v in post.items()}
+
+
+def golden_pretrain(R):
+    """The reference's stand-alone pre-training loops (RGBD2AP.py:52-137, AP2POH.py:118-218), two epochs each on two
+    training batches and one validation batch.  ``ReduceLROnPlateau(verbose=True)`` no longer exists in this torch, so the
+    name is rebound in the reference modules to the same scheduler without that keyword."""
+    from torch.optim.lr_scheduler import ReduceLROnPlateau
+
+    def plateau(*a, verbose=None, **k):
+        return ReduceLROnPlateau(*a, **k)
+
+    R.rgbd2ap.ReduceLROnPlateau = plateau
+    R.ap2poh.ReduceLROnPlateau = plateau
+    rows = cols = 32
+    pad, coef = 16, 0.45
+    sdG = seeded.generator_state_dict()
+    sd1 = {k[len("part1."):]: v for k, v in sdG.items() if k.startswith("part1.")}
+    sd2 = {k[len("part2."):]: v for k, v in sdG.items() if k.startswith("part2.")}
+    train = [seeded.smooth_batch(2, rows, cols, seed=31), seeded.smooth_batch(2, rows, cols, seed=32)]
+    val = [seeded.smooth_batch(2, rows, cols, seed=33)]
+
+    torch.manual_seed(0)
+    m1 = R.rgbd2ap.RGBD2AP(input_shape=(1, 4, rows, cols), cuda=False)
+    m1.load_state_dict(sd1, strict=True)
+    m1.train_model(train, val, epochs=2, lr=1e-3, alpha=1e-3, hyperparameter_gamma=0.1, save_path=None)
+    post1 = {k: v.clone() for k, v in m1.state_dict().items()}
+    out = dict(args=(rows, cols, pad, coef), train=train, val=val,
+               rgbd2ap=dict(train_loss=list(m1.train_loss), test_loss=list(m1.test_loss), post=_weights_summary(post1, sd1),
+                            post_small={k: v for k, v in post1.items() if "final_layer" in k}))
+
+    m2 = R.ap2poh.AP2POH(input_shape=(1, 6, rows, cols), cuda=False, pad_size=pad, filter_radius_coefficient=coef,
+                         pixel_pitch=PITCH, wave_length=WL, distance=torch.tensor([1e-3]), kernel_size=3)
+    m2.load_state_dict(sd2, strict=True)
+    ap = lambda b: (b[1], b[2] * 6.0)  # noqa: E731  (amplitude, phase in radians)
+    m2.train_model([ap(b) for b in train], [ap(b) for b in val], filter_radius_coefficient=coef, epochs=2, lr=1e-3, alpha=1e-3,
+                   beta=1e-5, hyperparameter_gamma=0.1, save_path=None)
+    post2 = {k: v.clone() for k, v in m2.state_dict().items()}
+    filt = m2.dataloader_filter(train[0][1], train[0][2] * 6.0, coef)
+    out["ap2poh"] = dict(train_loss=list(m2.train_loss), test_loss=list(m2.test_loss), post=post2,
+                         filtered_amp=filt[0].clone(), filtered_phs=filt[1].clone(),
+                         consts=dict(H_fixed=m2.propagator.H.clone(), mask=m2.propagator.diffraction_limited_mask.clone()))
+    save("pretrain_small.pt", out)
+
+
 def copy_known_answer():
     """The reference's only result-pinning artefact: data files, copied as data."""
     src = os.path.join(REF, "output", "test_output", "terminalTest")
@@ -315,10 +401,16 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     torch.set_num_threads(max(1, (os.cpu_count() or 2) // 2))
     R = import_reference()
-    for fn in (golden_constants, golden_asm, golden_losses, golden_critic, golden_unet_generator, golden_step):
+    every = (golden_constants, golden_asm, golden_losses, golden_critic, golden_unet_generator, golden_step, golden_validate,
+             golden_pretrain)
+    only = set(sys.argv[1:])  # e.g. `python oracle/make_golden.py golden_validate` regenerates one fixture
+    for fn in every:
+        if only and fn.__name__ not in only:
+            continue
         print(fn.__name__)
         fn(R)
-    copy_known_answer()
+    if not only:
+        copy_known_answer()
 
 
 if __name__ == "__main__":

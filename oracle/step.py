@@ -130,3 +130,24 @@ def train_step(st: TrainState, rgbd, target_amp, target_phs, w: LossWeights, pla
     out["target_amps"] = target_amps.detach()
     out["PSNR"] = float(losses.psnr(hat_amps.detach(), target_amps.detach()))
     return out
+
+
+# --------------------------------------------------------------------------- A14
+def validate(st: TrainState, batches, w: LossWeights):
+    """``_validate_generator``: eval-mode G and D (running BN statistics), every sample propagated to every plane of the
+    stack, loss terms and PSNR / SSIM averaged over the batches.  ref: watermelon.py:479-552."""
+    sums = {k: 0.0 for k in ("focal_phase_gradient_loss", "pixel_loss", "TV_loss", "gan_loss", "G_loss", "PSNR", "SSIM")}
+    with torch.no_grad():
+        for rgbd, target_amp, target_phs in batches:
+            poh = nets.generator(st.sd_G, st.o, st.H_fixed, rgbd, False)
+            G = torch.cat((optics.poh_to_filtered_spectrum(st.o, st.H_fixed, poh),
+                           optics.target_to_filtered_spectrum(st.o, target_amp, target_phs)), 0)
+            amps, phss = optics.spectrum_to_planes_all(st.o, st.H_stack, G)
+            n = rgbd.size(0) * st.H_stack.size(0)
+            adversarial = -nets.critic(st.sd_D, amps[:n], False).mean()
+            terms = generator_loss(amps[:n], amps[n:], phss[:n], phss[n:], adversarial, w)
+            for k, v in terms.items():
+                sums[k] += v.item()
+            sums["PSNR"] += losses.psnr(amps[:n], amps[n:]).item()
+            sums["SSIM"] += losses.ssim(amps[:n], amps[n:]).item()
+    return {k: v / max(len(batches), 1) for k, v in sums.items()}
