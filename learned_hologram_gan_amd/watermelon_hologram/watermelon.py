@@ -223,6 +223,8 @@ class watermelon:
         metrics_last = torch.zeros(2, device=self.device)
         n_train = n_batch = n_batch_last = 0
         for epoch in range(epoch_num):
+            if hasattr(data_loader_train, "set_epoch"):
+                data_loader_train.set_epoch(epoch)  # per-rank shards reshuffle every epoch
             self.generator.train()
             self.discriminator.train()
             for n_batch_in_epoch, (RGBD, target_amp, target_phs) in enumerate(data_loader_train):

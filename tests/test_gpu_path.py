@@ -630,3 +630,30 @@ def test_pretraining_loops_against_reference(golden):
     assert all(abs(a - b) < 2e-4 * b for a, b in zip(m2.train_loss + m2.test_loss, ref["train_loss"] + ref["test_loss"]))
     for k, v in ref["post"].items():
         assert rel_err(m2.state_dict()[k].cpu(), v) < 2e-3, k
+
+
+# ----------------------------------------------------------------------------- N3: input pipeline
+def test_prefetch_loader_delivers_dataset_batches_on_device(tmp_path):
+    """Pinned staging + async copies on a side stream give the same batches as indexing the dataset (the reference's path)."""
+    import numpy as np
+
+    from learned_hologram_gan_amd.watermelon_hologram.data_loader import PrefetchLoader, dataloaderImgDepthAmpPhs
+
+    N, C, H, W = 37, 3, 48, 64
+    rng = np.random.default_rng(1)
+    paths = {}
+    for k in ("img", "depth", "amp", "phs"):
+        paths[k] = str(tmp_path / f"{k}.bin")
+        rng.random((N, C, H, W), dtype=np.float32).tofile(paths[k])
+    ds = dataloaderImgDepthAmpPhs(paths["img"], paths["depth"], paths["amp"], paths["phs"], N, C, H, W, cuda=True)
+    loader = PrefetchLoader(ds, batch_size=4, shuffle=False, drop_last=False, depth=2)
+    seen = 0
+    for epoch in range(2):
+        i = 0
+        for rgbd, amp, phs in loader:
+            assert rgbd.is_cuda and rgbd.shape[1] == 4
+            want = [torch.stack(t) for t in zip(*(ds[j] for j in range(i, min(i + 4, N))))]
+            assert torch.equal(rgbd, want[0]) and torch.equal(amp, want[1]) and torch.equal(phs, want[2])
+            i += rgbd.shape[0]
+            seen += rgbd.shape[0]
+    assert seen == 2 * N

@@ -205,3 +205,61 @@ def test_metrics_two_restatements_agree():
     y = (x + 0.1 * torch.rand((3, 3, 32, 48), generator=g)).clamp(0, 1.3)
     assert abs(ssim(x, y).item() - losses.ssim(x, y).item()) < 1e-5
     assert abs(psnr(x, y).item() - losses.psnr(x, y).item()) < 1e-5
+
+
+def _bin_dataset(tmp_path, N=11, C=3, H=8, W=8):
+    import numpy as np
+
+    from learned_hologram_gan_amd.watermelon_hologram.data_loader import dataloaderImgDepthAmpPhs
+
+    rng = np.random.default_rng(0)
+    paths = {}
+    for k in ("img", "depth", "amp", "phs"):
+        paths[k] = str(tmp_path / f"{k}.bin")
+        rng.random((N, C, H, W), dtype=np.float32).tofile(paths[k])
+    return dataloaderImgDepthAmpPhs(paths["img"], paths["depth"], paths["amp"], paths["phs"], N, C, H, W, cuda=False), paths
+
+
+def _same(ref, got):
+    return len(ref) == len(got) and all(torch.equal(a, b) for r, g in zip(ref, got) for a, b in zip(r, g))
+
+
+def test_prefetch_loader_visits_samples_in_dataloader_order(tmp_path):
+    """N3: batches of PrefetchLoader == batches of the reference's DataLoader (same global RNG state), incl. the ragged tail."""
+    from torch.utils.data import DataLoader
+
+    from learned_hologram_gan_amd.watermelon_hologram.data_loader import PrefetchLoader, dataloaderAmpPIPhs
+
+    ds, paths = _bin_dataset(tmp_path)
+    for shuffle, drop in ((False, False), (True, True), (True, False)):
+        torch.manual_seed(5)
+        ref = list(DataLoader(ds, batch_size=4, shuffle=shuffle, drop_last=drop))
+        torch.manual_seed(5)
+        loader = PrefetchLoader(ds, 4, shuffle=shuffle, drop_last=drop)
+        got = list(loader)
+        assert _same(ref, got) and len(loader) == len(ref)
+    assert tuple(got[-1][0].shape) == (3, 4, 8, 8)  # RGB + depth channel 0
+    ds2 = dataloaderAmpPIPhs(paths["amp"], paths["phs"], 11, 3, 8, 8, cuda=False)
+    assert _same(list(DataLoader(ds2, batch_size=3)), list(PrefetchLoader(ds2, 3)))
+    with pytest.raises(IndexError):
+        ds[11]
+
+
+def test_prefetch_loader_shards_like_distributed_sampler(tmp_path):
+    from torch.utils.data import DataLoader
+    from torch.utils.data.distributed import DistributedSampler
+
+    from learned_hologram_gan_amd.watermelon_hologram.data_loader import PrefetchLoader
+
+    ds, _ = _bin_dataset(tmp_path)
+    seen = []
+    for rank in range(2):
+        sampler = DistributedSampler(ds, 2, rank, shuffle=True, seed=7)
+        sampler.set_epoch(3)
+        ref = list(DataLoader(ds, batch_size=2, sampler=sampler, drop_last=True))
+        loader = PrefetchLoader(ds, 2, shuffle=True, drop_last=True, rank=rank, world=2, seed=7)
+        loader.set_epoch(3)
+        got = list(loader)
+        assert _same(ref, got)
+        seen += [tuple(row.flatten()[:4].tolist()) for b in got for row in b[1]]
+    assert len(seen) == 12 and len(set(seen)) == 11  # disjoint shards; 11 samples padded to 12 by wrapping around

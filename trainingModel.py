@@ -39,7 +39,7 @@ def check_and_create_folder(path):
 
 def train_gan(a):
     from learned_hologram_gan_amd import distributed, utilities
-    from learned_hologram_gan_amd.watermelon_hologram.data_loader import dataloaderImgDepthAmpPhs
+    from learned_hologram_gan_amd.watermelon_hologram.data_loader import PrefetchLoader, dataloaderImgDepthAmpPhs
     from learned_hologram_gan_amd.watermelon_hologram.watermelon import watermelon_without_GAN as watermelon  # as shipped (trainingModel.py:4)
 
     rank, world, _ = distributed.init_from_env()
@@ -51,10 +51,10 @@ def train_gan(a):
                                         samplesNum=n, channlesNum=a.channlesNum, height=a.height, width=a.width, cuda=True)
 
     train_set, val_set = dataset("train", a.samplesNum), dataset("validate", 100)
-    sampler = torch.utils.data.distributed.DistributedSampler(train_set, world, rank, shuffle=True) if world > 1 else None
-    train_loader = torch.utils.data.DataLoader(train_set, batch_size=a.batch_size, shuffle=sampler is None, sampler=sampler,
-                                               num_workers=0, drop_last=True)
-    val_loader = torch.utils.data.DataLoader(val_set, batch_size=max(1, a.batch_size // 2), shuffle=False, num_workers=0)
+    # same batches as DataLoader(shuffle=True, drop_last=True) [+ DistributedSampler per rank], gathered into pinned memory by a
+    # background thread and copied asynchronously (ref: trainingModel.py:43-56 uses DataLoader(num_workers=0))
+    train_loader = PrefetchLoader(train_set, batch_size=a.batch_size, shuffle=True, drop_last=True, rank=rank, world=world, seed=0)
+    val_loader = PrefetchLoader(val_set, batch_size=max(1, a.batch_size // 2), shuffle=False)
 
     # The reference weighs a VGG19 perceptual term with 0.1 (trainingModel.py:78) using downloaded ImageNet weights; here the
     # weights must come from a local file ($LHG_VGG19_WEIGHTS), otherwise the term is switched off.
