@@ -55,6 +55,7 @@ struct GGParams {
   const float* res;
   int ldres, rows_pad, act, planar_out;
   float slope;
+  int xcd;  // 1: XCD-contiguous tile order (xcd_contiguous)
 };
 
 struct WGParams {
@@ -63,7 +64,27 @@ struct WGParams {
   const float* gout;  // [.., Co]  -> n
   float* slabs;       // [S][Tslabs][m_pad][n_pad]
   int m_pad, n_pad, Tslabs, kchunk;  // kchunk: pixels per split (multiple of 32)
+  int xcd;
 };
+
+// Workgroups are dealt round-robin over the 8 XCDs (linear id % 8 labels the XCD group), each XCD with a private 4 MiB L2.
+// Renumber them so that every XCD walks ONE contiguous range of the tile order: tiles that share input rows (the three rows of
+// a 3x3 gather), an A panel (all n-tiles of one m-tile) or a K slab (all tiles of one weight-gradient split) then meet in the
+// same L2 instead of being fetched once per XCD.  Bijective for any grid size; placement is a speed matter only.
+__device__ __forceinline__ unsigned xcd_contiguous(unsigned lin, unsigned total) {
+  constexpr unsigned XCDS = 8;
+  const unsigned x = lin % XCDS, j = lin / XCDS, q = total / XCDS, r = total % XCDS;
+  return x * q + (x < r ? x : r) + j;
+}
+
+struct Block3 { int x, y, z; };
+__device__ __forceinline__ Block3 xcd_block3(bool enabled) {
+  if (!enabled) return {(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
+  const unsigned gx = gridDim.x, gy = gridDim.y;
+  const unsigned v = xcd_contiguous(blockIdx.x + gx * (blockIdx.y + gy * blockIdx.z), gx * gy * gridDim.z);
+  const unsigned z = v / (gx * gy), rem = v - z * gx * gy;
+  return {(int)(rem % gx), (int)(rem / gx), (int)z};
+}
 
 __device__ __forceinline__ f32x16 mfma32(float a, float b, f32x16 c) {
   return __builtin_amdgcn_mfma_f32_32x32x2f32(a, b, c, 0, 0, 0);
@@ -86,7 +107,8 @@ __global__ __launch_bounds__(256, 2) void gg_kernel(const GGParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WGN, wn = wave % WGN;
   const int n_tiles = p.rows_pad / BN;
-  const int mt = blockIdx.x / n_tiles, nt = blockIdx.x - mt * n_tiles;
+  const int bid = p.xcd ? (int)xcd_contiguous(blockIdx.x, gridDim.x) : (int)blockIdx.x;
+  const int mt = bid / n_tiles, nt = bid - mt * n_tiles;
   const int ghw = g.gh * g.gw;
 
   // per-thread gather rows
@@ -226,9 +248,10 @@ __global__ __launch_bounds__(256, 2) void wg_kernel(const WGParams p) {
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int n_tiles = p.n_pad / WG_TILE;
-  const int mt = blockIdx.x / n_tiles, nt = blockIdx.x - mt * n_tiles;
-  const int t = blockIdx.y;
-  const int split = blockIdx.z;
+  const Block3 blk = xcd_block3(p.xcd != 0);
+  const int mt = blk.x / n_tiles, nt = blk.x - mt * n_tiles;
+  const int t = blk.y;
+  const int split = blk.z;
   const int ghw = g.gh * g.gw;
   const int dy = g.dy[t], dx = g.dx[t];
 
@@ -394,9 +417,16 @@ struct ScopedKernelTime {
   }
 };
 
+// LHG_XCD=0 keeps the hardware's round-robin tile order (for A/B measurements of the L2 effect)
+static int xcd_order() {
+  static const int on = [] { const char* e = getenv("LHG_XCD"); return e ? atoi(e) != 0 : 1; }();
+  return on;
+}
+
 static int launch_gg(GGParams& p, hipStream_t st) {
   const Geom& g = p.g;
   if (g.M <= 0) return LHG_OK;
+  p.xcd = xcd_order();
   LHG_REQUIRE(g.Ci % BK == 0 && g.Ci > 0, "gather-GEMM: K channels (%d) must be a positive multiple of 32", g.Ci);
   LHG_REQUIRE(g.ldi % 4 == 0 && (reinterpret_cast<uintptr_t>(p.in) & 15) == 0, "gather-GEMM: input must be 16-byte aligned (ld %d)", g.ldi);
   LHG_REQUIRE((reinterpret_cast<uintptr_t>(p.wp) & 15) == 0, "gather-GEMM: packed weights must be 16-byte aligned");
@@ -474,6 +504,7 @@ static int launch_gg(GGParams& p, hipStream_t st) {
 
 static int launch_wg(WGParams& p, int S, hipStream_t st, const WG3Params* p3 = nullptr) {
   const Geom& g = p.g;
+  p.xcd = xcd_order();
   LHG_REQUIRE(g.ldi % 4 == 0 && g.ldo % 4 == 0 && g.Ci % 4 == 0 && g.Co % 4 == 0, "wgrad: channel counts / strides must be multiples of 4");
   LHG_REQUIRE((reinterpret_cast<uintptr_t>(p.in) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.gout) & 15) == 0, "wgrad: inputs must be 16-byte aligned");
   LHG_REQUIRE(p.m_pad % 64 == 0 && p.n_pad % 64 == 0 && p.m_pad >= g.Ci && p.n_pad >= g.Co, "wgrad: bad padded extents");
@@ -497,7 +528,12 @@ static int launch_wg(WGParams& p, int S, hipStream_t st, const WG3Params* p3 = n
       case 1: hipLaunchKernelGGL((wg2_kernel<128, 64>), grid(128, 64), dim3(256), 0, st, p, ib, gb); break;
       case 2: hipLaunchKernelGGL((wg2_kernel<64, 128>), grid(64, 128), dim3(256), 0, st, p, ib, gb); break;
       case 3: hipLaunchKernelGGL((wg2_kernel<64, 64>), grid(64, 64), dim3(256), 0, st, p, ib, gb); break;
-      case 5: hipLaunchKernelGGL(wg3_kernel, dim3((p.m_pad / 64) * (p.n_pad / 64), 1, S), dim3(256), 0, st, *p3, ib, gb); break;
+      case 5: {
+        WG3Params q3 = *p3;
+        q3.xcd = p.xcd;
+        hipLaunchKernelGGL(wg3_kernel, dim3((p.m_pad / 64) * (p.n_pad / 64), 1, S), dim3(256), 0, st, q3, ib, gb);
+        break;
+      }
       default: hipLaunchKernelGGL(wg_kernel, grid(64, 64), dim3(256), 0, st, p); break;
     }
   };
