@@ -106,6 +106,25 @@ int lhg_conv2d_backward_weight(const float* x, int N, int H, int W, int Ci, int 
                                const float* gy, int Co, int ldgy, int KH, int KW, int stride,
                                float* slabs, int S, int ci_pad, int co_pad, lhg_stream_t s);
 
+/* ---- thin convolutions: 3x3 (pad 1) or 1x1, stride 1, where one side has very few channels — the RGBD / RGB inputs
+ * (4 -> 64 neural_network_components.py:244-249, 3 -> 32 discriminator.py:16-19), the 64 -> 6 head (:288-291) and the
+ * 1024 -> 1 critic head (discriminator.py:41).  On an MFMA tile these are > 90 % padding; they run as direct fp32 FMA
+ * kernels bound by HBM instead.  `w` is the checkpoint OIHW tensor (Co, Ci, k, k) itself, no packed panel.
+ * lhg_conv2d_thin_supported: 0 = not a thin convolution (use the engine above), 1 = thin input (Ci <= 4, Co = 4*2^n <= 256),
+ * 2 = thin output (Co <= 8, Ci = 4*2^n <= 256 or 1024 with Co = 1; 5..8 output channels only for 1x1).
+ * Forward epilogue: v = act((acc + bias[c]) * scale[c] + shift[c]) (scale / shift only with a thin input); planar_out stores a
+ * thin output as (N, Co, H, W).  The three calls are closed under differentiation exactly like the engine above. */
+int lhg_conv2d_thin_supported(int Ci, int Co, int k, int stride);
+int lhg_conv2d_thin_forward(const float* x, int N, int H, int W, int Ci, int ldx, const float* w, int Co, int k,
+                            float* y, int ldy, const float* bias, const float* scale, const float* shift,
+                            int act, float slope, int planar_out, lhg_stream_t s);
+int lhg_conv2d_thin_backward_input(const float* gy, int N, int H, int W, int Co, int ldgy, const float* w, int Ci, int k,
+                                   float* gx, int ldgx, lhg_stream_t s);
+/* gw (Co, Ci, k, k) written in place (deterministic two-stage sum); ws >= lhg_conv2d_thin_wgrad_workspace bytes. */
+size_t lhg_conv2d_thin_wgrad_workspace(int N, int H, int W, int Ci, int Co, int k);
+int lhg_conv2d_thin_backward_weight(const float* x, int N, int H, int W, int Ci, int ldx, const float* gy, int Co, int ldgy,
+                                    int k, float* gw, float* ws, size_t ws_bytes, lhg_stream_t s);
+
 /* y = conv_transpose2d(x, W, kernel 2, stride 2).  ref: neural_network_components.py:270-286. */
 int lhg_conv_transpose2x2_forward(const float* x, int N, int H, int W, int Ci, int ldx,
                                   const float* wp, int rows_pad, float* y, int Co, int ldy,

@@ -86,6 +86,16 @@ class CatViewsFn(Function):
         return g[..., : ctx.ca], g[..., ctx.ca :], None
 
 
+def _as_nhwc_view(t):
+    """`t` itself when it already is an NHWC (sliced) view, else a dense copy (autograd hands out expanded gradients,
+    e.g. the all-ones gradient of ``.sum()``, with zero strides)."""
+    N, H, W, Cc = t.shape
+    s = t.stride()
+    ld = s[2] if W > 1 else (s[1] if H > 1 else max(Cc, s[2]))
+    ok = (Cc == 1 or s[3] == 1) and (W == 1 or s[2] == ld) and (H == 1 or s[1] == W * ld) and (N == 1 or s[0] == H * W * ld) and ld >= Cc
+    return t if ok else t.contiguous()
+
+
 def _dense(t):
     """Materialise a strided NHWC view as a dense tensor when a kernel needs ld == C."""
     return t if t.is_contiguous() else t.contiguous()
@@ -212,12 +222,42 @@ def _conv_out_hw(H, W, k, stride):
     return (H + 2 * p - k) // stride + 1, (W + 2 * p - k) // stride + 1
 
 
+_THIN_MODE = {}
+
+
+def thin_mode(Ci, Co, k, stride):
+    """0: MFMA gather-GEMM; 1 / 2: direct kernels of csrc/thin_conv.hip (thin input / thin output).  LHG_THIN=0 disables."""
+    key = (Ci, Co, k, stride)
+    if key not in _THIN_MODE:
+        import os
+
+        on = os.environ.get("LHG_THIN", "1") != "0"
+        _THIN_MODE[key] = int(native.load().lhg_conv2d_thin_supported(Ci, Co, k, stride)) if on else 0
+    return _THIN_MODE[key]
+
+
+def _raw_weight(w):
+    wd = w.detach()
+    return wd if wd.is_contiguous() else wd.contiguous()
+
+
 def conv2d_forward_raw(x, w, bias, stride, act=ACT_NONE, slope=0.0, scale=None, shift=None, res=None, out=None, planar=False):
     """y = act((conv(x, w) + bias) * scale + shift + res); no autograd."""
     px, N, H, W, Ci, ldx = nhwc(x)
     Co, Ciw, KH, KW = w.shape
-    if pad_to(Ciw, 32) != Ci:
+    if pad_to(Ciw, 32) != Ci and not (Ciw <= Ci and thin_mode(Ciw, Co, KH, stride)):
         raise ValueError(f"conv2d: input has {Ci} channels, weight expects {Ciw} (padded {pad_to(Ciw, 32)})")
+    mode = thin_mode(Ciw, Co, KH, stride) if KH == KW and res is None else 0
+    if mode and not (mode == 2 and (scale is not None or shift is not None)) and not (mode == 1 and planar):
+        if planar:
+            y = _resolve_out(out, (N, Co, H, W), x.device)
+            py, ldy = ptr(y), Co
+        else:
+            y = _resolve_out(out, (N, H, W, Co), x.device)
+            py, _, _, _, _, ldy = nhwc(y)
+        call("lhg_conv2d_thin_forward", px, N, H, W, Ciw, ldx, ptr(_raw_weight(w)), Co, KH, py, ldy, ptr(bias), ptr(scale), ptr(shift),
+             act, float(slope), int(planar), stream_ptr())
+        return y
     wp = pack_weight(w, True)
     Ho, Wo = _conv_out_hw(H, W, KH, stride)
     if planar:
@@ -280,9 +320,18 @@ class Conv2dInputGradFn(Function):
 
     @staticmethod
     def forward(ctx, gy, w, stride, H, W, Cx):
-        gyp = _padded_gy(gy)
         ctx.save_for_backward(gy, w)
         ctx.stride = stride
+        Co, Ci, KH, KW = w.shape
+        if KH == KW and gy.shape[-1] >= Co and thin_mode(Ci, Co, KH, stride):
+            gyv = _as_nhwc_view(gy)  # keep the (possibly temporary) dense copy alive until the launch
+            pg, N, _, _, _, ldg = nhwc(gyv)
+            gx = new_nhwc(N, H, W, Cx, gy.device)
+            if Cx > Ci:
+                gx[..., Ci:].zero_()
+            call("lhg_conv2d_thin_backward_input", pg, N, H, W, Co, ldg, ptr(_raw_weight(w)), Ci, KH, ptr(gx), Cx, stream_ptr())
+            return gx
+        gyp = _padded_gy(gy)
         pg, N, Ho, Wo, Cg, ldg = nhwc(gyp)
         Co, Ci, KH, KW = w.shape
         wp = pack_weight(w, False, 32)
@@ -315,6 +364,15 @@ class Conv2dWeightGradFn(Function):
         ctx.save_for_backward(x, gy)
         ctx.stride, ctx.wshape = stride, tuple(wshape)
         Co, Ci, KH, KW = wshape
+        if KH == KW and gy.shape[-1] >= Co and x.shape[-1] >= Ci and thin_mode(Ci, Co, KH, stride):
+            px, N, H, W, _, ldx = nhwc(x)
+            gyv = _as_nhwc_view(gy)
+            pg, _, _, _, _, ldg = nhwc(gyv)
+            nbytes = int(native.load().lhg_conv2d_thin_wgrad_workspace(N, H, W, Ci, Co, KH))
+            ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=x.device)
+            gw = torch.empty(ctx.wshape, dtype=torch.float32, device=x.device)
+            call("lhg_conv2d_thin_backward_weight", px, N, H, W, Ci, ldx, pg, Co, ldg, KH, ptr(gw), ptr(ws), nbytes, stream_ptr())
+            return gw
         gyp = _padded_gy(gy, 4)
         px, N, H, W, Cx, ldx = nhwc(x)
         pg, _, _, _, Cg, ldg = nhwc(gyp)
@@ -568,7 +626,7 @@ class SigmoidHeadFn(Function):
     def backward(ctx, gy):
         x, w, y = ctx.saved_tensors
         g_pre = gy * y * (1 - y)  # (N, Co, H, W): 6 planes, negligible
-        g_nhwc = ToNHWC.apply(g_pre, 32)
+        g_nhwc = ToNHWC.apply(g_pre, 8 if thin_mode(w.shape[1], w.shape[0], 1, 1) else 32)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = Conv2dInputGradFn.apply(g_nhwc, w, 1, x.shape[1], x.shape[2], x.shape[3])

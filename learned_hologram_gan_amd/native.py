@@ -45,6 +45,11 @@ _SIGNATURES = {
     "lhg_conv2d_backward_input": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p],
     "lhg_conv2d_wgrad_splits": [_i, _i, _i, _i, _i, _i, _i, _i],
     "lhg_conv2d_backward_weight": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _p],
+    "lhg_conv2d_thin_supported": [_i, _i, _i, _i],
+    "lhg_conv2d_thin_forward": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _i, _p, _p, _p, _i, _f, _i, _p],
+    "lhg_conv2d_thin_backward_input": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _i, _p],
+    "lhg_conv2d_thin_wgrad_workspace": [_i, _i, _i, _i, _i, _i],
+    "lhg_conv2d_thin_backward_weight": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _p, _p, _sz, _p],
     "lhg_conv_transpose2x2_forward": [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _i, _p, _p],
     "lhg_conv_transpose2x2_backward_input": [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _i, _p],
     "lhg_conv_transpose2x2_wgrad_splits": [_i, _i, _i, _i, _i],
@@ -72,7 +77,7 @@ _SIGNATURES = {
     "lhg_recon_loss_backward": [_p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p],
     "lhg_adam_step": [_p, _p, _p, _p, _ll, _f, _f, _f, _f, _i, _p],
 }
-_RESTYPE = {"lhg_last_error": C.c_char_p}
+_RESTYPE = {"lhg_last_error": C.c_char_p, "lhg_conv2d_thin_wgrad_workspace": C.c_size_t}
 
 _lib = None
 

@@ -47,10 +47,8 @@ class ResidualBlock(nn.Module):
         c1, c2, c3 = self.convolution_layer_1, self.convolution_layer_2, self.convolution_layer_3
         b1, b2 = self.batch_norm_layer_1, self.batch_norm_layer_2
         if self.training:
-            if self.in_channels <= 4 and self.strides == 1:  # thin first layer: taps packed along K, then a 1x1 GEMM
-                y = ops.Conv2dFn.apply(ops.Im2Col4Fn.apply(x), ops.thin3x3_weight_as_1x1(c1.weight), c1.bias, 1, "feeds_bn")
-            else:
-                y = ops.Conv2dFn.apply(x, c1.weight, c1.bias, self.strides, "feeds_bn")
+            # (the RGBD first layer, 4 -> 64, is routed to the direct thin-convolution kernels inside the op)
+            y = ops.Conv2dFn.apply(x, c1.weight, c1.bias, self.strides, "feeds_bn")
             y = ops.BatchNormTrainFn.apply(y, b1.weight, b1.bias, b1.running_mean, b1.running_var, None, ACT_RELU, 0.0, None)
             y = ops.Conv2dFn.apply(y, c2.weight, c2.bias, 1, "feeds_bn")
             skip = ops.Conv2dFn.apply(x, c3.weight, c3.bias, self.strides, None) if c3 is not None else x
@@ -62,10 +60,7 @@ class ResidualBlock(nn.Module):
         with torch.no_grad():
             s1, t1 = _bn_eval_affine(b1)
             s2, t2 = _bn_eval_affine(b2)
-            if self.in_channels <= 4 and self.strides == 1:
-                y = ops.conv2d_forward_raw(ops.Im2Col4Fn.apply(x), ops.thin3x3_weight_as_1x1(c1.weight), c1.bias, 1, act=ACT_RELU, scale=s1, shift=t1)
-            else:
-                y = ops.conv2d_forward_raw(x, c1.weight, c1.bias, self.strides, act=ACT_RELU, scale=s1, shift=t1)
+            y = ops.conv2d_forward_raw(x, c1.weight, c1.bias, self.strides, act=ACT_RELU, scale=s1, shift=t1)
             skip = ops.conv2d_forward_raw(x, c3.weight, c3.bias, self.strides) if c3 is not None else x
             return ops.conv2d_forward_raw(y, c2.weight, c2.bias, 1, act=ACT_RELU, scale=s2, shift=t2, res=skip, out=out)
 

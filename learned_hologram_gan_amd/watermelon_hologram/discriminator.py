@@ -37,8 +37,8 @@ class WGANGPDiscriminator192(nn.Module):
         h = ops.ToNHWC.apply(x, 32)
         c1 = self.block1[0]
         if self.training:
-            # thin first layer (3 -> 32, 3x3): taps packed along K by im2col4, then a 1x1 GEMM with the fused LeakyReLU
-            h = ops.ConvBiasActFn.apply(ops.Im2Col4Fn.apply(h), ops.thin3x3_weight_as_1x1(c1.weight), c1.bias, 1, ACT_LEAKY, 0.2)
+            # thin first layer (3 -> 32) and thin head (1024 -> 1): direct kernels (csrc/thin_conv.hip), LeakyReLU fused
+            h = ops.ConvBiasActFn.apply(h, c1.weight, c1.bias, 1, ACT_LEAKY, 0.2)
             for blk in (self.block2, self.block3, self.block4, self.block5, self.block6):
                 conv, bn = blk[0], blk[1]
                 y = ops.Conv2dFn.apply(h, conv.weight, conv.bias, conv.stride[0], "feeds_bn")
@@ -47,7 +47,7 @@ class WGANGPDiscriminator192(nn.Module):
             s = ops.Conv2dFn.apply(h, self.conv.weight, self.conv.bias, 1, None)
         else:
             with torch.no_grad():
-                h = ops.conv2d_forward_raw(ops.Im2Col4Fn.apply(h), ops.thin3x3_weight_as_1x1(c1.weight), c1.bias, 1, act=ACT_LEAKY, slope=0.2)
+                h = ops.conv2d_forward_raw(h, c1.weight, c1.bias, 1, act=ACT_LEAKY, slope=0.2)
                 for blk in (self.block2, self.block3, self.block4, self.block5, self.block6):
                     conv, bn = blk[0], blk[1]
                     sc, sh = ops.batch_norm_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var)

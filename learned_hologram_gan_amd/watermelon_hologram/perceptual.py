@@ -71,10 +71,8 @@ class perceptualLoss(nn.Module):
         for name, layer in self.net._modules.items():
             idx = int(name)
             if isinstance(layer, nn.Conv2d):
-                if layer.in_channels <= 4:  # first layer: taps packed along K (im2col4), then a 1x1 GEMM
-                    h = ops.ConvBiasActFn.apply(ops.Im2Col4Fn.apply(h), ops.thin3x3_weight_as_1x1(layer.weight), layer.bias, 1, ACT_RELU, 0.0)
-                else:
-                    h = ops.ConvBiasActFn.apply(h, layer.weight, layer.bias, 1, ACT_RELU, 0.0)  # conv + the following ReLU, fused
+                # conv + the following ReLU, fused (the 3 -> 64 first layer takes the thin-convolution kernels inside the op)
+                h = ops.ConvBiasActFn.apply(h, layer.weight, layer.bias, 1, ACT_RELU, 0.0)
             elif isinstance(layer, nn.MaxPool2d):
                 h = ops.MaxPool2x2Fn.apply(h)
             # nn.ReLU entries are fused into the conv epilogue; a tap index names the ReLU's output

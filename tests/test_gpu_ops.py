@@ -54,6 +54,15 @@ CONV_CASES = [
     (3, 256, 128, 8, 8, 1, 1),     # 1x1
     (4, 64, 64, 96, 96, 3, 1),     # enough blocks for the 256x64 tile path
     (2, 128, 128, 64, 64, 3, 1),   # 128x128 tile path
+    # thin convolutions (csrc/thin_conv.hip): ragged widths, every (taps, thin, wide) kernel instance
+    (2, 4, 64, 15, 37, 1, 1),      # thin input 1x1
+    (2, 3, 32, 17, 23, 3, 1),      # thin input, 3 real channels of a 32-padded tensor
+    (2, 64, 6, 13, 29, 1, 1),      # thin output, 6 channels
+    (1, 1024, 1, 7, 5, 3, 1),      # thin output, 4 chunks per lane
+    (2, 64, 1, 11, 9, 3, 1),       # one output channel, 16 lanes per pixel
+    (2, 1, 64, 9, 14, 3, 1),       # one input channel
+    (1, 2, 8, 6, 70, 3, 1),        # two lanes per pixel, 32 pixels per wave
+    (3, 256, 4, 5, 6, 3, 1),       # 64 lanes per pixel
 ]
 
 
@@ -99,6 +108,52 @@ def test_thin_first_layer_via_im2col4(ops, Ci, Co):
     (yg * to_nhwc(proj)).sum().backward()
     assert rel_err(to_nchw(xg.grad, Ci), xr.grad) < TOL and xg.grad[..., 4:].abs().max() == 0
     assert rel_err(wg.grad.cpu(), wr.grad) < 5e-5 and rel_err(bg.grad.cpu(), br.grad) < 5e-5
+
+
+def test_thin_conv_epilogues(ops):
+    """Thin-input conv with bias / folded-BN affine / activation, and the planar sigmoid head (thin output)."""
+    N, H, W = 2, 11, 19
+    x, w, b = rnd(N, 4, H, W, seed=1), rnd(64, 4, 3, 3, seed=2, scale=0.2), rnd(64, seed=3)
+    sc, sh = rnd(64, seed=4) + 1.5, rnd(64, seed=5)
+    assert ops.thin_mode(4, 64, 3, 1) == 1 and ops.thin_mode(64, 6, 1, 1) == 2 and ops.thin_mode(64, 64, 3, 1) == 0
+    ref = F.relu((F.conv2d(x, w, b, padding=1) * sc.view(1, -1, 1, 1) + sh.view(1, -1, 1, 1)))
+    y = ops.conv2d_forward_raw(to_nhwc(x, 32), w.to(DEV), b.to(DEV), 1, act=ops.ACT_RELU, scale=sc.to(DEV), shift=sh.to(DEV))
+    assert rel_err(to_nchw(y), ref) < TOL
+    x2, w2, b2 = rnd(N, 64, H, W, seed=6), rnd(6, 64, 1, 1, seed=7, scale=0.2), rnd(6, seed=8)
+    ref2 = torch.sigmoid(F.conv2d(x2, w2, b2))
+    y2 = ops.conv2d_forward_raw(to_nhwc(x2), w2.to(DEV), b2.to(DEV), 1, act=ops.ACT_SIGMOID, planar=True)
+    assert y2.shape == (N, 6, H, W) and rel_err(y2.cpu(), ref2) < TOL
+
+
+def test_thin_conv_double_backward(ops):
+    """Gradient-penalty pattern through a thin-input conv and a thin-output conv: d/dw of || d sum(y) / d x ||^2."""
+    N, H, W = 2, 10, 12
+    x = rnd(N, 3, H, W, seed=1)
+    w1, b1 = rnd(32, 3, 3, 3, seed=2, scale=0.3), rnd(32, seed=3, scale=0.1)
+    w2, b2 = rnd(1, 32, 3, 3, seed=4, scale=0.1), rnd(1, seed=5, scale=0.1)
+
+    def penalty(conv1, conv2, xin):
+        s = conv2(F.leaky_relu(conv1(xin), 0.2)) if conv1.__name__ == "ref1" else conv2(conv1(xin))
+        (g,) = torch.autograd.grad(s.sum(), xin, create_graph=True)
+        return (g * g).sum()
+
+    xr = x.clone().requires_grad_(True)
+    pr = [t.clone().requires_grad_(True) for t in (w1, b1, w2, b2)]
+
+    def ref1(t):
+        return F.conv2d(t, pr[0], pr[1], padding=1)
+
+    penalty(ref1, lambda t: F.conv2d(t, pr[2], pr[3], padding=1), xr).backward()
+
+    xg = to_nhwc(x, 32).requires_grad_(True)
+    pg = [t.to(DEV).requires_grad_(True) for t in (w1, b1, w2, b2)]
+
+    def hip1(t):
+        return ops.ConvBiasActFn.apply(t, pg[0], pg[1], 1, ops.ACT_LEAKY, 0.2)
+
+    penalty(hip1, lambda t: ops.Conv2dFn.apply(t, pg[2], pg[3], 1, None), xg).backward()
+    assert rel_err(pg[0].grad.cpu(), pr[0].grad) < 1e-4 and rel_err(pg[2].grad.cpu(), pr[2].grad) < 1e-4
+    assert rel_err(to_nchw(xg.grad, 3), xr.grad) < 1e-4
 
 
 def test_conv2d_fused_epilogue(ops):
