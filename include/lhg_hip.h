@@ -63,12 +63,6 @@ int lhg_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, i
 /* NHWC (first C of ld channels) -> NCHW.  Adjoint of the above. */
 int lhg_nhwc_to_nchw(const float* src, int ld, float* dst, int N, int C, int H, int W, lhg_stream_t s);
 
-/* Thin first layers (Cin <= 4; 3x3, stride 1, pad 1): col[p][t*4 + c] = x[p + off_t][c], 64 channels per pixel
- * (36 used), so that the convolution becomes a 1x1 GEMM with K = 64; lhg_col2im4 is the adjoint (gx has ldo channels,
- * the first 4 carry the gradient).  ref: first convs of neural_network_components.py:247-249 / discriminator.py:16-19. */
-int lhg_im2col4(const float* x, int N, int H, int W, int ldx, float* col, lhg_stream_t s);
-int lhg_col2im4(const float* gcol, int ldc, int N, int H, int W, float* gx, int ldo, lhg_stream_t s);
-
 /* Pack a PyTorch 4-D weight w[D0][D1][KH][KW] into GEMM panels dst[KH*KW][rows_pad][k_pad],
  * K contiguous, zero padded.  rows_from_d0 = 1: rows = D0, K = D1 (Conv2d forward,
  * ConvTranspose2d dgrad);  0: rows = D1, K = D0 (Conv2d dgrad, ConvTranspose2d forward).

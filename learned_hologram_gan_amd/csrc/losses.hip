@@ -76,22 +76,27 @@ __global__ __launch_bounds__(256) void recon_loss_fwd_kernel(const float* __rest
 }
 
 // sums[9] (double-accumulated) and losses[3] = (focal, pixel, tv)
-__global__ void recon_loss_final_kernel(const float* __restrict__ partial, int nblk, int planes, int H, int W, float* __restrict__ sums,
-                                        float* __restrict__ losses) {
+__global__ __launch_bounds__(64 * NRED) void recon_loss_final_kernel(const float* __restrict__ partial, int nblk, int planes, int H, int W,
+                                                                      float* __restrict__ sums, float* __restrict__ losses) {
+  // wave k reduces quantity k over the partial blocks: 64 strided lanes, then a fixed-order xor tree
   __shared__ double s[NRED];
-  const int k = threadIdx.x;
-  if (k < NRED) {
-    const bool is_max = (k == 1 || k == 3);
-    double v = 0;
-    for (int b = 0; b < nblk; ++b) {
-      const double p = partial[(size_t)b * NRED + k];
-      v = is_max ? (p > v ? p : v) : v + p;
-    }
+  const int k = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  const bool is_max = (k == 1 || k == 3);
+  double v = 0;
+  for (int b = lane; b < nblk; b += 64) {
+    const double q = partial[(size_t)b * NRED + k];
+    v = is_max ? (q > v ? q : v) : v + q;
+  }
+  for (int m = 32; m >= 1; m >>= 1) {
+    const double o = __shfl_xor(v, m, 64);
+    v = is_max ? (o > v ? o : v) : v + o;
+  }
+  if (lane == 0) {
     s[k] = v;
     sums[k] = (float)v;
   }
   __syncthreads();
-  if (k == 0) {
+  if (threadIdx.x == 0) {
     const double n_w = 2.0 * planes * H * (W - 1), n_h = 2.0 * planes * (H - 1) * W;  // sin and cos channels
     const double a_w = (double)planes * H * (W - 1), a_h = (double)planes * (H - 1) * W, n = (double)planes * H * W;
     losses[0] = (float)(s[0] / (n_w * s[1]) + s[2] / (n_h * s[3]));  // NaN when hat == target, as in the reference
@@ -154,7 +159,7 @@ int lhg_recon_loss_forward(const float* hat_amp, const float* tgt_amp, const flo
   LHG_REQUIRE(planes > 0 && H > 1 && W > 1, "recon_loss_forward: bad extents");
   const int nblk = loss_blocks((size_t)planes * H * W);
   hipLaunchKernelGGL(recon_loss_fwd_kernel, dim3(nblk), dim3(256), 0, as_stream(s), hat_amp, tgt_amp, hat_phs, tgt_phs, planes, H, W, ws);
-  hipLaunchKernelGGL(recon_loss_final_kernel, dim3(1), dim3(64), 0, as_stream(s), ws, nblk, planes, H, W, sums9, losses3);
+  hipLaunchKernelGGL(recon_loss_final_kernel, dim3(1), dim3(64 * NRED), 0, as_stream(s), ws, nblk, planes, H, W, sums9, losses3);
   return check_launch("recon_loss_forward");
 }
 

@@ -274,48 +274,6 @@ __global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, int ld, float
   }
 }
 
-// ------------------------------------------------------------------ thin first layers (Cin <= 4, 3x3, stride 1, pad 1)
-// col[p][t*4 + c] = x[p + off_t][c] (zero outside the image), t = kh*3 + kw, c < 4; channels 36..63 are zero.
-// The 4->64 / 3->32 3x3 convolutions then run as ordinary 1x1 GEMMs with K = 64 instead of nine K-steps of 32
-// mostly-zero channels (8x less MFMA work).
-__global__ __launch_bounds__(256) void im2col4_kernel(const float* __restrict__ x, int N, int H, int W, int ldx, float* __restrict__ col) {
-  const size_t total = (size_t)N * H * W * 16;  // 16 float4 per pixel
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int t = (int)(i & 15);
-    const size_t pix = i >> 4;
-    f32x4 v = {0.f, 0.f, 0.f, 0.f};
-    if (t < 9) {
-      const int xx = (int)(pix % W) + (t % 3) - 1, yy = (int)((pix / W) % H) + (t / 3) - 1;
-      if ((unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H) {
-        const size_t n = pix / ((size_t)W * H);
-        v = ld4(x + ((n * H + yy) * W + xx) * (size_t)ldx);
-      }
-    }
-    st4(col + pix * 64 + t * 4, v);
-  }
-}
-
-// adjoint: gx[p][c] = sum_t gcol[p - off_t][t*4 + c]; channels 4..ldo-1 of gx are zero-filled.
-__global__ __launch_bounds__(256) void col2im4_kernel(const float* __restrict__ gcol, int ldc, int N, int H, int W, float* __restrict__ gx, int ldo) {
-  const int C4 = ldo / 4;
-  const size_t total = (size_t)N * H * W * C4;
-  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
-    const int q = (int)(i % C4);
-    const size_t pix = i / C4;
-    f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-    if (q == 0) {
-      const int x0 = (int)(pix % W), y0 = (int)((pix / W) % H);
-      const size_t n = pix / ((size_t)W * H);
-#pragma unroll
-      for (int t = 0; t < 9; ++t) {
-        const int xx = x0 - ((t % 3) - 1), yy = y0 - ((t / 3) - 1);
-        if ((unsigned)xx < (unsigned)W && (unsigned)yy < (unsigned)H) acc += ld4(gcol + ((n * H + yy) * W + xx) * (size_t)ldc + t * 4);
-      }
-    }
-    st4(gx + pix * ldo + q * 4, acc);
-  }
-}
-
 // ------------------------------------------------------------------ max pool 2x2
 __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, int N, int H, int W, int C, int ldx,
                                                           float* __restrict__ y, int ldy) {
@@ -438,20 +396,6 @@ int lhg_nhwc_to_nchw(const float* src, int ld, float* dst, int N, int C, int H, 
   const size_t total = (size_t)N * C * H * W;
   hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, as_stream(s), src, ld, dst, N, C, H * W);
   return check_launch("nhwc_to_nchw");
-}
-
-int lhg_im2col4(const float* x, int N, int H, int W, int ldx, float* col, lhg_stream_t s) {
-  LHG_REQUIRE(ldx % 4 == 0 && ldx >= 4 && aligned16(x) && aligned16(col), "im2col4: input needs >= 4 channels, 16-byte aligned");
-  const size_t total = (size_t)N * H * W * 16;
-  hipLaunchKernelGGL(im2col4_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, as_stream(s), x, N, H, W, ldx, col);
-  return check_launch("im2col4");
-}
-
-int lhg_col2im4(const float* gcol, int ldc, int N, int H, int W, float* gx, int ldo, lhg_stream_t s) {
-  LHG_REQUIRE(ldc >= 36 && ldc % 4 == 0 && ldo % 4 == 0 && ldo >= 4 && aligned16(gcol) && aligned16(gx), "col2im4: bad strides");
-  const size_t total = (size_t)N * H * W * (ldo / 4);
-  hipLaunchKernelGGL(col2im4_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, as_stream(s), gcol, ldc, N, H, W, gx, ldo);
-  return check_launch("col2im4");
 }
 
 int lhg_channel_sum(const float* x, long long pixels, int C, int ld, float* out, float* ws, lhg_stream_t s) {

@@ -171,51 +171,6 @@ class ToNCHW(Function):
         return ToNHWC.apply(g, ctx.Cx), None
 
 
-# --------------------------------------------------------------------------- thin first layers (Cin <= 4)
-class Im2Col4Fn(Function):
-    """(N,H,W,ld>=4) -> (N,H,W,64): the nine 3x3 taps of the first 4 channels side by side (zero padded)."""
-
-    @staticmethod
-    def forward(ctx, x):
-        px, N, H, W, Cc, ldx = nhwc(x)
-        ctx.Cc = Cc
-        col = new_nhwc(N, H, W, 64, x.device)
-        call("lhg_im2col4", px, N, H, W, ldx, ptr(col), stream_ptr())
-        return col
-
-    @staticmethod
-    def backward(ctx, g):
-        return Col2Im4Fn.apply(g, ctx.Cc)
-
-
-class Col2Im4Fn(Function):
-    @staticmethod
-    def forward(ctx, gcol, Cc):
-        pg, N, H, W, _, ldc = nhwc(gcol)
-        gx = new_nhwc(N, H, W, Cc, gcol.device)
-        call("lhg_col2im4", pg, ldc, N, H, W, ptr(gx), Cc, stream_ptr())
-        return gx
-
-    @staticmethod
-    def backward(ctx, gg):
-        return Im2Col4Fn.apply(gg), None
-
-
-def thin3x3_weight_as_1x1(w):
-    """OIHW (Co, Ci<=4, 3, 3) -> (Co, 64, 1, 1) with k = (kh*3 + kw)*4 + ci (differentiable tensor ops on a tiny tensor)."""
-    Co, Ci = w.shape[0], w.shape[1]
-    wk = torch.zeros((Co, 9, 4), dtype=w.dtype, device=w.device)
-    wk = torch.cat((w.permute(0, 2, 3, 1).reshape(Co, 9, Ci), wk[:, :, Ci:]), dim=2)
-    out = torch.cat((wk.reshape(Co, 36), torch.zeros((Co, 28), dtype=w.dtype, device=w.device)), dim=1).reshape(Co, 64, 1, 1)
-    out._lhg_true_k = 9 * Ci  # algorithmic-FLOP accounting counts the real taps x channels, not the zero padding
-    return out
-
-
-def _true_k(w):
-    """Real reduction length per output of a conv weight (taps x input channels)."""
-    return getattr(w, "_lhg_true_k", w.shape[1] * w.shape[2] * w.shape[3])
-
-
 # --------------------------------------------------------------------------- convolution family
 def _conv_out_hw(H, W, k, stride):
     p = k // 2
@@ -269,7 +224,7 @@ def conv2d_forward_raw(x, w, bias, stride, act=ACT_NONE, slope=0.0, scale=None, 
     pres, ldres = (None, 0)
     if res is not None:
         pres, _, _, _, _, ldres = nhwc(res)
-    native.count_flops(0, 2.0 * N * Ho * Wo * Co * _true_k(w))
+    native.count_flops(0, 2.0 * N * Ho * Wo * Co * (w.shape[1] * w.shape[2] * w.shape[3]))
     call("lhg_conv2d_forward", px, N, H, W, Ci, ldx, ptr(wp), wp.shape[1], KH, KW, stride, py, Co, ldy,
          ptr(bias), ptr(scale), ptr(shift), pres, ldres, act, float(slope), int(planar), stream_ptr())
     return y
@@ -341,7 +296,7 @@ class Conv2dInputGradFn(Function):
         if Cx > Ci:
             gx[..., Ci:].zero_()
         pgx, _, _, _, _, ldgx = nhwc(gx)
-        native.count_flops(0, 2.0 * N * Ho * Wo * Co * _true_k(w))
+        native.count_flops(0, 2.0 * N * Ho * Wo * Co * (w.shape[1] * w.shape[2] * w.shape[3]))
         call("lhg_conv2d_backward_input", pg, N, H, W, Cg, ldg, ptr(wp), wp.shape[1], KH, KW, stride, pgx, Ci, ldgx, stream_ptr())
         return gx
 

@@ -90,26 +90,6 @@ def test_conv2d_forward_and_gradients(ops, case):
     assert rel_err(bg.grad.cpu(), br.grad) < 5e-5
 
 
-@pytest.mark.parametrize("Ci,Co", [(4, 64), (3, 32)])
-def test_thin_first_layer_via_im2col4(ops, Ci, Co):
-    """3x3 conv with <= 4 input channels computed as im2col4 + 1x1 GEMM; gradients through col2im4."""
-    N, H, W = 2, 14, 18
-    x, w, b = rnd(N, Ci, H, W, seed=1), rnd(Co, Ci, 3, 3, seed=2, scale=0.2), rnd(Co, seed=3, scale=0.1)
-    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
-    yr = F.conv2d(xr, wr, br, padding=1)
-    proj = rnd(*yr.shape, seed=4)
-    (yr * proj).sum().backward()
-    xg = to_nhwc(x, 32).requires_grad_(True)
-    wg, bg = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
-    col = ops.Im2Col4Fn.apply(xg)
-    assert col.shape == (N, H, W, 64) and col[..., 36:].abs().max() == 0
-    yg = ops.Conv2dFn.apply(col, ops.thin3x3_weight_as_1x1(wg), bg, 1, None)
-    assert rel_err(to_nchw(yg), yr.detach()) < TOL
-    (yg * to_nhwc(proj)).sum().backward()
-    assert rel_err(to_nchw(xg.grad, Ci), xr.grad) < TOL and xg.grad[..., 4:].abs().max() == 0
-    assert rel_err(wg.grad.cpu(), wr.grad) < 5e-5 and rel_err(bg.grad.cpu(), br.grad) < 5e-5
-
-
 def test_thin_conv_epilogues(ops):
     """Thin-input conv with bias / folded-BN affine / activation, and the planar sigmoid head (thin output)."""
     N, H, W = 2, 11, 19
