@@ -48,6 +48,9 @@ def parse():
     ap.add_argument("--cpu-baseline", type=int, default=1, help="0 skips the CPU oracle timing")
     ap.add_argument("--cpu-rows", type=int, default=0, help="frame size of the CPU sample (0 = same as --rows)")
     ap.add_argument("--graph", type=int, default=0, help="infer mode: replay a captured hipGraph instead of eager launches")
+    ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
+                    help="f32 (the benchmark metric): exact fp32 MFMA.  bf16 (BASELINE configs[2]/[4], informational): conv GEMM operands "
+                         "rounded to bf16, fp32 accumulation, fp32 tensors")
     ap.add_argument("--mode", choices=("train", "infer"), default="train",
                     help="train: the GAN step (the benchmark metric); infer: eval-mode generator forward RGBD->POH only (informational)")
     return ap.parse_args()
@@ -79,6 +82,8 @@ def main():
     from learned_hologram_gan_amd import distributed, native
     from learned_hologram_gan_amd.watermelon_hologram.watermelon import watermelon
 
+    from learned_hologram_gan_amd import hip_ops
+
     rank, world, local = distributed.init_from_env()
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
@@ -87,6 +92,10 @@ def main():
     dev = torch.device("cuda", local)
     torch.manual_seed(122731 + rank)
 
+    if args.dtype == "bf16":
+        hip_ops.set_conv_precision("bf16")
+    bf16 = args.dtype == "bf16"
+    mfma_peak = 2500.0 if bf16 else FP32_MFMA_PEAK_TFLOPS  # dense bf16 MFMA peak (MI355X_MICROARCH.md) / fp32 MFMA peak
     stack = torch.linspace(-4e-4, 0.0, 21)[:-1]  # trainingModel.py:62
     W = watermelon(filter_radius_coefficient=0.45, pad_size=args.pad, distance_stack=stack, input_shape=(1, 4, args.rows, args.cols))
     W.generator.to(dev).train()
@@ -125,7 +134,7 @@ def main():
             print(json.dumps({"metric": "RGBD->POH inference frames/sec (eval-mode generator forward, informational)",
                               "value": round(B * world * args.steps / dt, 3), "unit": "frames/s", "n_gpus": world, "steps": args.steps,
                               "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
-                              "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                              "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                               "config": {"workload": f"{args.rows}x{args.cols}x3 bs={B} generator forward (UNet + ASM back-propagation + POH encode)"
                                                      + (", hipGraph replay" if args.graph else "")}}))
         return
@@ -164,15 +173,17 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": "f32",
+            "dtype": args.dtype,
             "data": "synthetic random RGBD / target amplitude+phase in [0,1), reference-style random-init weights",
             "config": {"workload": f"{args.rows}x{args.cols}x3 bs={B}/GPU generator+critic train step (d_ratio={args.d_ratio}, "
-                                   f"lambda_gp=10, pad {args.pad} -> {args.rows + 2 * args.pad}^2 FFTs, 20-plane stack, no VGG term), fp32",
+                                   f"lambda_gp=10, pad {args.pad} -> {args.rows + 2 * args.pad}^2 FFTs, 20-plane stack, no VGG term), "
+                                   + ("bf16 conv-GEMM operands, fp32 accumulation / tensors / FFT (informational)" if bf16 else "fp32"),
                        "global_batch": B * world, "parallelism": f"dp{world}"},
             "roofline": {
-                "kernel": "lhg::gg_kernel (MFMA fp32 gather-GEMM: conv forward / input-gradient / conv-transpose)",
-                "bound": "mfma", "achieved": round(achieved, 3), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": traffic,
+                "kernel": "lhg::gg2b_kernel (MFMA bf16 gather-GEMM)" if bf16 else
+                          "lhg::gg_kernel (MFMA fp32 gather-GEMM: conv forward / input-gradient / conv-transpose)",
+                "bound": "mfma", "achieved": round(achieved, 3), "peak": mfma_peak, "unit": "TFLOP/s",
+                "frac": round(achieved / mfma_peak, 4), "traffic": None if bf16 else traffic,
                 "algorithmic_flop_per_launch": round(gg["algorithmic_flops"] / max(gg["launches"], 1)),
                 "launches_per_step": gg["launches"] / args.steps,
                 "avg_launch_us": round(gg["total_ms"] * 1e3 / max(gg["launches"], 1), 2),
@@ -184,6 +195,8 @@ def main():
                                  "algorithmic_gflop_per_step": round(wg["algorithmic_flops"] / args.steps / 1e9, 2)},
             },
         }
+        if bf16:
+            out["metric"] += " [bf16 operand mode, informational]"
         if world == 1 and args.cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

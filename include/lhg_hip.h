@@ -39,6 +39,7 @@ enum {
 };
 
 enum { LHG_ACT_NONE = 0, LHG_ACT_RELU = 1, LHG_ACT_LEAKY = 2, LHG_ACT_SIGMOID = 3 };
+enum { LHG_PRECISION_F32 = 0, LHG_PRECISION_BF16 = 1 };
 
 typedef void* lhg_stream_t; /* hipStream_t */
 
@@ -62,6 +63,14 @@ int lhg_profile_read(int kernel, double* total_ms, long long* launches, double* 
 int lhg_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, int ld, lhg_stream_t s);
 /* NHWC (first C of ld channels) -> NCHW.  Adjoint of the above. */
 int lhg_nhwc_to_nchw(const float* src, int ld, float* dst, int N, int C, int H, int W, lhg_stream_t s);
+
+/* Operand precision of the gather-GEMM behind conv / conv-transpose forward and input-gradient (process-wide, default
+ * LHG_PRECISION_F32 = exact fp32 MFMA).  LHG_PRECISION_BF16 (BASELINE configs[2], [4]): tensors stay fp32 in memory, the GEMM
+ * rounds its operands to bf16 (nearest even) and accumulates in fp32 on v_mfma_f32_32x32x16_bf16; lhg_pack_weight then writes
+ * bf16 panels into `dst`, so panels must be re-packed after a mode change.  The weight-gradient GEMMs round x and gy the same
+ * way (lhg_conv2d_wgrad_splits depends on the mode).  Thin convolutions and every non-GEMM kernel are unaffected. */
+int lhg_set_conv_precision(int precision);
+int lhg_get_conv_precision(void);
 
 /* Pack a PyTorch 4-D weight w[D0][D1][KH][KW] into GEMM panels dst[KH*KW][rows_pad][k_pad],
  * K contiguous, zero padded.  rows_from_d0 = 1: rows = D0, K = D1 (Conv2d forward,

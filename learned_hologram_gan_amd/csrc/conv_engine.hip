@@ -235,6 +235,7 @@ __global__ __launch_bounds__(256, 2) void gg_kernel(const GGParams p) {
 }
 
 #include "gg2_kernel.inc"
+#include "gg2b_kernel.inc"
 
 // ------------------------------------------------------------------------------------ wg_kernel
 constexpr int WG_TILE = 64;
@@ -323,6 +324,7 @@ __global__ __launch_bounds__(256, 2) void wg_kernel(const WGParams p) {
 }
 
 #include "wg2_kernel.inc"
+#include "wg2b_kernel.inc"
 #include "wg3_kernel.inc"
 
 // ------------------------------------------------------------------------------------ small kernels
@@ -340,6 +342,23 @@ __global__ void pack_weight_kernel(const float* __restrict__ w, int D0, int D1, 
       v = w[((size_t)d0 * D1 + d1) * T + t];
     }
     dst[i] = v;
+  }
+}
+
+__global__ void pack_weight_bf16_kernel(const float* __restrict__ w, int D0, int D1, int T, int rows_from_d0,
+                                        __bf16* __restrict__ dst, int rows_pad, int k_pad) {
+  const size_t total = (size_t)T * rows_pad * k_pad;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i % k_pad);
+    const int row = (int)((i / k_pad) % rows_pad);
+    const int t = (int)(i / ((size_t)k_pad * rows_pad));
+    const int rows = rows_from_d0 ? D0 : D1, K = rows_from_d0 ? D1 : D0;
+    float v = 0.f;
+    if (row < rows && k < K) {
+      const int d0 = rows_from_d0 ? row : k, d1 = rows_from_d0 ? k : row;
+      v = w[((size_t)d0 * D1 + d1) * T + t];
+    }
+    dst[i] = (__bf16)v;  // round to nearest even
   }
 }
 
@@ -423,10 +442,16 @@ static int xcd_order() {
   return on;
 }
 
+// process-wide operand precision of the gather-GEMM (lhg_set_conv_precision); weight gradients always run in fp32
+static int g_precision = LHG_PRECISION_F32;
+
+static int launch_gg_bf16(GGParams& p, hipStream_t st);
+
 static int launch_gg(GGParams& p, hipStream_t st) {
   const Geom& g = p.g;
   if (g.M <= 0) return LHG_OK;
   p.xcd = xcd_order();
+  if (g_precision == LHG_PRECISION_BF16) return launch_gg_bf16(p, st);
   LHG_REQUIRE(g.Ci % BK == 0 && g.Ci > 0, "gather-GEMM: K channels (%d) must be a positive multiple of 32", g.Ci);
   LHG_REQUIRE(g.ldi % 4 == 0 && (reinterpret_cast<uintptr_t>(p.in) & 15) == 0, "gather-GEMM: input must be 16-byte aligned (ld %d)", g.ldi);
   LHG_REQUIRE((reinterpret_cast<uintptr_t>(p.wp) & 15) == 0, "gather-GEMM: packed weights must be 16-byte aligned");
@@ -502,6 +527,68 @@ static int launch_gg(GGParams& p, hipStream_t st) {
   return check_launch("gg_kernel");
 }
 
+// bf16 operands: `p.wp` holds bf16 panels (lhg_pack_weight in the same mode).  Tilings 128x128 / 128x64 / 64x64, autotuned.
+static int launch_gg_bf16(GGParams& p, hipStream_t st) {
+  const Geom& g = p.g;
+  LHG_REQUIRE(g.Ci % BK == 0 && g.Ci > 0, "gather-GEMM: K channels (%d) must be a positive multiple of 32", g.Ci);
+  LHG_REQUIRE(g.ldi % 4 == 0 && (reinterpret_cast<uintptr_t>(p.in) & 15) == 0, "gather-GEMM: input must be 16-byte aligned (ld %d)", g.ldi);
+  LHG_REQUIRE((reinterpret_cast<uintptr_t>(p.wp) & 15) == 0, "gather-GEMM: packed weights must be 16-byte aligned");
+  LHG_REQUIRE(p.rows_pad % 64 == 0 && p.rows_pad >= g.Co, "gather-GEMM: rows_pad %d must be a multiple of 64 covering Co=%d", p.rows_pad, g.Co);
+  int max_ws = 0;
+  for (int t = 0; t < g.T; ++t) max_ws = std::max(max_ws, g.ws[t]);
+  const unsigned long long in_bytes = (((unsigned long long)g.N * g.Hi * g.Wi - 1) * g.ldi + g.Ci) * 4ull;
+  const unsigned long long wp_bytes = (unsigned long long)(max_ws + 1) * p.rows_pad * g.Ci * 2ull;
+  LHG_REQUIRE(in_bytes < (1ull << 32) - 64 && wp_bytes < (1ull << 32) - 64, "gather-GEMM (bf16 mode): tensors of 4 GiB and more are not supported");
+  const unsigned ib = (unsigned)in_bytes, wb = (unsigned)wp_bytes;
+  auto blocks = [&](int bm, int bn) { return (unsigned)(((g.M + bm - 1) / bm) * (p.rows_pad / bn)); };
+  const bool n128 = p.rows_pad % 128 == 0;
+  constexpr int NV = 3;
+  auto valid = [&](int v) { return v == 0 ? n128 : true; };
+  auto run = [&](int v) {
+    switch (v) {
+      case 0: hipLaunchKernelGGL((gg2b_kernel<128, 128, 2, 2>), dim3(blocks(128, 128)), dim3(256), 0, st, p, ib, wb); break;
+      case 1: hipLaunchKernelGGL((gg2b_kernel<128, 64, 2, 2>), dim3(blocks(128, 64)), dim3(256), 0, st, p, ib, wb); break;
+      default: hipLaunchKernelGGL((gg2b_kernel<64, 64, 2, 2>), dim3(blocks(64, 64)), dim3(256), 0, st, p, ib, wb); break;
+    }
+  };
+  static const int forced = [] { const char* e = getenv("LHG_GGB_VARIANT"); return e ? atoi(e) : -1; }();
+  int choice = (forced >= 0 && forced < NV && valid(forced)) ? forced : -1;
+  if (choice < 0 && g_autotune_enabled) {
+    const std::array<int, 12> key = {g.M, p.rows_pad, g.Ci, g.Co, g.T, g.istep, g.ostep, g.Hi, g.Wi, g.ldi, g.ldo, p.planar_out + 2};
+    auto it = g_gg_choice.find(key);
+    if (it != g_gg_choice.end()) {
+      choice = it->second;
+    } else {
+      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+      if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {
+        hipEvent_t e0, e1;
+        (void)hipEventCreate(&e0);
+        (void)hipEventCreate(&e1);
+        float best = 1e30f;
+        for (int v = 0; v < NV; ++v) {
+          if (!valid(v)) continue;
+          run(v);
+          (void)hipEventRecord(e0, st);
+          run(v);
+          run(v);
+          (void)hipEventRecord(e1, st);
+          if (hipEventSynchronize(e1) != hipSuccess || hipGetLastError() != hipSuccess) continue;
+          float ms = 0;
+          (void)hipEventElapsedTime(&ms, e0, e1);
+          if (ms < best) { best = ms; choice = v; }
+        }
+        (void)hipEventDestroy(e0);
+        (void)hipEventDestroy(e1);
+        if (choice >= 0) g_gg_choice[key] = choice;
+      }
+    }
+  }
+  if (choice < 0) choice = n128 && blocks(128, 128) >= 256 ? 0 : (blocks(128, 64) >= 256 ? 1 : 2);
+  ScopedKernelTime timed(0, st, 2.0 * g.M * (double)p.rows_pad * g.Ci * g.T);
+  run(choice);
+  return check_launch("gg2b_kernel");
+}
+
 static int launch_wg(WGParams& p, int S, hipStream_t st, const WG3Params* p3 = nullptr) {
   const Geom& g = p.g;
   p.xcd = xcd_order();
@@ -516,9 +603,13 @@ static int launch_wg(WGParams& p, int S, hipStream_t st, const WG3Params* p3 = n
   const bool small = in_bytes < (1ull << 32) - 64 && go_bytes < (1ull << 32) - 64;
   const unsigned ib = (unsigned)in_bytes, gb = (unsigned)go_bytes;
   const bool m128 = p.m_pad % 128 == 0, n128 = p.n_pad % 128 == 0;
-  constexpr int NV = 6;  // 5: nine-tap fused kernel for 3x3 stride 1
+  constexpr int NV = 10;  // 5: nine-tap fused kernel for 3x3 stride 1; 6..9: bf16-operand kernels (lhg_set_conv_precision)
+  const bool bf16 = g_precision == LHG_PRECISION_BF16;
+  if (bf16) LHG_REQUIRE(small, "wgrad (bf16 mode): tensors of 4 GiB and more are not supported");
   auto valid = [&](int v) {
-    if (v == 5) return small && p3 != nullptr;
+    if (bf16) return v >= 6 && (v == 6 ? m128 && n128 : v == 7 ? m128 : v == 8 ? n128 : true);
+    if (v >= 6) return false;
+    if (v == 5) return p3 != nullptr && small;
     return v == 4 || (small && (v == 0 ? m128 && n128 : v == 1 ? m128 : v == 2 ? n128 : true));
   };
   auto run = [&](int v) {
@@ -534,6 +625,10 @@ static int launch_wg(WGParams& p, int S, hipStream_t st, const WG3Params* p3 = n
         hipLaunchKernelGGL(wg3_kernel, dim3((p.m_pad / 64) * (p.n_pad / 64), 1, S), dim3(256), 0, st, q3, ib, gb);
         break;
       }
+      case 6: hipLaunchKernelGGL((wg2b_kernel<128, 128>), grid(128, 128), dim3(256), 0, st, p, ib, gb); break;
+      case 7: hipLaunchKernelGGL((wg2b_kernel<128, 64>), grid(128, 64), dim3(256), 0, st, p, ib, gb); break;
+      case 8: hipLaunchKernelGGL((wg2b_kernel<64, 128>), grid(64, 128), dim3(256), 0, st, p, ib, gb); break;
+      case 9: hipLaunchKernelGGL((wg2b_kernel<64, 64>), grid(64, 64), dim3(256), 0, st, p, ib, gb); break;
       default: hipLaunchKernelGGL(wg_kernel, grid(64, 64), dim3(256), 0, st, p); break;
     }
   };
@@ -542,7 +637,7 @@ static int launch_wg(WGParams& p, int S, hipStream_t st, const WG3Params* p3 = n
   int choice = -1;
   if (forced >= 0 && forced < NV && valid(forced)) choice = forced;
   if (choice < 0 && tune && g_autotune_enabled) {
-    const std::array<int, 12> key = {g.M, p.m_pad, p.n_pad, g.T, S, g.istep, g.ostep, g.Hi, g.Wi, g.ldi, g.ldo, g.ws[0]};
+    const std::array<int, 12> key = {g.M, p.m_pad, p.n_pad, g.T, S, g.istep, g.ostep, g.Hi, g.Wi, g.ldi, g.ldo, g.ws[0] + 100 * g_precision};
     auto it = g_wg_choice.find(key);
     if (it != g_wg_choice.end()) {
       choice = it->second;
@@ -571,6 +666,7 @@ static int launch_wg(WGParams& p, int S, hipStream_t st, const WG3Params* p3 = n
       }
     }
   }
+  if (choice < 0 && bf16) choice = m128 && n128 && (p.m_pad / 128) * (p.n_pad / 128) * g.T * S >= 400 ? 6 : 9;
   if (choice < 0) choice = small ? (p3 ? 5 : (m128 && n128 && (p.m_pad / 128) * (p.n_pad / 128) * g.T * S >= 400 ? 0 : 3)) : 4;
   ScopedKernelTime timed(1, st, 2.0 * g.M * (double)p.m_pad * p.n_pad * g.T);
   run(choice);
@@ -653,9 +749,21 @@ int lhg_pack_weight(const float* w, int D0, int D1, int KH, int KW, int rows_fro
   LHG_REQUIRE(rows_pad >= rows && k_pad >= K && rows_pad % 64 == 0 && k_pad % 32 == 0, "pack_weight: bad padding (%d>=%d, %d>=%d)", rows_pad, rows, k_pad, K);
   const size_t total = (size_t)KH * KW * rows_pad * k_pad;
   const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
-  hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, as_stream(s), w, D0, D1, KH * KW, rows_from_d0, dst, rows_pad, k_pad);
+  if (g_precision == LHG_PRECISION_BF16)
+    hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3(blocks), dim3(256), 0, as_stream(s), w, D0, D1, KH * KW, rows_from_d0,
+                       reinterpret_cast<__bf16*>(dst), rows_pad, k_pad);
+  else
+    hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, as_stream(s), w, D0, D1, KH * KW, rows_from_d0, dst, rows_pad, k_pad);
   return check_launch("pack_weight");
 }
+
+int lhg_set_conv_precision(int precision) {
+  LHG_REQUIRE(precision == LHG_PRECISION_F32 || precision == LHG_PRECISION_BF16, "set_conv_precision: unknown precision %d", precision);
+  g_precision = precision;
+  return LHG_OK;
+}
+
+int lhg_get_conv_precision(void) { return g_precision; }
 
 int lhg_conv2d_forward(const float* x, int N, int H, int W, int Ci, int ldx, const float* wp, int rows_pad, int KH, int KW, int stride,
                        float* y, int Co, int ldy, const float* bias, const float* scale, const float* shift,
@@ -728,7 +836,7 @@ static void fused3x3_split(int N, int H, int W, int Ci, int Co, int& segs, int& 
 
 int lhg_conv2d_wgrad_splits(int N, int H, int W, int Ci, int Co, int KH, int KW, int stride) {
   const int Ho = (H + 2 * (KH / 2) - KH) / stride + 1, Wo = (W + 2 * (KW / 2) - KW) / stride + 1;
-  if (KH == 3 && KW == 3 && stride == 1) {
+  if (KH == 3 && KW == 3 && stride == 1 && g_precision == LHG_PRECISION_F32) {
     int segs, cps, rpc;
     fused3x3_split(N, H, W, Ci, Co, segs, cps, rpc);
     return N * segs * cps;
@@ -742,7 +850,7 @@ int lhg_conv2d_backward_weight(const float* x, int N, int H, int W, int Ci, int 
   WGParams p{};
   conv_fwd_geom(p.g, N, H, W, Ci, ldx, Co, ldgy, KH, KW, stride);
   p.in = x; p.gout = gy; p.slabs = slabs; p.m_pad = ci_pad; p.n_pad = co_pad; p.Tslabs = KH * KW;
-  if (KH == 3 && KW == 3 && stride == 1) {
+  if (KH == 3 && KW == 3 && stride == 1 && g_precision == LHG_PRECISION_F32) {
     WG3Params q{};
     fused3x3_split(N, H, W, Ci, Co, q.segs, q.cps, q.rpc);
     if (S == N * q.segs * q.cps && ci_pad == pad64(Ci) && co_pad == pad64(Co)) {

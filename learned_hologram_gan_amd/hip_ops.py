@@ -101,6 +101,24 @@ def _dense(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+# --------------------------------------------------------------------------- operand precision of the conv GEMMs
+_PRECISIONS = {"fp32": 0, "f32": 0, "bf16": 1}
+_precision = 0
+
+
+def set_conv_precision(name: str) -> None:
+    """"fp32" (default, exact fp32 MFMA) or "bf16" (bf16 operands, fp32 accumulation, fp32 tensors): see lhg_set_conv_precision."""
+    global _precision
+    if name not in _PRECISIONS:
+        raise ValueError(f"unknown precision {name!r} (fp32 | bf16)")
+    call("lhg_set_conv_precision", _PRECISIONS[name])
+    _precision = _PRECISIONS[name]
+
+
+def conv_precision() -> str:
+    return "bf16" if _precision else "fp32"
+
+
 # --------------------------------------------------------------------------- weight packing
 def pack_weight(w: torch.Tensor, rows_from_d0: bool, k_pad_to: int = 32) -> torch.Tensor:
     """OIHW / IOHW -> [KH*KW][rows_pad][k_pad] panels (lhg_pack_weight).
@@ -116,7 +134,7 @@ def pack_weight(w: torch.Tensor, rows_from_d0: bool, k_pad_to: int = 32) -> torc
         cache = w.__dict__.setdefault("_lhg_packed", {})
     except AttributeError:  # pragma: no cover
         cache = {}
-    hit = cache.get((rows_from_d0, k_pad))
+    hit = cache.get((rows_from_d0, k_pad, _precision))
     if hit is not None and hit[0] == stamp:
         return hit[1]
     wd = w.detach()
@@ -124,7 +142,7 @@ def pack_weight(w: torch.Tensor, rows_from_d0: bool, k_pad_to: int = 32) -> torc
         wd = wd.contiguous()
     out = torch.empty((KH * KW, rows_pad, k_pad), dtype=torch.float32, device=w.device)
     call("lhg_pack_weight", ptr(wd), D0, D1, KH, KW, int(rows_from_d0), ptr(out), rows_pad, k_pad, stream_ptr())
-    cache[(rows_from_d0, k_pad)] = (stamp, out)
+    cache[(rows_from_d0, k_pad, _precision)] = (stamp, out)
     return out
 
 

@@ -38,6 +38,8 @@ _SIGNATURES = {
     "lhg_profile_read": [_i, C.POINTER(C.c_double), C.POINTER(C.c_longlong), C.POINTER(C.c_double)],
     "lhg_nchw_to_nhwc": [_p, _p, _i, _i, _i, _i, _i, _p],
     "lhg_nhwc_to_nchw": [_p, _i, _p, _i, _i, _i, _i, _p],
+    "lhg_set_conv_precision": [_i],
+    "lhg_get_conv_precision": [],
     "lhg_pack_weight": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _p],
     "lhg_conv2d_forward": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _i, _i, _f, _i, _p],
     "lhg_conv2d_backward_input": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p],

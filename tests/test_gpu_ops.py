@@ -90,6 +90,39 @@ def test_conv2d_forward_and_gradients(ops, case):
     assert rel_err(bg.grad.cpu(), br.grad) < 5e-5
 
 
+@pytest.mark.parametrize("case", [(2, 64, 64, 24, 20, 3, 1), (1, 32, 128, 40, 40, 3, 1), (2, 128, 256, 16, 16, 3, 1), (2, 32, 64, 18, 22, 3, 2),
+                                  (3, 256, 128, 8, 8, 1, 1), (2, 128, 128, 64, 64, 3, 1)], ids=lambda c: "x".join(map(str, c)))
+def test_conv2d_bf16_operand_mode(ops, case):
+    """lhg_set_conv_precision(bf16): operands rounded to bf16 (nearest even), fp32 accumulation.  Checked against fp32 convs of the
+    bf16-ROUNDED operands (tight: only the summation order differs) and against the unrounded fp32 conv (loose: bf16 has 8 bits)."""
+    N, Ci, Co, H, W, k, stride = case
+    x = rnd(N, Ci, H, W, seed=1)
+    w = rnd(Co, Ci, k, k, seed=2, scale=(Ci * k * k) ** -0.5)
+    b = rnd(Co, seed=3, scale=0.1)
+    rb = lambda t: t.bfloat16().float()  # noqa: E731
+    y_exact = F.conv2d(x, w, b, stride=stride, padding=k // 2)
+    y_ref = F.conv2d(rb(x), rb(w), b, stride=stride, padding=k // 2)
+    proj = rnd(*y_ref.shape, seed=4)
+    gx_ref = torch.autograd.grad((F.conv2d(xr := rb(x).requires_grad_(True), rb(w), b, stride=stride, padding=k // 2) * rb(proj)).sum(), xr)[0]
+    ops.set_conv_precision("bf16")
+    try:
+        assert ops.conv_precision() == "bf16"
+        xg = to_nhwc(x).requires_grad_(True)
+        wg, bg = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+        yg = ops.Conv2dFn.apply(xg, wg, bg, stride, None)
+        assert rel_err(to_nchw(yg), y_ref) < TOL
+        assert rel_err(to_nchw(yg), y_exact) < 2e-2
+        (yg * to_nhwc(proj)).sum().backward()
+        assert rel_err(to_nchw(xg.grad), gx_ref) < TOL  # input gradient: gy and W rounded to bf16
+        wgrad_ref = torch.autograd.grad((F.conv2d(rb(x), wr := w.clone().requires_grad_(True), b, stride=stride, padding=k // 2) * rb(proj)).sum(), wr)[0]
+        assert rel_err(wg.grad.cpu(), wgrad_ref) < 5e-5  # weight gradient: x and gy rounded to bf16, fp32 accumulation
+    finally:
+        ops.set_conv_precision("fp32")
+    # back in fp32 mode the packed panels are fp32 again
+    y32 = ops.Conv2dFn.apply(to_nhwc(x), w.to(DEV), b.to(DEV), stride, None)
+    assert rel_err(to_nchw(y32), y_exact) < TOL
+
+
 def test_thin_conv_epilogues(ops):
     """Thin-input conv with bias / folded-BN affine / activation, and the planar sigmoid head (thin output)."""
     N, H, W = 2, 11, 19

@@ -657,3 +657,42 @@ def test_prefetch_loader_delivers_dataset_batches_on_device(tmp_path):
             i += rgbd.shape[0]
             seen += rgbd.shape[0]
     assert seen == 2 * N
+
+
+# ----------------------------------------------------------------------------- bf16 operand mode (BASELINE configs[2], [4])
+def test_bf16_mode_train_step_quality():
+    """bf16-operand conv GEMMs (fp32 accumulation, tensors, FFTs): the reconstruction of one training step stays within PSNR bounds of the
+    fp32 CPU oracle on identical inputs (BASELINE.json: 'recon PSNR vs ref'), and the mode switches back cleanly."""
+    from learned_hologram_gan_amd import hip_ops
+    from learned_hologram_gan_amd.watermelon_hologram.watermelon import watermelon
+
+    rows = cols = 64
+    pad, coef, ratio = 32, 0.45, 1
+    stack = torch.linspace(-4e-4, 0.0, 21)[:-1][:8]
+    rgbd, tamp, tphs = seeded.smooth_batch(2, rows, cols, seed=78)
+    idx = torch.tensor([5, 2])
+    alphas = [torch.tensor([0.3, 0.8]).view(2, 1, 1, 1)]
+    st = step.make_state(rows, cols, pad, coef, stack, seeded.generator_state_dict(), seeded.critic_state_dict())
+    ref = step.train_step(st, rgbd, tamp, tphs, step.LossWeights(d_ratio=ratio), idx, alphas)
+
+    def psnr(a, b):
+        return (10 * torch.log10((b.max() - b.min()) ** 2 / torch.mean((a - b) ** 2))).item()
+
+    hip_ops.set_conv_precision("bf16")
+    try:
+        W = watermelon(filter_radius_coefficient=coef, pad_size=pad, distance_stack=stack, input_shape=(1, 4, rows, cols))
+        W.generator.load_state_dict(seeded.generator_state_dict())
+        W.discriminator.load_state_dict(seeded.critic_state_dict())
+        W.generator.to(DEV).train()
+        W.discriminator.to(DEV).train()
+        W.configure(1, 0.0, 1, 1e-3, 0.1, 1e-3, 1e-3, ratio, 10)
+        out = W.train_step(rgbd.to(DEV), tamp.to(DEV), tphs.to(DEV), idx, [a.to(DEV) for a in alphas])
+    finally:
+        hip_ops.set_conv_precision("fp32")
+    p_amp = psnr(out["hat_amps"].cpu(), ref["hat_amps"])
+    p_poh = psnr(torch.cos(out["POH"].cpu()), torch.cos(ref["POH"]))
+    assert p_amp > 35.0 and p_poh > 30.0, (p_amp, p_poh)
+    assert rel_err(out["target_amps"].cpu(), ref["target_amps"]) < PARITY  # no conv GEMM on the target path
+    assert abs(out["G_loss"].item() - ref["G_loss"]) <= 5e-2 * abs(ref["G_loss"])
+    assert abs(out["D_loss"].item() - ref["D_loss"]) <= 1e-1 * abs(ref["D_loss"])
+    assert hip_ops.conv_precision() == "fp32"

@@ -1,11 +1,13 @@
 """Per-layer timing of the conv GEMM kernels at the benchmark shapes (B=4, 384x384).
-Usage (GPU box): python tools/bench_conv.py [reps]"""
+Usage (GPU box): python tools/bench_conv.py [reps] [fp32|bf16]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from learned_hologram_gan_amd import hip_ops as ops
 DEV = "cuda:0"
 reps = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+if len(sys.argv) > 2:
+    ops.set_conv_precision(sys.argv[2])  # "bf16": bf16 operands in the forward / input-gradient GEMMs
 B = 4
 # (name, Ci, Co, HW, k, stride)
 LAYERS = [("enc1.c1", 4, 64, 384, 3, 1), ("enc1.c2", 64, 64, 384, 3, 1), ("enc1.c3", 4, 64, 384, 1, 1),
