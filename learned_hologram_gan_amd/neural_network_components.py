@@ -29,6 +29,21 @@ def _warn_eval_grad(name):
                   "(the reference only evaluates under torch.no_grad())", stacklevel=3)
 
 
+_PENDING_COUNTERS: list = []
+
+
+def _count_batch(*bns):
+    """``num_batches_tracked += 1`` (nn.BatchNorm2d bookkeeping, checkpoint parity), batched: one multi-tensor launch per network
+    forward (``flush_batch_counters``) instead of one tiny kernel per BatchNorm layer."""
+    _PENDING_COUNTERS.extend(b.num_batches_tracked for b in bns)
+
+
+def flush_batch_counters():
+    if _PENDING_COUNTERS:
+        torch._foreach_add_(_PENDING_COUNTERS, 1)
+        _PENDING_COUNTERS.clear()
+
+
 class ResidualBlock(nn.Module):
     """relu(BN2(conv3x3(relu(BN1(conv3x3(X))))) + conv1x1(X)). ref: neural_network_components.py:6-32."""
 
@@ -52,8 +67,7 @@ class ResidualBlock(nn.Module):
             y = ops.BatchNormTrainFn.apply(y, b1.weight, b1.bias, b1.running_mean, b1.running_var, None, ACT_RELU, 0.0, None)
             y = ops.Conv2dFn.apply(y, c2.weight, c2.bias, 1, "feeds_bn")
             skip = ops.Conv2dFn.apply(x, c3.weight, c3.bias, self.strides, None) if c3 is not None else x
-            b1.num_batches_tracked += 1
-            b2.num_batches_tracked += 1
+            _count_batch(b1, b2)
             return ops.BatchNormTrainFn.apply(y, b2.weight, b2.bias, b2.running_mean, b2.running_var, skip, ACT_RELU, 0.0, out)
         if torch.is_grad_enabled() and (x.requires_grad or c1.weight.requires_grad):
             _warn_eval_grad("ResidualBlock")
@@ -66,7 +80,9 @@ class ResidualBlock(nn.Module):
 
     def forward(self, X):
         x = ops.ToNHWC.apply(X, ops.pad_to(X.shape[1], 32))
-        return ops.ToNCHW.apply(self.forward_nhwc(x), self.num_channels)
+        y = ops.ToNCHW.apply(self.forward_nhwc(x), self.num_channels)
+        flush_batch_counters()
+        return y
 
 
 class SymmetricConv2d(nn.Module):
@@ -180,6 +196,7 @@ class UNet(nn.Module):
         u = self._up(self.decoder3[1], d, OutSlot(buf4[..., 64:]))
         d = self._block(self.decoder4).forward_nhwc(self._cat(e1, u, buf4))
         head = self.final_layer[0]
+        flush_batch_counters()
         if self.training:
             return ops.SigmoidHeadFn.apply(d, head.weight, head.bias)
         with torch.no_grad():

@@ -7,6 +7,7 @@ from torch import nn
 
 from .. import hip_ops as ops
 from ..hip_ops import ACT_LEAKY
+from ..neural_network_components import _count_batch, flush_batch_counters
 
 
 class WGANGPDiscriminator192(nn.Module):
@@ -43,7 +44,8 @@ class WGANGPDiscriminator192(nn.Module):
                 conv, bn = blk[0], blk[1]
                 y = ops.Conv2dFn.apply(h, conv.weight, conv.bias, conv.stride[0], "feeds_bn")
                 h = ops.BatchNormTrainFn.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, None, ACT_LEAKY, 0.2, None)
-                bn.num_batches_tracked += 1
+                _count_batch(bn)
+            flush_batch_counters()
             s = ops.Conv2dFn.apply(h, self.conv.weight, self.conv.bias, 1, None)
         else:
             with torch.no_grad():
