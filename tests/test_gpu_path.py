@@ -696,3 +696,51 @@ def test_bf16_mode_train_step_quality():
     assert abs(out["G_loss"].item() - ref["G_loss"]) <= 5e-2 * abs(ref["G_loss"])
     assert abs(out["D_loss"].item() - ref["D_loss"]) <= 1e-1 * abs(ref["D_loss"])
     assert hip_ops.conv_precision() == "fp32"
+
+
+# ----------------------------------------------------------------------------- the two entry points, end to end through files
+def _write_bins(tmp_path, prefix, N, H, W, seed):
+    import numpy as np
+
+    rng = np.random.default_rng(seed)
+    paths = {}
+    for k in ("img", "depth", "amp", "phs"):
+        paths[k] = str(tmp_path / f"{prefix}_{k}.bin")
+        rng.random((N, 3, H, W), dtype=np.float32).tofile(paths[k])
+    return paths
+
+
+def test_training_and_generation_clis_end_to_end(tmp_path):
+    """trainingModel.py (reference flags, PrefetchLoader input pipeline, checkpoints + metrics JSON) and generatePOH.py --propagate
+    (checkpoint -> POH file -> PNG planes) on tiny synthetic .bin data sets."""
+    import json
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    import generatePOH
+    import trainingModel
+
+    H = W = 32
+    tr, va = _write_bins(tmp_path, "train", 8, H, W, 1), _write_bins(tmp_path, "val", 100, H, W, 2)
+    out = tmp_path / "out"
+    argv = []
+    for prefix, p in (("train", tr), ("validate", va)):
+        for k in ("img", "depth", "amp", "phs"):
+            argv += [f"--{prefix}_{k}_path", p[k]]
+    argv += ["--samplesNum", "8", "--channlesNum", "3", "--height", str(H), "--width", str(W), "--batch_size", "4", "--epoch_num", "1",
+             "--save_path_G", str(out / "G.pth"), "--save_path_D", str(out / "D.pth"), "--loss_metrics_file", str(out / "metrics.json"),
+             "--save_path_img", str(out / "img")]
+    trainingModel.train_gan(trainingModel.build_parser().parse_args(argv))
+    sd = torch.load(out / "G.pth", map_location="cpu")
+    assert len(sd) == len(seeded.generator_state_dict()) and all(torch.isfinite(v.float()).all() for v in sd.values())
+    assert (out / "G_epoch0.pth").exists() and isinstance(json.load(open(out / "metrics.json")), dict)
+
+    gen_args = generatePOH.build_parser().parse_args([
+        "--img_path", tr["img"], "--depth_path", tr["depth"], "--index", "3", "--model_path", str(out / "G.pth"),
+        "--poh_output_path", str(out / "poh.pt"), "--samplesNum", "8", "--sample_row_num", str(H), "--sample_col_num", str(W),
+        "--pad_size", "16", "--propagate", "--num_intervals", "3", "--output_image_dir", str(out / "planes")])
+    generatePOH.main(gen_args)
+    poh = torch.load(out / "poh.pt", map_location="cpu")
+    assert poh.shape == (3, H, W) and torch.isfinite(poh).all() and poh.abs().max() <= 1.5 * torch.pi + 1e-4
+    assert sorted(os.listdir(out / "planes")) == ["0.png", "1.png", "2.png"]
