@@ -106,6 +106,10 @@ class GradSynchronizer:
         if not self.enabled:
             return
         self._armed = False
+        if self.flat_grad.is_cuda:
+            from . import hip_ops
+
+            hip_ops.join_side_stream(self.flat_grad.device)  # conv weight gradients are accumulated on a side stream
         for b, done in enumerate(self._launched):
             if not done:
                 self._launch(b)

@@ -101,6 +101,56 @@ def _dense(t):
     return t if t.is_contiguous() else t.contiguous()
 
 
+# --------------------------------------------------------------------------- weight gradients on a side stream
+# The weight-gradient GEMMs are MFMA-bound and nothing in backward depends on them before the optimiser step, while the chain they
+# branch off (BN backward -> input-gradient -> BN backward ...) alternates MFMA-bound and HBM-bound kernels.  For parameters whose
+# gradient lives in a flat buffer (optim.FlatParams registers the slot), the weight gradient is therefore launched on a second HIP
+# stream and ACCUMULATED straight into the slot; autograd gets None for it.  The main stream's HBM-bound kernels then run under the
+# side stream's GEMMs.  join_side_stream() is the fence (optimiser step, gradient all-reduce).  LHG_SIDE_WGRAD=0 disables.
+import os as _os
+
+_GRAD_SLOTS: dict = {}
+_SIDE_STREAMS: dict = {}
+SIDE_WGRAD = _os.environ.get("LHG_SIDE_WGRAD", "1") != "0"
+
+
+def register_grad_slot(param: torch.Tensor, grad_view: torch.Tensor) -> None:
+    _GRAD_SLOTS[param.data_ptr()] = grad_view
+
+
+def unregister_grad_slots(params) -> None:
+    for p_ in params:
+        _GRAD_SLOTS.pop(p_.data_ptr(), None)
+
+
+def _side_stream(device):
+    key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
+    if key not in _SIDE_STREAMS:
+        _SIDE_STREAMS[key] = torch.cuda.Stream(key)
+    return _SIDE_STREAMS[key]
+
+
+def join_side_stream(device=None) -> None:
+    """Make the current stream wait for every weight gradient launched on the side stream so far."""
+    for key, st in _SIDE_STREAMS.items():
+        if device is None or torch.device(device).index in (None, key):
+            torch.cuda.current_stream(key).wait_stream(st)
+
+
+def _weight_grad(w, inputs, fn):
+    """fn() -> weight gradient from `inputs`.  Plain backward into a registered slot: run on the side stream, accumulate, return None."""
+    slot = _GRAD_SLOTS.get(w.data_ptr()) if (SIDE_WGRAD and not torch.is_grad_enabled()) else None
+    if slot is None or slot.shape != w.shape:
+        return fn()
+    main, side = torch.cuda.current_stream(w.device), _side_stream(w.device)
+    side.wait_stream(main)  # inputs (and the zeroed slot) are ready on the main stream
+    for t in inputs:
+        t.record_stream(side)  # keep their memory out of main-stream reuse until the side stream is done with it
+    with torch.cuda.stream(side):
+        slot.add_(fn())
+    return None
+
+
 # --------------------------------------------------------------------------- operand precision of the conv GEMMs
 _PRECISIONS = {"fp32": 0, "f32": 0, "bf16": 1}
 _precision = 0
@@ -282,7 +332,7 @@ class Conv2dFn(Function):
         if ctx.needs_input_grad[0]:
             gx = Conv2dInputGradFn.apply(gy, w, ctx.stride, x.shape[1], x.shape[2], x.shape[3])
         if ctx.needs_input_grad[1]:
-            gw = Conv2dWeightGradFn.apply(x, gy, w.shape, ctx.stride)
+            gw = _weight_grad(w, (x, gy), lambda: Conv2dWeightGradFn.apply(x, gy, w.shape, ctx.stride))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = torch.zeros(w.shape[0], dtype=torch.float32, device=w.device) if ctx.bias_grad_is_zero else channel_sum(gy)
         return gx, gw, gb, None, None
@@ -325,7 +375,7 @@ class Conv2dInputGradFn(Function):
         if ctx.needs_input_grad[0]:
             g_gy = Conv2dFn.apply(ggx, w, None, ctx.stride, None)
         if ctx.needs_input_grad[1]:
-            g_w = Conv2dWeightGradFn.apply(ggx, gy, w.shape, ctx.stride)
+            g_w = _weight_grad(w, (ggx, gy), lambda: Conv2dWeightGradFn.apply(ggx, gy, w.shape, ctx.stride))
         return g_gy, g_w, None, None, None, None
 
 
@@ -400,16 +450,19 @@ class ConvTranspose2x2Fn(Function):
             native.count_flops(0, 2.0 * N * (H2 // 2) * (W2 // 2) * 4 * Ci * Co)
             call("lhg_conv_transpose2x2_backward_input", pg, N, H2 // 2, W2 // 2, Cg, ldg, ptr(wp), wp.shape[1], pgx, Ci, ldgx, stream_ptr())
         if ctx.needs_input_grad[1]:
-            px, N, H, W, Cx, ldx = nhwc(x)
-            pg, _, _, _, Cg, ldg = nhwc(gy)
-            lib = native.load()
-            S = lib.lhg_conv_transpose2x2_wgrad_splits(N, H, W, Cx, Cg)
-            ci_pad, co_pad = pad_to(Cx, 64), pad_to(Cg, 64)
-            slabs = torch.empty((S, 4, ci_pad, co_pad), dtype=torch.float32, device=x.device)
-            native.count_flops(1, 2.0 * N * H * W * 4 * Ci * Co)
-            call("lhg_conv_transpose2x2_backward_weight", px, N, H, W, Cx, ldx, pg, Cg, ldg, ptr(slabs), S, ci_pad, co_pad, stream_ptr())
-            gw = torch.empty_like(w)
-            call("lhg_wgrad_reduce", ptr(slabs), S, 4, ci_pad, co_pad, ptr(gw), Ci, Co, 0, stream_ptr())
+            def wgrad():
+                px, N, H, W, Cx, ldx = nhwc(x)
+                pg, _, _, _, Cg, ldg = nhwc(gy)
+                S = native.load().lhg_conv_transpose2x2_wgrad_splits(N, H, W, Cx, Cg)
+                ci_pad, co_pad = pad_to(Cx, 64), pad_to(Cg, 64)
+                slabs = torch.empty((S, 4, ci_pad, co_pad), dtype=torch.float32, device=x.device)
+                native.count_flops(1, 2.0 * N * H * W * 4 * Ci * Co)
+                call("lhg_conv_transpose2x2_backward_weight", px, N, H, W, Cx, ldx, pg, Cg, ldg, ptr(slabs), S, ci_pad, co_pad, stream_ptr())
+                out = torch.empty(w.shape, dtype=torch.float32, device=x.device)
+                call("lhg_wgrad_reduce", ptr(slabs), S, 4, ci_pad, co_pad, ptr(out), Ci, Co, 0, stream_ptr())
+                return out
+
+            gw = _weight_grad(w, (x, gy), wgrad)
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = channel_sum(gy)
         return gx, gw, gb, None
@@ -476,7 +529,7 @@ class ConvBiasActFn(Function):
         if ctx.needs_input_grad[0]:
             gx = Conv2dInputGradFn.apply(g, w, ctx.stride, x.shape[1], x.shape[2], x.shape[3])
         if ctx.needs_input_grad[1]:
-            gw = Conv2dWeightGradFn.apply(x, g, w.shape, ctx.stride)
+            gw = _weight_grad(w, (x, g), lambda: Conv2dWeightGradFn.apply(x, g, w.shape, ctx.stride))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = channel_sum(g)
         return gx, gw, gb, None, None, None
@@ -604,7 +657,7 @@ class SigmoidHeadFn(Function):
         if ctx.needs_input_grad[0]:
             gx = Conv2dInputGradFn.apply(g_nhwc, w, 1, x.shape[1], x.shape[2], x.shape[3])
         if ctx.needs_input_grad[1]:
-            gw = Conv2dWeightGradFn.apply(x, g_nhwc, w.shape, 1)
+            gw = _weight_grad(w, (x, g_nhwc), lambda: Conv2dWeightGradFn.apply(x, g_nhwc, w.shape, 1))
         if ctx.needs_input_grad[2]:
             gb = g_pre.sum(dim=(0, 2, 3))
         return gx, gw, gb

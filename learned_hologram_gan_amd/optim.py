@@ -34,9 +34,13 @@ class FlatParams:
                 self.data[o:o + p.numel()].copy_(p.detach().reshape(-1))
                 p.data = self.data[o:o + p.numel()].view_as(p)
                 p.grad = self.grad[o:o + p.numel()].view_as(p)
+                if p.dim() == 4 and p.is_cuda:  # conv / conv-transpose weights: gradient GEMMs may write here from a side stream
+                    hip_ops.register_grad_slot(p, p.grad)
 
     def zero_grad(self):
         """Keep .grad bound to the flat buffer (set_to_none would drop the views)."""
+        if self.grad.is_cuda:
+            hip_ops.join_side_stream(self.grad.device)
         self.grad.zero_()
         for p, o in zip(self.params, self.offsets):
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:
@@ -61,6 +65,8 @@ class FusedAdam:
 
     def step(self):
         self.step_count += 1
+        if self.flat.grad.is_cuda:
+            hip_ops.join_side_stream(self.flat.grad.device)  # weight gradients accumulated on the side stream
         hip_ops.adam_step_(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1],
                            self.eps, self.step_count)
         for p in self.flat.params:
