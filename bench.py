@@ -157,7 +157,7 @@ def main():
     # stream, so the per-launch durations measured above include time spent sharing the GPU.  A few extra steps with that overlap
     # switched off (outside the timed region) give the kernels' own rates, reported as roofline["isolated"].
     iso = None
-    if rank == 0 and hip_ops.SIDE_WGRAD:
+    if hip_ops.SIDE_WGRAD:  # every rank: the steps contain collectives
         hip_ops.SIDE_WGRAD = False
         W.train_step(rgbd, tamp, tphs)
         torch.cuda.synchronize()

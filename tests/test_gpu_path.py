@@ -744,3 +744,29 @@ def test_training_and_generation_clis_end_to_end(tmp_path):
     poh = torch.load(out / "poh.pt", map_location="cpu")
     assert poh.shape == (3, H, W) and torch.isfinite(poh).all() and poh.abs().max() <= 1.5 * torch.pi + 1e-4
     assert sorted(os.listdir(out / "planes")) == ["0.png", "1.png", "2.png"]
+
+
+# ----------------------------------------------------------------------------- data-parallel bench path, two ranks on one GPU
+def test_two_rank_bench_rehearsal():
+    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), rehearsed on ONE GPU with the gloo
+    backend (RCCL needs one GPU per rank): every rank must issue the same collectives — a rank-conditional train step deadlocks here."""
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LHG_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rows", "64",
+           "--cols", "64", "--pad", "32", "--cpu-baseline", "0"]
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=280)
+    assert res.returncode == 0, res.stderr[-2000:]
+    line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
+    out = json.loads(line)
+    assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0 and out["config"]["global_batch"] == 8
+    assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
