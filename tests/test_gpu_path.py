@@ -770,3 +770,52 @@ def test_two_rank_bench_rehearsal():
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0 and out["config"]["global_batch"] == 8
     assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+
+
+# ----------------------------------------------------------------------------- second stream for the weight gradients
+def test_side_stream_weight_gradients_match_single_stream():
+    """Gradients of a training step with the weight-gradient GEMMs on the second stream (accumulated straight into the flat gradient
+    slots) against the same step on one stream through autograd's own accumulation, captured right before each optimiser step:
+    the generator's are identical (one contribution per weight), the critic's agree up to the summation order of its three
+    contributions.  Run twice to give a stream race a chance to show."""
+    from learned_hologram_gan_amd import hip_ops
+    from learned_hologram_gan_amd.watermelon_hologram.watermelon import watermelon
+
+    rows = cols = 64
+    stack = torch.linspace(-4e-4, 0.0, 21)[:-1][:8]
+    rgbd, tamp, tphs = seeded.smooth_batch(2, rows, cols, seed=90)
+    idx = torch.tensor([5, 2])
+    alphas = [torch.tensor([0.3, 0.8]).view(2, 1, 1, 1).to(DEV)]
+
+    def run(side):
+        hip_ops.SIDE_WGRAD = side
+        W = watermelon(filter_radius_coefficient=0.45, pad_size=32, distance_stack=stack, input_shape=(1, 4, rows, cols))
+        W.generator.load_state_dict(seeded.generator_state_dict())
+        W.discriminator.load_state_dict(seeded.critic_state_dict())
+        W.generator.to(DEV).train()
+        W.discriminator.to(DEV).train()
+        W.configure(1, 0.0, 1, 1e-3, 0.1, 1e-3, 1e-3, 1, 10)
+        grads = {}
+        for name, opt in (("D", W._opt_D), ("G", W._opt_G)):
+            real_step = opt.step
+
+            def step(name=name, opt=opt, real_step=real_step):
+                hip_ops.join_side_stream()
+                torch.cuda.synchronize()
+                grads[name] = opt.flat.grad.detach().cpu().clone()
+                real_step()
+
+            opt.step = step
+        W.train_step(rgbd.to(DEV), tamp.to(DEV), tphs.to(DEV), idx, alphas)
+        torch.cuda.synchronize()
+        return grads
+
+    keep = hip_ops.SIDE_WGRAD
+    try:
+        for _ in range(2):
+            g1, g0 = run(True), run(False)
+            assert torch.equal(g1["G"], g0["G"])
+            assert (g1["D"] - g0["D"]).norm() <= 1e-5 * g0["D"].norm()
+            assert g0["G"].abs().max() > 0 and g0["D"].abs().max() > 0
+    finally:
+        hip_ops.SIDE_WGRAD = keep
