@@ -43,13 +43,15 @@ __device__ void lds_fft(float2* buf, int n, int nf, int stride, const float2* tw
     const int T = n / R;
     const int total = nf * T;
     const int twstep = n / (p * R);
+    const bool t_pow2 = (T & (T - 1)) == 0;  // wave-uniform: butterfly -> (transform, index) by shift instead of an integer division
+    const int lt = __ffs(T) - 1;
     float2 u[MAX_IT][4];
     if (R == 4) {
 #pragma unroll
       for (int it = 0; it < MAX_IT; ++it) {
         const int b = tid + it * nthreads;
         if (b < total) {
-          const int f = b / T, i = b - f * T;
+          const int f = t_pow2 ? b >> lt : b / T, i = b - f * T;
           const int k = p_pow2 ? (i & (p - 1)) : (i % p);
           const float2* x = buf + f * stride + i;
           float2 u0 = x[0], u1 = x[T], u2 = x[2 * T], u3 = x[3 * T];
@@ -68,7 +70,7 @@ __device__ void lds_fft(float2* buf, int n, int nf, int stride, const float2* tw
       for (int it = 0; it < MAX_IT; ++it) {
         const int b = tid + it * nthreads;
         if (b < total) {
-          const int f = b / T, i = b - f * T;
+          const int f = t_pow2 ? b >> lt : b / T, i = b - f * T;
           const int k = p_pow2 ? (i & (p - 1)) : (i % p);
           float2* y = buf + f * stride + ((i - k) << 2) + k;
           y[0] = u[it][0]; y[p] = u[it][1]; y[2 * p] = u[it][2]; y[3 * p] = u[it][3];
@@ -81,7 +83,7 @@ __device__ void lds_fft(float2* buf, int n, int nf, int stride, const float2* tw
       for (int it = 0; it < 2 * MAX_IT; ++it) {
         const int b = tid + it * nthreads;
         if (b < total) {
-          const int f = b / T, i = b - f * T;
+          const int f = t_pow2 ? b >> lt : b / T, i = b - f * T;
           const int k = p_pow2 ? (i & (p - 1)) : (i % p);
           const float2* x = buf + f * stride + i;
           float2 u0 = x[0], u1 = x[T];
@@ -97,7 +99,7 @@ __device__ void lds_fft(float2* buf, int n, int nf, int stride, const float2* tw
       for (int it = 0; it < 2 * MAX_IT; ++it) {
         const int b = tid + it * nthreads;
         if (b < total) {
-          const int f = b / T, i = b - f * T;
+          const int f = t_pow2 ? b >> lt : b / T, i = b - f * T;
           const int k = p_pow2 ? (i & (p - 1)) : (i % p);
           float2* y = buf + f * stride + ((i - k) << 1) + k;
           y[0] = u[it >> 1][(it & 1) * 2];
@@ -112,7 +114,7 @@ __device__ void lds_fft(float2* buf, int n, int nf, int stride, const float2* tw
       for (int it = 0; it < MAX_IT; ++it) {
         const int b = tid + it * nthreads;
         if (b < total) {
-          const int f = b / T, i = b - f * T;
+          const int f = t_pow2 ? b >> lt : b / T, i = b - f * T;
           const int k = i % p;
           const float2* x = buf + f * stride + i;
           float2 u0 = x[0], u1 = x[T], u2 = x[2 * T];
@@ -133,7 +135,7 @@ __device__ void lds_fft(float2* buf, int n, int nf, int stride, const float2* tw
       for (int it = 0; it < MAX_IT; ++it) {
         const int b = tid + it * nthreads;
         if (b < total) {
-          const int f = b / T, i = b - f * T;
+          const int f = t_pow2 ? b >> lt : b / T, i = b - f * T;
           const int k = i % p;
           float2* y = buf + f * stride + (i - k) * 3 + k;
           y[0] = u[it][0]; y[p] = u[it][1]; y[2 * p] = u[it][2];
@@ -225,8 +227,9 @@ __global__ __launch_bounds__(1024) void cols_filter_kernel(const ColsParams p) {
   const int plane = blockIdx.x / groups, c0 = (blockIdx.x - plane * groups) * p.G;
   for (int i = tid; i < p.R; i += nth) tw[i] = p.tw[i];
   // load G columns (zero outside the stored rows)
+  const int lg = __ffs(p.G) - 1, gm = p.G - 1;  // G is a power of two
   for (int i = tid; i < p.R * p.G; i += nth) {
-    const int g = i % p.G, r = i / p.G;
+    const int g = i & gm, r = i >> lg;
     const int sr = r - p.src_off;
     float2 z = make_float2(0.f, 0.f);
     if (sr >= 0 && sr < p.src_rows) z = p.src[((size_t)plane * p.src_rows + sr) * p.C + c0 + g];
@@ -238,7 +241,7 @@ __global__ __launch_bounds__(1024) void cols_filter_kernel(const ColsParams p) {
   const int s2 = p.f2_op ? (p.f2_index ? p.f2_index[plane] : 0) : 0;
   if (p.f1_op || p.f2_op || p.scale != 1.f) {
     for (int i = tid; i < p.R * p.G; i += nth) {
-      const int g = i % p.G, k = i / p.G;
+      const int g = i & gm, k = i >> lg;
       float2 z = buf[g * stride + k];
       if (p.f1_op) z = apply_filter(z, p.f1[((size_t)s1 * p.R + k) * p.C + c0 + g], p.f1_op);
       if (p.f2_op) z = apply_filter(z, p.f2[((size_t)s2 * p.R + k) * p.C + c0 + g], p.f2_op);
@@ -249,7 +252,7 @@ __global__ __launch_bounds__(1024) void cols_filter_kernel(const ColsParams p) {
   }
   if (p.do_inv) lds_fft<true>(buf, p.R, p.G, stride, tw);
   for (int i = tid; i < p.dst_rows * p.G; i += nth) {
-    const int g = i % p.G, r = i / p.G;
+    const int g = i & gm, r = i >> lg;
     p.dst[((size_t)plane * p.dst_rows + r) * p.C + c0 + g] = buf[g * stride + r + p.dst_off];
   }
 }
