@@ -33,8 +33,103 @@ __device__ __forceinline__ float2 csub(float2 a, float2 b) { return make_float2(
 
 // nf transforms of length n at buf + f*stride.  tw: n entries exp(-2 pi i k / n) (LDS).
 // All threads of the workgroup must call this (barriers inside).
+// ---- power-of-two lengths: every stage parameter is a compile-time constant, so butterfly -> (transform, index, twiddle) is
+// shifts and masks and the four element offsets are immediates.  The passes are bound by the butterflies' instruction stream
+// (the generic code below spends two thirds of it on index arithmetic), not by LDS or HBM.
+template <int N, int P, bool INV>
+__device__ __forceinline__ void stage4_pow2(float2* buf, int nf, int stride, const float2* tw) {
+  constexpr int T = N / 4, TWSTEP = N / (P * 4);
+  constexpr int LT = __builtin_ctz(T);
+  const int nthreads = blockDim.x, tid = threadIdx.x;
+  const int total = nf * T;
+  float2 u[MAX_IT][4];
+  int off[MAX_IT];
+#pragma unroll
+  for (int it = 0; it < MAX_IT; ++it) {
+    const int b = tid + it * nthreads;
+    if (b < total) {
+      const int f = b >> LT, i = b & (T - 1), k = i & (P - 1);
+      const float2* x = buf + f * stride + i;
+      float2 u0 = x[0], u1 = x[T], u2 = x[2 * T], u3 = x[3 * T];
+      if (P > 1) {
+        float2 w1 = tw[k * TWSTEP], w2 = tw[2 * k * TWSTEP], w3 = tw[3 * k * TWSTEP];
+        if (INV) { w1.y = -w1.y; w2.y = -w2.y; w3.y = -w3.y; }
+        u1 = cmul(u1, w1); u2 = cmul(u2, w2); u3 = cmul(u3, w3);
+      }
+      const float2 v0 = cadd(u0, u2), v1 = csub(u0, u2), v2 = cadd(u1, u3), d = csub(u1, u3);
+      const float2 v3 = INV ? make_float2(-d.y, d.x) : make_float2(d.y, -d.x);
+      u[it][0] = cadd(v0, v2); u[it][1] = cadd(v1, v3); u[it][2] = csub(v0, v2); u[it][3] = csub(v1, v3);
+      off[it] = f * stride + ((i - k) << 2) + k;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < MAX_IT; ++it) {
+    if (tid + it * nthreads < total) {
+      float2* y = buf + off[it];
+      y[0] = u[it][0]; y[P] = u[it][1]; y[2 * P] = u[it][2]; y[3 * P] = u[it][3];
+    }
+  }
+  __syncthreads();
+}
+
+template <int N, int P, bool INV>
+__device__ __forceinline__ void stage2_pow2(float2* buf, int nf, int stride, const float2* tw) {
+  constexpr int T = N / 2, TWSTEP = N / (P * 2);
+  constexpr int LT = __builtin_ctz(T);
+  const int nthreads = blockDim.x, tid = threadIdx.x;
+  const int total = nf * T;
+  float2 u[2 * MAX_IT][2];
+  int off[2 * MAX_IT];
+#pragma unroll
+  for (int it = 0; it < 2 * MAX_IT; ++it) {
+    const int b = tid + it * nthreads;
+    if (b < total) {
+      const int f = b >> LT, i = b & (T - 1), k = i & (P - 1);
+      const float2* x = buf + f * stride + i;
+      float2 u0 = x[0], u1 = x[T];
+      float2 w = tw[k * TWSTEP];
+      if (INV) w.y = -w.y;
+      u1 = cmul(u1, w);
+      u[it][0] = cadd(u0, u1);
+      u[it][1] = csub(u0, u1);
+      off[it] = f * stride + ((i - k) << 1) + k;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < 2 * MAX_IT; ++it) {
+    if (tid + it * nthreads < total) {
+      float2* y = buf + off[it];
+      y[0] = u[it][0];
+      y[P] = u[it][1];
+    }
+  }
+  __syncthreads();
+}
+
+template <int N, int P, bool INV>
+__device__ __forceinline__ void stages_pow2(float2* buf, int nf, int stride, const float2* tw) {
+  if constexpr (N / P >= 4) {
+    stage4_pow2<N, P, INV>(buf, nf, stride, tw);
+    stages_pow2<N, P * 4, INV>(buf, nf, stride, tw);
+  } else if constexpr (N / P == 2) {
+    stage2_pow2<N, P, INV>(buf, nf, stride, tw);
+  }
+}
+
 template <bool INV>
 __device__ void lds_fft(float2* buf, int n, int nf, int stride, const float2* tw) {
+  switch (n) {  // wave-uniform
+    case 64: return stages_pow2<64, 1, INV>(buf, nf, stride, tw);
+    case 128: return stages_pow2<128, 1, INV>(buf, nf, stride, tw);
+    case 256: return stages_pow2<256, 1, INV>(buf, nf, stride, tw);
+    case 512: return stages_pow2<512, 1, INV>(buf, nf, stride, tw);
+    case 1024: return stages_pow2<1024, 1, INV>(buf, nf, stride, tw);
+    case 2048: return stages_pow2<2048, 1, INV>(buf, nf, stride, tw);
+    case 4096: return stages_pow2<4096, 1, INV>(buf, nf, stride, tw);
+    default: break;
+  }
   const int nthreads = blockDim.x, tid = threadIdx.x;
   for (int p = 1; p < n;) {
     const int rem = n / p;                                   // n = 2^a * 3^b: radix 4 while possible, then 2, then 3
