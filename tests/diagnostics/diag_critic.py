@@ -1,6 +1,6 @@
 """Per-parameter gradient errors of the critic step (GPU vs CPU oracle)."""
 import sys, os
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
 from oracle import nets, seeded, step
 from learned_hologram_gan_amd.watermelon_hologram.discriminator import WGANGPDiscriminator192

@@ -207,7 +207,7 @@ def test_unet_train_gradients_vs_fp64_truth(rows, batch):
     maths as the fp32 CPU (reference-arithmetic) result is.
 
     Max-pool argmax is discontinuous: among ~5e5 2x2 windows some top-2 values differ by < 1e-6 relative, so two fp32
-    implementations route a few window gradients to different pixels (measured: 1 flip at 64x64, tools/dbg_levels.py).
+    implementations route a few window gradients to different pixels (measured: 1 flip at 64x64, tests/diagnostics/dbg_levels.py).
     Gradients are therefore compared in relative L2, plus an aggregate criterion over ALL parameters."""
     import statistics
 
@@ -323,7 +323,7 @@ def test_train_step_against_reference_loop(golden):
                    W.train_losses_tensor.tolist()))
     # Quantities that pass through the UPDATED critic are compared more loosely: Adam's first steps move every
     # weight by ~lr*sign(g), the critic output moves by O(1) per step (gradient-penalty loss ~1e2), and the fp32
-    # rounding differences between the GPU and CPU GEMMs (gradients agree to ~3e-6, tools/diag_critic.py) are
+    # rounding differences between the GPU and CPU GEMMs (gradients agree to ~3e-6, tests/diagnostics/diag_critic.py) are
     # amplified to ~2e-3 of gan_loss after two critic updates.
     loose = {"gan_loss": 2e-2, "G_loss": 2e-2, "D_loss": 2e-2}
     for k, ref in g["losses"].items():
