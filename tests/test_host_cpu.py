@@ -263,3 +263,25 @@ def test_prefetch_loader_shards_like_distributed_sampler(tmp_path):
         assert _same(ref, got)
         seen += [tuple(row.flatten()[:4].tolist()) for b in got for row in b[1]]
     assert len(seen) == 12 and len(set(seen)) == 11  # disjoint shards; 11 samples padded to 12 by wrapping around
+
+
+def test_product_never_imports_the_oracle():
+    """The oracle is test infrastructure: only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may use it."""
+    import ast
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    offenders = []
+    files = [os.path.join(dp, f) for dp, _, fs in os.walk(os.path.join(root, "learned_hologram_gan_amd")) for f in fs if f.endswith(".py")]
+    files += [os.path.join(root, f) for f in ("trainingModel.py", "generatePOH.py")] + \
+             [os.path.join(root, "tools", f) for f in os.listdir(os.path.join(root, "tools")) if f.endswith(".py")]
+    for path in files:
+        for node in ast.walk(ast.parse(open(path).read())):
+            names = [a.name for a in node.names] if isinstance(node, ast.Import) else [node.module or ""] if isinstance(node, ast.ImportFrom) else []
+            if any(n == "oracle" or n.startswith("oracle.") for n in names):
+                offenders.append(os.path.relpath(path, root))
+    assert not offenders, offenders
+    # bench.py: the oracle appears only inside cpu_baseline()
+    tree = ast.parse(open(os.path.join(root, "bench.py")).read())
+    for fn in [n for n in tree.body if isinstance(n, ast.FunctionDef)]:
+        uses = any(isinstance(n, ast.ImportFrom) and (n.module or "").startswith("oracle") for n in ast.walk(fn))
+        assert uses == (fn.name == "cpu_baseline"), fn.name
