@@ -115,12 +115,28 @@ SIDE_WGRAD = _os.environ.get("LHG_SIDE_WGRAD", "1") != "0"
 
 
 def register_grad_slot(param: torch.Tensor, grad_view: torch.Tensor) -> None:
-    _GRAD_SLOTS[param.data_ptr()] = grad_view
+    """Keyed by address for the lookup in backward, but validated against a weak reference to the parameter itself: an entry whose
+    parameter has died is dropped, so a later tensor that happens to reuse the address can never inherit the slot."""
+    import weakref
+
+    _GRAD_SLOTS[param.data_ptr()] = (weakref.ref(param), grad_view)
 
 
 def unregister_grad_slots(params) -> None:
     for p_ in params:
         _GRAD_SLOTS.pop(p_.data_ptr(), None)
+
+
+def _grad_slot(w):
+    entry = _GRAD_SLOTS.get(w.data_ptr())
+    if entry is None:
+        return None
+    owner = entry[0]()
+    if owner is None:
+        del _GRAD_SLOTS[w.data_ptr()]
+        return None
+    same = owner is w or (owner.data_ptr() == w.data_ptr() and owner.shape == w.shape and owner._version == w._version)
+    return entry[1] if same and entry[1].shape == w.shape else None
 
 
 def _side_stream(device):
@@ -139,8 +155,8 @@ def join_side_stream(device=None) -> None:
 
 def _weight_grad(w, inputs, fn):
     """fn() -> weight gradient from `inputs`.  Plain backward into a registered slot: run on the side stream, accumulate, return None."""
-    slot = _GRAD_SLOTS.get(w.data_ptr()) if (SIDE_WGRAD and not torch.is_grad_enabled()) else None
-    if slot is None or slot.shape != w.shape:
+    slot = _grad_slot(w) if (SIDE_WGRAD and not torch.is_grad_enabled()) else None
+    if slot is None:
         return fn()
     main, side = torch.cuda.current_stream(w.device), _side_stream(w.device)
     side.wait_stream(main)  # inputs (and the zeroed slot) are ready on the main stream
@@ -328,6 +344,7 @@ class Conv2dFn(Function):
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
+        gy = _as_nhwc_view(gy)  # autograd may hand out an expanded (zero-stride) gradient, e.g. from .sum()
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = Conv2dInputGradFn.apply(gy, w, ctx.stride, x.shape[1], x.shape[2], x.shape[3])
@@ -440,6 +457,7 @@ class ConvTranspose2x2Fn(Function):
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
+        gy = _as_nhwc_view(gy)
         gx = gw = gb = None
         Ci, Co = w.shape[0], w.shape[1]
         if ctx.needs_input_grad[0]:
@@ -524,7 +542,7 @@ class ConvBiasActFn(Function):
     @staticmethod
     def backward(ctx, gy):
         x, w, y = ctx.saved_tensors
-        g = ActGradFn.apply(gy, y, ctx.act, ctx.slope)
+        g = ActGradFn.apply(_as_nhwc_view(gy), y, ctx.act, ctx.slope)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = Conv2dInputGradFn.apply(g, w, ctx.stride, x.shape[1], x.shape[2], x.shape[3])
@@ -565,7 +583,7 @@ class BatchNormTrainFn(Function):
     @staticmethod
     def backward(ctx, gy):
         x, y, gamma, stats = ctx.saved_tensors
-        gx, gres, ggamma, gbeta = BatchNormGradFn.apply(gy, x, y, gamma, stats, ctx.act, ctx.slope, ctx.has_res)
+        gx, gres, ggamma, gbeta = BatchNormGradFn.apply(_as_nhwc_view(gy), x, y, gamma, stats, ctx.act, ctx.slope, ctx.has_res)
         return gx, ggamma, gbeta, None, None, (gres if ctx.has_res else None), None, None, None
 
 

@@ -374,3 +374,22 @@ def test_recon_losses_match_reference_definitions():
     (out * wts.to(DEV)).sum().backward()
     assert rel_err(hag.grad.cpu(), har.grad) < 1e-4
     assert rel_err(hpg.grad.cpu(), hpr.grad) < 1e-4
+
+
+def test_stale_gradient_slot_is_never_inherited(ops):
+    """A weight-gradient slot registered for a parameter must not be picked up by an unrelated tensor that reuses its address."""
+    w = torch.nn.Parameter(rnd(64, 64, 3, 3, seed=1, scale=0.05).to(DEV))
+    slot = torch.zeros_like(w)
+    ops.register_grad_slot(w, slot)
+    addr = w.data_ptr()
+    assert ops._grad_slot(w) is slot
+    del w
+    torch.cuda.empty_cache()
+    other = torch.empty((64, 64, 3, 3), device=DEV)  # may or may not land on the same address
+    if other.data_ptr() == addr:
+        assert ops._grad_slot(other) is None
+    assert addr not in ops._GRAD_SLOTS or ops._GRAD_SLOTS[addr][0]() is None or other.data_ptr() != addr
+    x = to_nhwc(rnd(1, 64, 8, 8, seed=2)).requires_grad_(True)
+    w2 = rnd(64, 64, 3, 3, seed=3, scale=0.05).to(DEV).requires_grad_(True)
+    ops.Conv2dFn.apply(x, w2, None, 1, None).sum().backward()
+    assert w2.grad is not None and torch.isfinite(w2.grad).all()
