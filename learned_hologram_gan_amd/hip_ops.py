@@ -106,10 +106,12 @@ def _dense(t):
 # branch off (BN backward -> input-gradient -> BN backward ...) alternates MFMA-bound and HBM-bound kernels.  For parameters whose
 # gradient lives in a flat buffer (optim.FlatParams registers the slot), the weight gradient is therefore launched on a second HIP
 # stream and ACCUMULATED straight into the slot; autograd gets None for it.  The main stream's HBM-bound kernels then run under the
-# side stream's GEMMs.  join_side_stream() is the fence (optimiser step, gradient all-reduce).  LHG_SIDE_WGRAD=0 disables.
+# side stream's GEMMs.  A callback queued on the autograd engine joins the two streams when the backward pass ends, so reading
+# .grad after backward() is as safe as without the second stream (join_side_stream() is that fence).  LHG_SIDE_WGRAD=0 disables.
 import os as _os
 
 _GRAD_SLOTS: dict = {}
+_JOIN_QUEUED = False
 _SIDE_STREAMS: dict = {}
 SIDE_WGRAD = _os.environ.get("LHG_SIDE_WGRAD", "1") != "0"
 
@@ -159,6 +161,16 @@ def _weight_grad(w, inputs, fn):
     if slot is None:
         return fn()
     main, side = torch.cuda.current_stream(w.device), _side_stream(w.device)
+    global _JOIN_QUEUED
+    if not _JOIN_QUEUED:  # when this backward pass ends, its stream waits for the side stream: .grad is then safe to read as usual
+        _JOIN_QUEUED = True
+
+        def _join_at_end(dev=w.device):
+            global _JOIN_QUEUED
+            _JOIN_QUEUED = False
+            join_side_stream(dev)
+
+        torch.autograd.Variable._execution_engine.queue_callback(_join_at_end)
     side.wait_stream(main)  # inputs (and the zeroed slot) are ready on the main stream
     for t in inputs:
         t.record_stream(side)  # keep their memory out of main-stream reuse until the side stream is done with it
