@@ -819,3 +819,17 @@ def test_side_stream_weight_gradients_match_single_stream():
             assert g0["G"].abs().max() > 0 and g0["D"].abs().max() > 0
     finally:
         hip_ops.SIDE_WGRAD = keep
+
+
+# ----------------------------------------------------------------------------- the C ABI without Python
+def test_standalone_cpp_host_of_the_c_abi():
+    """examples/abi_demo (built by __graft_entry__.build()): a C++ program that links liblhg_hip.so, owns its buffers and stream, and checks
+    a convolution against a scalar loop and the angular-spectrum operator against the identity."""
+    import os
+    import subprocess
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    exe = os.path.join(root, "examples", "abi_demo")
+    assert os.path.exists(exe), "run python __graft_entry__.py first"
+    res = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert res.returncode == 0 and "abi_demo ok" in res.stdout, res.stdout + res.stderr
