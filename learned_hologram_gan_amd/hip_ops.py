@@ -15,6 +15,8 @@ There is no CPU path here: every op raises if its tensors are not on the GPU.
 from __future__ import annotations
 
 import ctypes
+import os
+import weakref
 
 import torch
 from torch.autograd import Function
@@ -108,19 +110,15 @@ def _dense(t):
 # stream and ACCUMULATED straight into the slot; autograd gets None for it.  The main stream's HBM-bound kernels then run under the
 # side stream's GEMMs.  A callback queued on the autograd engine joins the two streams when the backward pass ends, so reading
 # .grad after backward() is as safe as without the second stream (join_side_stream() is that fence).  LHG_SIDE_WGRAD=0 disables.
-import os as _os
-
 _GRAD_SLOTS: dict = {}
 _JOIN_QUEUED = False
 _SIDE_STREAMS: dict = {}
-SIDE_WGRAD = _os.environ.get("LHG_SIDE_WGRAD", "1") != "0"
+SIDE_WGRAD = os.environ.get("LHG_SIDE_WGRAD", "1") != "0"
 
 
 def register_grad_slot(param: torch.Tensor, grad_view: torch.Tensor) -> None:
     """Keyed by address for the lookup in backward, but validated against a weak reference to the parameter itself: an entry whose
     parameter has died is dropped, so a later tensor that happens to reuse the address can never inherit the slot."""
-    import weakref
-
     _GRAD_SLOTS[param.data_ptr()] = (weakref.ref(param), grad_view)
 
 
@@ -280,8 +278,6 @@ def thin_mode(Ci, Co, k, stride):
     """0: MFMA gather-GEMM; 1 / 2: direct kernels of csrc/thin_conv.hip (thin input / thin output).  LHG_THIN=0 disables."""
     key = (Ci, Co, k, stride)
     if key not in _THIN_MODE:
-        import os
-
         on = os.environ.get("LHG_THIN", "1") != "0"
         _THIN_MODE[key] = int(native.load().lhg_conv2d_thin_supported(Ci, Co, k, stride)) if on else 0
     return _THIN_MODE[key]
