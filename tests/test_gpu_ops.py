@@ -393,3 +393,36 @@ def test_stale_gradient_slot_is_never_inherited(ops):
     w2 = rnd(64, 64, 3, 3, seed=3, scale=0.05).to(DEV).requires_grad_(True)
     ops.Conv2dFn.apply(x, w2, None, 1, None).sum().backward()
     assert w2.grad is not None and torch.isfinite(w2.grad).all()
+
+
+def test_conv2d_randomised_shape_sweep(ops):
+    """Seeded sweep over ragged extents, channel counts that are not tile multiples, both kernel sizes and strides: forward, input
+    gradient, weight gradient and bias gradient against PyTorch fp32 on the CPU (covers the MFMA engine's padding / masking paths and
+    the dispatch to the thin kernels)."""
+    import random
+
+    rng = random.Random(1234)
+    channels_in, channels_out = (1, 3, 4, 6, 32, 64, 96, 128), (1, 4, 6, 32, 64, 96, 160)
+    for case in range(28):
+        N, H, W = rng.randint(1, 3), rng.randint(5, 40), rng.randint(5, 40)
+        Ci, Co, k = rng.choice(channels_in), rng.choice(channels_out), rng.choice((1, 3))
+        stride = rng.choice((1, 2)) if k == 3 else 1
+        x = rnd(N, Ci, H, W, seed=10 * case + 1)
+        w = rnd(Co, Ci, k, k, seed=10 * case + 2, scale=(Ci * k * k) ** -0.5)
+        b = rnd(Co, seed=10 * case + 3, scale=0.1)
+        xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+        yr = F.conv2d(xr, wr, br, stride=stride, padding=k // 2)
+        proj = rnd(*yr.shape, seed=10 * case + 4)
+        (yr * proj).sum().backward()
+        ld = ops.pad_to(Ci, 32)
+        xg = to_nhwc(x, ld).requires_grad_(True)
+        wg, bg = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+        yg = ops.Conv2dFn.apply(xg, wg, bg, stride, None)
+        tag = (case, N, Ci, Co, H, W, k, stride)
+        assert yg.shape == (N, yr.shape[2], yr.shape[3], Co), tag
+        assert rel_err(to_nchw(yg), yr.detach()) < TOL, tag
+        (yg * to_nhwc(proj)).sum().backward()
+        assert rel_err(to_nchw(xg.grad, Ci), xr.grad) < TOL, tag
+        assert ld == Ci or xg.grad[..., Ci:].abs().max().item() == 0, tag
+        assert rel_err(wg.grad.cpu(), wr.grad) < 5e-5, tag
+        assert rel_err(bg.grad.cpu(), br.grad) < 5e-5, tag
