@@ -420,6 +420,38 @@ static KernelTimer g_timer[2];  // 0: gg_kernel, 1: wg_kernel
 static bool g_autotune_enabled = true;
 static std::map<std::array<int, 12>, int> g_gg_choice, g_wg_choice;
 
+// One-time timing of the valid kernel variants for a geometry not seen before (HIP events on `st`: the only place the library
+// synchronises; skipped while the stream is being captured).  Returns the cached / measured winner or -1.
+template <class Valid, class Run>
+static int autotuned_variant(std::map<std::array<int, 12>, int>& cache, const std::array<int, 12>& key, int variants, Valid valid, Run run,
+                             hipStream_t st) {
+  auto it = cache.find(key);
+  if (it != cache.end()) return it->second;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return -1;
+  hipEvent_t e0, e1;
+  (void)hipEventCreate(&e0);
+  (void)hipEventCreate(&e1);
+  float best = 1e30f;
+  int choice = -1;
+  for (int v = 0; v < variants; ++v) {
+    if (!valid(v)) continue;
+    run(v);  // warm-up (code object load, caches)
+    (void)hipEventRecord(e0, st);
+    run(v);
+    run(v);
+    (void)hipEventRecord(e1, st);
+    if (hipEventSynchronize(e1) != hipSuccess || hipGetLastError() != hipSuccess) continue;
+    float ms = 0;
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    if (ms < best) { best = ms; choice = v; }
+  }
+  (void)hipEventDestroy(e0);
+  (void)hipEventDestroy(e1);
+  if (choice >= 0) cache[key] = choice;
+  return choice;
+}
+
 struct ScopedKernelTime {
   KernelTimer& t;
   hipStream_t st;
@@ -490,36 +522,8 @@ static int launch_gg(GGParams& p, hipStream_t st) {
   int choice = -1;
   if (forced >= 0 && forced < NV && valid(forced)) choice = forced;
   if (choice < 0 && tune && g_autotune_enabled) {
-    // One-time timing of the valid variants for a geometry not seen before (HIP events on `st`; this is the
-    // only place the library synchronises, and it is skipped while the stream is being captured).
     const std::array<int, 12> key = {g.M, p.rows_pad, g.Ci, g.Co, g.T, g.istep, g.ostep, g.Hi, g.Wi, g.ldi, g.ldo, p.planar_out};
-    auto it = g_gg_choice.find(key);
-    if (it != g_gg_choice.end()) {
-      choice = it->second;
-    } else {
-      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-      if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {
-        hipEvent_t e0, e1;
-        (void)hipEventCreate(&e0);
-        (void)hipEventCreate(&e1);
-        float best = 1e30f;
-        for (int v = 0; v < NV; ++v) {
-          if (!valid(v)) continue;
-          run(v);  // warm-up (code object load, caches)
-          (void)hipEventRecord(e0, st);
-          run(v);
-          run(v);
-          (void)hipEventRecord(e1, st);
-          if (hipEventSynchronize(e1) != hipSuccess || hipGetLastError() != hipSuccess) continue;
-          float ms = 0;
-          (void)hipEventElapsedTime(&ms, e0, e1);
-          if (ms < best) { best = ms; choice = v; }
-        }
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-        if (choice >= 0) g_gg_choice[key] = choice;
-      }
-    }
+    choice = autotuned_variant(g_gg_choice, key, NV, valid, run, st);
   }
   if (choice < 0) choice = heuristic();
   ScopedKernelTime timed(0, st, 2.0 * g.M * (double)p.rows_pad * g.Ci * g.T);
@@ -555,33 +559,7 @@ static int launch_gg_bf16(GGParams& p, hipStream_t st) {
   int choice = (forced >= 0 && forced < NV && valid(forced)) ? forced : -1;
   if (choice < 0 && g_autotune_enabled) {
     const std::array<int, 12> key = {g.M, p.rows_pad, g.Ci, g.Co, g.T, g.istep, g.ostep, g.Hi, g.Wi, g.ldi, g.ldo, p.planar_out + 2};
-    auto it = g_gg_choice.find(key);
-    if (it != g_gg_choice.end()) {
-      choice = it->second;
-    } else {
-      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-      if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {
-        hipEvent_t e0, e1;
-        (void)hipEventCreate(&e0);
-        (void)hipEventCreate(&e1);
-        float best = 1e30f;
-        for (int v = 0; v < NV; ++v) {
-          if (!valid(v)) continue;
-          run(v);
-          (void)hipEventRecord(e0, st);
-          run(v);
-          run(v);
-          (void)hipEventRecord(e1, st);
-          if (hipEventSynchronize(e1) != hipSuccess || hipGetLastError() != hipSuccess) continue;
-          float ms = 0;
-          (void)hipEventElapsedTime(&ms, e0, e1);
-          if (ms < best) { best = ms; choice = v; }
-        }
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-        if (choice >= 0) g_gg_choice[key] = choice;
-      }
-    }
+    choice = autotuned_variant(g_gg_choice, key, NV, valid, run, st);
   }
   if (choice < 0) choice = n128 && blocks(128, 128) >= 256 ? 0 : (blocks(128, 64) >= 256 ? 1 : 2);
   ScopedKernelTime timed(0, st, 2.0 * g.M * (double)p.rows_pad * g.Ci * g.T);
@@ -638,33 +616,7 @@ static int launch_wg(WGParams& p, int S, hipStream_t st, const WG3Params* p3 = n
   if (forced >= 0 && forced < NV && valid(forced)) choice = forced;
   if (choice < 0 && tune && g_autotune_enabled) {
     const std::array<int, 12> key = {g.M, p.m_pad, p.n_pad, g.T, S, g.istep, g.ostep, g.Hi, g.Wi, g.ldi, g.ldo, g.ws[0] + 100 * g_precision};
-    auto it = g_wg_choice.find(key);
-    if (it != g_wg_choice.end()) {
-      choice = it->second;
-    } else {
-      hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
-      if (hipStreamIsCapturing(st, &cap) == hipSuccess && cap == hipStreamCaptureStatusNone) {
-        hipEvent_t e0, e1;
-        (void)hipEventCreate(&e0);
-        (void)hipEventCreate(&e1);
-        float best = 1e30f;
-        for (int v = 0; v < NV; ++v) {
-          if (!valid(v)) continue;
-          run(v);
-          (void)hipEventRecord(e0, st);
-          run(v);
-          run(v);
-          (void)hipEventRecord(e1, st);
-          if (hipEventSynchronize(e1) != hipSuccess || hipGetLastError() != hipSuccess) continue;
-          float ms = 0;
-          (void)hipEventElapsedTime(&ms, e0, e1);
-          if (ms < best) { best = ms; choice = v; }
-        }
-        (void)hipEventDestroy(e0);
-        (void)hipEventDestroy(e1);
-        if (choice >= 0) g_wg_choice[key] = choice;
-      }
-    }
+    choice = autotuned_variant(g_wg_choice, key, NV, valid, run, st);
   }
   if (choice < 0 && bf16) choice = m128 && n128 && (p.m_pad / 128) * (p.n_pad / 128) * g.T * S >= 400 ? 6 : 9;
   if (choice < 0) choice = small ? (p3 ? 5 : (m128 && n128 && (p.m_pad / 128) * (p.n_pad / 128) * g.T * S >= 400 ? 0 : 3)) : 4;
