@@ -37,6 +37,22 @@ def world_size() -> int:
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
 
+def broadcast_module_state(module: torch.nn.Module, flat_data: torch.Tensor | None = None, src: int = 0, group=None) -> None:
+    """Replicas start from rank `src`'s weights and buffers (as DistributedDataParallel does at construction): one broadcast of the
+    flat parameter buffer (or one per parameter without it) plus one per floating-point buffer.  No-op for a single process."""
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size(group) == 1:
+        return
+    with torch.no_grad():
+        if flat_data is not None:
+            dist.broadcast(flat_data, src=src, group=group)
+        else:
+            for p in module.parameters():
+                dist.broadcast(p.data, src=src, group=group)
+        for b in module.buffers():
+            if b.dtype.is_floating_point or b.dtype == torch.int64:
+                dist.broadcast(b, src=src, group=group)
+
+
 class GradSynchronizer:
     """Average the gradients held in one flat buffer across ranks.
 

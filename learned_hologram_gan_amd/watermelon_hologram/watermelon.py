@@ -20,7 +20,7 @@ import torch.autograd as autograd
 import torch.nn.functional as F
 
 from ..angular_spectrum_method import bandLimitedAngularSpectrumMethod_for_multiple_distances
-from ..distributed import GradSynchronizer
+from ..distributed import GradSynchronizer, broadcast_module_state
 from ..optim import FlatParams, FusedAdam
 from ..poh_ops import ReconLossFn
 from ..utilities import try_gpu
@@ -113,11 +113,13 @@ class watermelon:
         self.discriminator_train_ratio, self.discriminator_lambda = discriminator_train_ratio, discriminator_lambda
         self.generator.to(self.device)
         flat_G = FlatParams(self.generator)
+        broadcast_module_state(self.generator, flat_G.data)  # data-parallel replicas start from rank 0's weights
         self._opt_G = FusedAdam(flat_G, lr=lr_G)
         self._sync_G = GradSynchronizer(flat_G.params, flat_G.offsets, flat_G.grad, grad_buckets)
         trainable_D = [p for p in self.discriminator.parameters() if p.requires_grad]
         if discriminator_train_ratio > 0 and trainable_D and isinstance(self.discriminator, WGANGPDiscriminator192):
             flat_D = FlatParams(self.discriminator)
+            broadcast_module_state(self.discriminator, flat_D.data)
             self._opt_D = FusedAdam(flat_D, lr=lr_D)
             self._sync_D = GradSynchronizer(flat_D.params, flat_D.offsets, flat_D.grad, max(1, grad_buckets // 2))
         else:

@@ -37,9 +37,14 @@ def _worker(rank, world, port, q):
 
     r, w, _ = distributed.init_from_env("gloo")
     assert (r, w) == (rank, world) and distributed.world_size() == world
-    torch.manual_seed(0)
+    torch.manual_seed(100 + rank)  # replicas are built from different seeds ...
     net = _Net()
     flat = FlatParams(net)
+    distributed.broadcast_module_state(net, flat.data)  # ... and start from rank 0's weights
+    torch.manual_seed(100)
+    want = torch.cat([p.detach().reshape(-1) for p in _Net().parameters()])
+    got = torch.cat([p.detach().reshape(-1) for p in net.parameters()])
+    assert torch.equal(got, want)
     assert all(p.data_ptr() == flat.data.data_ptr() + 4 * o for p, o in zip(flat.params, flat.offsets))
     sync = distributed.GradSynchronizer(flat.params, flat.offsets, flat.grad, n_buckets=3)
     assert len(sync.ranges) >= 2 and sum(sync.expected) == len(flat.params)
