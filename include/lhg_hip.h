@@ -253,6 +253,13 @@ int lhg_recon_loss_backward(const float* hat_amp, const float* tgt_amp, const fl
                             int planes, int H, int W, const float* sums9, const float* upstream3,
                             float* g_hat_amp, float* g_hat_phs, lhg_stream_t s);
 
+/* PSNR and SSIM of `hat` against `tgt` (planar (planes, H, W), e.g. planes = B*3) exactly as the reference records them every batch
+ * with torchmetrics' defaults (watermelon.py:134-135, 447-456): out2[0] = 10 log10((max tgt - min tgt)^2 / mse), out2[1] = mean SSIM
+ * (11x11 Gaussian window, sigma 1.5, data range max(range hat, range tgt), k1 0.01, k2 0.03, border of 5 pixels cropped).
+ * Device-side reductions only (no host synchronisation); ws >= lhg_psnr_ssim_workspace bytes. */
+size_t lhg_psnr_ssim_workspace(int planes, int H, int W);
+int lhg_psnr_ssim(const float* hat, const float* tgt, int planes, int H, int W, float* out2, void* ws, size_t ws_bytes, lhg_stream_t s);
+
 /* ------------------------------------------------------------------ optimiser
  * torch.optim.Adam (no weight decay, no amsgrad) on one flat tensor.  ref: watermelon.py:137-138. */
 int lhg_adam_step(float* p, const float* g, float* m, float* v, long long n,

@@ -75,9 +75,11 @@ _SIGNATURES = {
     "lhg_recon_loss_blocks": [_i, _i, _i],
     "lhg_recon_loss_forward": [_p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p],
     "lhg_recon_loss_backward": [_p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p],
+    "lhg_psnr_ssim_workspace": [_i, _i, _i],
+    "lhg_psnr_ssim": [_p, _p, _i, _i, _i, _p, _p, _sz, _p],
     "lhg_adam_step": [_p, _p, _p, _p, _ll, _f, _f, _f, _f, _i, _p],
 }
-_RESTYPE = {"lhg_last_error": C.c_char_p, "lhg_conv2d_thin_wgrad_workspace": C.c_size_t}
+_RESTYPE = {"lhg_last_error": C.c_char_p, "lhg_conv2d_thin_wgrad_workspace": C.c_size_t, "lhg_psnr_ssim_workspace": C.c_size_t}
 
 _lib = None
 

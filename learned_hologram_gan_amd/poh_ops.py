@@ -79,3 +79,20 @@ class ReconLossFn(Function):
         call("lhg_recon_loss_backward", ptr(ha), ptr(ta), ptr(hp), ptr(tp), B * Cc, H, W, ptr(sums), ptr(g.contiguous().float()),
              ptr(g_ha), ptr(g_hp), stream_ptr())
         return g_ha, None, g_hp, None
+
+
+def psnr_ssim(hat: torch.Tensor, target: torch.Tensor) -> torch.Tensor:
+    """(PSNR, SSIM) of torchmetrics' default configuration as a 2-element device tensor: three reduction launches and one tiled
+    separable-window kernel (csrc/metrics.hip), no host synchronisation.  ref: watermelon.py:134-135, 447-456."""
+    if not hat.is_cuda:
+        raise RuntimeError("psnr_ssim runs on the GPU only")
+    h, t = hat.detach().contiguous().float(), target.detach().contiguous().float()
+    if h.shape != t.shape or h.dim() < 2:
+        raise ValueError(f"psnr_ssim: shapes {tuple(h.shape)} vs {tuple(t.shape)}")
+    H, W = h.shape[-2], h.shape[-1]
+    planes = h.numel() // (H * W)
+    nbytes = int(native.load().lhg_psnr_ssim_workspace(planes, H, W))
+    ws = torch.empty((nbytes,), dtype=torch.uint8, device=h.device)
+    out = torch.empty((2,), dtype=torch.float32, device=h.device)
+    native.call("lhg_psnr_ssim", native.ptr(h), native.ptr(t), planes, H, W, native.ptr(out), native.ptr(ws), nbytes, native.stream_ptr())
+    return out

@@ -22,7 +22,7 @@ import torch.nn.functional as F
 from ..angular_spectrum_method import bandLimitedAngularSpectrumMethod_for_multiple_distances
 from ..distributed import GradSynchronizer, broadcast_module_state
 from ..optim import FlatParams, FusedAdam
-from ..poh_ops import ReconLossFn
+from ..poh_ops import ReconLossFn, psnr_ssim
 from ..utilities import try_gpu
 from .discriminator import WGANGPDiscriminator192, fakeDiscriminator
 from .generator import Generator
@@ -160,7 +160,10 @@ class watermelon:
 
     def record_metrics(self, hat_amps, target_amps, recorder=None):
         with torch.no_grad():
-            recorder += torch.stack([psnr(hat_amps, target_amps), ssim(hat_amps, target_amps)])
+            if hat_amps.is_cuda:  # fused HIP kernels (csrc/metrics.hip)
+                recorder += psnr_ssim(hat_amps, target_amps)
+            else:                 # host-side evaluation of the same definitions (used by the CPU tests of the definitions)
+                recorder += torch.stack([psnr(hat_amps, target_amps), ssim(hat_amps, target_amps)])
 
     def reconstruct(self, RGBD, target_amp, target_phs, plane_indices=None):
         """G forward + hat/target amplitude and phase at one plane per sample (watermelon.py:216-241)."""

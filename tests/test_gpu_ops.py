@@ -426,3 +426,21 @@ def test_conv2d_randomised_shape_sweep(ops):
         assert ld == Ci or xg.grad[..., Ci:].abs().max().item() == 0, tag
         assert rel_err(wg.grad.cpu(), wr.grad) < 5e-5, tag
         assert rel_err(bg.grad.cpu(), br.grad) < 5e-5, tag
+
+
+@pytest.mark.parametrize("shape", [(4, 3, 384, 384), (2, 3, 37, 53), (5, 1, 64, 12)])
+def test_psnr_ssim_kernels_match_definitions(shape):
+    """csrc/metrics.hip against the oracle's float64 restatement of the torchmetrics defaults and against the host-side expression."""
+    from learned_hologram_gan_amd.poh_ops import psnr_ssim
+    from learned_hologram_gan_amd.watermelon_hologram.watermelon import psnr, ssim
+    from oracle import losses
+
+    g = torch.Generator().manual_seed(11)
+    x = torch.rand(shape, generator=g)
+    y = (x + 0.15 * (torch.rand(shape, generator=g) - 0.4)).clamp(0, 1.4)
+    got = psnr_ssim(x.to(DEV), y.to(DEV)).cpu()
+    assert abs(got[0].item() - losses.psnr(x, y).item()) < 1e-3
+    assert abs(got[1].item() - losses.ssim(x, y).item()) < 2e-5
+    assert abs(got[1].item() - ssim(x, y).item()) < 2e-5 and abs(got[0].item() - psnr(x, y).item()) < 1e-3
+    same = psnr_ssim(x.to(DEV), x.to(DEV)).cpu()
+    assert abs(same[1].item() - 1.0) < 1e-6 and torch.isinf(same[0])
