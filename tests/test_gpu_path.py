@@ -833,3 +833,28 @@ def test_standalone_cpp_host_of_the_c_abi():
     assert os.path.exists(exe), "run python __graft_entry__.py first"
     res = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert res.returncode == 0 and "abi_demo ok" in res.stdout, res.stdout + res.stderr
+
+
+# ----------------------------------------------------------------------------- does it learn
+def test_training_reduces_the_loss_and_raises_psnr():
+    """60 steps of the reconstruction-only trainer (watermelon_without_GAN, as shipped in trainingModel.py) on four smooth synthetic
+    batches: the generator loss falls and the reconstruction PSNR rises (measured: 0.30 -> 0.11, 14.9 -> 18.8 dB)."""
+    from learned_hologram_gan_amd.poh_ops import psnr_ssim
+    from learned_hologram_gan_amd.watermelon_hologram.watermelon import watermelon_without_GAN
+
+    R = 64
+    torch.manual_seed(0)
+    W = watermelon_without_GAN(filter_radius_coefficient=0.45, pad_size=R // 2, distance_stack=torch.linspace(-4e-4, 0.0, 21)[:-1],
+                               input_shape=(1, 4, R, R))
+    W.generator.to(DEV).train()
+    W.configure(1, 0.0, 1, 1e-3, 1e-1, 1e-3, 1e-3, 0, 10)
+    batches = [tuple(t.to(DEV) for t in seeded.smooth_batch(4, R, R, seed=200 + i)) for i in range(4)]
+    first = last = None
+    for it in range(60):
+        out = W.train_step(*batches[it % 4])
+        if it < 4 or it >= 56:
+            rec = (out["G_loss"].item(), psnr_ssim(out["hat_amps"], out["target_amps"])[0].item())
+            first = rec if it == 0 else first
+            last = rec
+    assert all(map(lambda v: v == v, first + last))  # no NaN
+    assert last[0] < 0.6 * first[0] and last[1] > first[1] + 2.0, (first, last)
