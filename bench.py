@@ -51,6 +51,8 @@ def parse():
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
                     help="f32 (the benchmark metric): exact fp32 MFMA.  bf16 (BASELINE configs[2]/[4], informational): conv GEMM operands "
                          "rounded to bf16, fp32 accumulation, fp32 tensors")
+    ap.add_argument("--planes", type=int, default=0,
+                    help="infer mode: also propagate the hologram to this many planes (BASELINE configs[3]: inference + multi-plane propagate)")
     ap.add_argument("--mode", choices=("train", "infer"), default="train",
                     help="train: the GAN step (the benchmark metric); infer: eval-mode generator forward RGBD->POH only (informational)")
     return ap.parse_args()
@@ -116,6 +118,17 @@ def main():
     if args.mode == "infer":
         W.generator.eval()
         run = W.generator
+        if args.planes > 0:  # generatePOH.py --propagate: |crop(ifft2(fft2(pad(e^{i POH})) H(d) mask))| at `planes` distances
+            from learned_hologram_gan_amd.angular_spectrum_method import bandLimitedAngularSpectrumMethod_for_multiple_distances as Mu
+
+            dist_p = torch.linspace(4e-4, 10e-4, args.planes)
+            prop = Mu(sample_row_num=args.rows, sample_col_num=args.cols, distances=dist_p, pad_size=args.pad, filter_radius_coefficient=0.35,
+                      pixel_pitch=3.74e-6, wave_length=torch.tensor([638e-9, 520e-9, 450e-9]), band_limit=False, cuda=True)
+            gen = W.generator
+
+            def run(x):  # noqa: F811
+                poh = gen(x)
+                return prop(torch.ones_like(poh), poh, dist_p)
         if args.graph:
             from learned_hologram_gan_amd.graph import GraphedGenerator
 
@@ -136,6 +149,7 @@ def main():
                               "warmup": args.warmup, "ms_per_step": round(dt / args.steps * 1e3, 3), "higher_is_better": True,
                               "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                               "config": {"workload": f"{args.rows}x{args.cols}x3 bs={B} generator forward (UNet + ASM back-propagation + POH encode)"
+                                                     + (f" + propagation to {args.planes} planes" if args.planes > 0 else "")
                                                      + (", hipGraph replay" if args.graph else "")}}))
         return
 
