@@ -494,8 +494,9 @@ static int launch_gg(GGParams& p, hipStream_t st) {
   for (int t = 0; t < g.T; ++t) max_ws = std::max(max_ws, g.ws[t]);
   const unsigned long long in_bytes = (((unsigned long long)g.N * g.Hi * g.Wi - 1) * g.ldi + g.Ci) * 4ull;
   const unsigned long long wp_bytes = (unsigned long long)(max_ws + 1) * p.rows_pad * g.Ci * 4ull;
-  const bool small = in_bytes < (1ull << 32) - 64 && wp_bytes < (1ull << 32) - 64;
-  const unsigned ib = (unsigned)in_bytes, wb = (unsigned)wp_bytes;
+  const bool small = wp_bytes < (1ull << 32) - 64;  // the pipelined kernels window the gathered tensor per workgroup: any size
+  const unsigned long long ib = in_bytes;
+  const unsigned wb = (unsigned)wp_bytes;
   auto blocks = [&](int bm, int bn) { return (unsigned)(((g.M + bm - 1) / bm) * (p.rows_pad / bn)); };
   const bool n128 = p.rows_pad % 128 == 0;
 
@@ -542,8 +543,9 @@ static int launch_gg_bf16(GGParams& p, hipStream_t st) {
   for (int t = 0; t < g.T; ++t) max_ws = std::max(max_ws, g.ws[t]);
   const unsigned long long in_bytes = (((unsigned long long)g.N * g.Hi * g.Wi - 1) * g.ldi + g.Ci) * 4ull;
   const unsigned long long wp_bytes = (unsigned long long)(max_ws + 1) * p.rows_pad * g.Ci * 2ull;
-  LHG_REQUIRE(in_bytes < (1ull << 32) - 64 && wp_bytes < (1ull << 32) - 64, "gather-GEMM (bf16 mode): tensors of 4 GiB and more are not supported");
-  const unsigned ib = (unsigned)in_bytes, wb = (unsigned)wp_bytes;
+  LHG_REQUIRE(wp_bytes < (1ull << 32) - 64, "gather-GEMM (bf16 mode): weight panels of 4 GiB and more are not supported");
+  const unsigned long long ib = in_bytes;
+  const unsigned wb = (unsigned)wp_bytes;
   auto blocks = [&](int bm, int bn) { return (unsigned)(((g.M + bm - 1) / bm) * (p.rows_pad / bn)); };
   const bool n128 = p.rows_pad % 128 == 0;
   constexpr int NV = 3;
