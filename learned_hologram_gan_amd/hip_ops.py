@@ -338,7 +338,7 @@ class Conv2dFn(Function):
     ``out`` is None, an OutSlot, or the string "feeds_bn": the conv output goes straight into a train-mode
     BatchNorm, whose input-gradient has exactly zero mean per channel, so d loss / d bias == 0 analytically.
     The reference (and the generic path here) would compute rounding noise of ~1e-7 for it; it is returned as
-    exact zeros instead, which saves one full read of gy per such conv."""
+    exact zero (``None`` in a plain backward pass) instead, which saves one full read of gy per such conv."""
 
     @staticmethod
     def forward(ctx, x, w, bias, stride, out):
@@ -359,7 +359,9 @@ class Conv2dFn(Function):
         if ctx.needs_input_grad[1]:
             gw = _weight_grad(w, (x, gy), lambda: Conv2dWeightGradFn.apply(x, gy, w.shape, ctx.stride))
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = torch.zeros(w.shape[0], dtype=torch.float32, device=w.device) if ctx.bias_grad_is_zero else channel_sum(gy)
+            # exactly-zero gradient: None (autograd's zero) instead of a zero tensor saves a fill and an accumulate launch per layer
+            gb = None if (ctx.bias_grad_is_zero and not torch.is_grad_enabled()) else (
+                torch.zeros(w.shape[0], dtype=torch.float32, device=w.device) if ctx.bias_grad_is_zero else channel_sum(gy))
         return gx, gw, gb, None, None
 
 
