@@ -45,6 +45,9 @@ def main(args):
     from learned_hologram_gan_amd.watermelon_hologram.data_loader import dataloaderImgDepth
     from learned_hologram_gan_amd.watermelon_hologram.generator import Generator
 
+    from learned_hologram_gan_amd import hip_ops
+
+    hip_ops.apply_env_precision()  # LHG_CONV_PRECISION=bf16: bf16 operands in the conv GEMMs (the flags stay the reference's)
     dataset = dataloaderImgDepth(img_path=args.img_path, depth_path=args.depth_path, samplesNum=args.samplesNum, channlesNum=3,
                                  height=args.sample_row_num, width=args.sample_col_num, cuda=True)
     wave_length = torch.tensor(args.wave_length)

@@ -195,6 +195,14 @@ def conv_precision() -> str:
     return "bf16" if _precision else "fp32"
 
 
+def apply_env_precision() -> None:
+    """LHG_CONV_PRECISION=bf16 selects the bf16 operand mode for programs whose flags must stay the reference's (trainingModel.py,
+    generatePOH.py).  Called by the trainer / generator constructors."""
+    want = os.environ.get("LHG_CONV_PRECISION")
+    if want and _PRECISIONS.get(want, _precision) != _precision:
+        set_conv_precision(want)
+
+
 # --------------------------------------------------------------------------- weight packing
 def pack_weight(w: torch.Tensor, rows_from_d0: bool, k_pad_to: int = 32) -> torch.Tensor:
     """OIHW / IOHW -> [KH*KW][rows_pad][k_pad] panels (lhg_pack_weight).

@@ -43,6 +43,9 @@ def train_gan(a):
     from learned_hologram_gan_amd.watermelon_hologram.watermelon import watermelon_without_GAN as watermelon  # as shipped (trainingModel.py:4)
 
     rank, world, _ = distributed.init_from_env()
+    from learned_hologram_gan_amd import hip_ops
+
+    hip_ops.apply_env_precision()  # LHG_CONV_PRECISION=bf16: bf16 operands in the conv GEMMs (the flags stay the reference's)
     utilities.set_seed(122731 + rank)
 
     def dataset(prefix, n):
