@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
                     help="f32 (the benchmark metric): exact fp32 MFMA.  bf16 (BASELINE configs[2]/[4], informational): conv GEMM operands "
                          "rounded to bf16, fp32 accumulation, fp32 tensors")
+    ap.add_argument("--perceptual", type=float, default=0.0,
+                    help="weight of the VGG19 perceptual term (reference CLI: 0.1; seeded random VGG weights: throughput only).  The benchmark "
+                         "metric follows BASELINE.md's assembled step, which has no VGG term")
     ap.add_argument("--planes", type=int, default=0,
                     help="infer mode: also propagate the hologram to this many planes (BASELINE configs[3]: inference + multi-plane propagate)")
     ap.add_argument("--mode", choices=("train", "infer"), default="train",
@@ -99,10 +102,20 @@ def main():
     bf16 = args.dtype == "bf16"
     mfma_peak = 2500.0 if bf16 else FP32_MFMA_PEAK_TFLOPS  # dense bf16 MFMA peak (MI355X_MICROARCH.md) / fp32 MFMA peak
     stack = torch.linspace(-4e-4, 0.0, 21)[:-1]  # trainingModel.py:62
-    W = watermelon(filter_radius_coefficient=0.45, pad_size=args.pad, distance_stack=stack, input_shape=(1, 4, args.rows, args.cols))
+    perceptual = None
+    if args.perceptual > 0:
+        import warnings
+
+        from learned_hologram_gan_amd.watermelon_hologram.perceptual import perceptualLoss
+
+        with warnings.catch_warnings():
+            warnings.simplefilter("ignore")
+            perceptual = perceptualLoss()
+    W = watermelon(filter_radius_coefficient=0.45, pad_size=args.pad, distance_stack=stack, input_shape=(1, 4, args.rows, args.cols),
+                   perceptual_loss=perceptual)
     W.generator.to(dev).train()
     W.discriminator.to(dev).train()
-    W.configure(phs_gradient_loss_weight=1, perceptual_loss_weight=0.0, pixel_loss_weight=1, TV_loss_weight=1e-3,
+    W.configure(phs_gradient_loss_weight=1, perceptual_loss_weight=args.perceptual, pixel_loss_weight=1, TV_loss_weight=1e-3,
                 discriminator_loss_weight=1e-1, lr_G=1e-3, lr_D=1e-3, discriminator_train_ratio=args.d_ratio, discriminator_lambda=10)
     g = torch.Generator().manual_seed(122731 + rank)
     B = args.batch
@@ -205,7 +218,8 @@ def main():
             "dtype": args.dtype,
             "data": "synthetic random RGBD / target amplitude+phase in [0,1), reference-style random-init weights",
             "config": {"workload": f"{args.rows}x{args.cols}x3 bs={B}/GPU generator+critic train step (d_ratio={args.d_ratio}, "
-                                   f"lambda_gp=10, pad {args.pad} -> {args.rows + 2 * args.pad}^2 FFTs, 20-plane stack, no VGG term), "
+                                   f"lambda_gp=10, pad {args.pad} -> {args.rows + 2 * args.pad}^2 FFTs, 20-plane stack, "
+                                   + (f"VGG19 perceptual term x{args.perceptual} with random weights" if args.perceptual > 0 else "no VGG term") + "), "
                                    + ("bf16 conv-GEMM operands, fp32 accumulation / tensors / FFT (informational)" if bf16 else "fp32"),
                        "global_batch": B * world, "parallelism": f"dp{world}"},
             "roofline": {
