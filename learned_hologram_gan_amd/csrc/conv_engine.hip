@@ -548,13 +548,17 @@ static int launch_gg_bf16(GGParams& p, hipStream_t st) {
   const unsigned wb = (unsigned)wp_bytes;
   auto blocks = [&](int bm, int bn) { return (unsigned)(((g.M + bm - 1) / bm) * (p.rows_pad / bn)); };
   const bool n128 = p.rows_pad % 128 == 0;
-  constexpr int NV = 3;
-  auto valid = [&](int v) { return v == 0 ? n128 : true; };
+  constexpr int NV = 6;  // 0..2: 32-k steps; 3..5: 64-k steps (half the barriers and address arithmetic per flop; Ci % 64 == 0)
+  const bool k64 = g.Ci % 64 == 0;
+  auto valid = [&](int v) { return (v % 3 == 0 ? n128 : true) && (v < 3 || k64); };
   auto run = [&](int v) {
     switch (v) {
       case 0: hipLaunchKernelGGL((gg2b_kernel<128, 128, 2, 2>), dim3(blocks(128, 128)), dim3(256), 0, st, p, ib, wb); break;
       case 1: hipLaunchKernelGGL((gg2b_kernel<128, 64, 2, 2>), dim3(blocks(128, 64)), dim3(256), 0, st, p, ib, wb); break;
-      default: hipLaunchKernelGGL((gg2b_kernel<64, 64, 2, 2>), dim3(blocks(64, 64)), dim3(256), 0, st, p, ib, wb); break;
+      case 2: hipLaunchKernelGGL((gg2b_kernel<64, 64, 2, 2>), dim3(blocks(64, 64)), dim3(256), 0, st, p, ib, wb); break;
+      case 3: hipLaunchKernelGGL((gg2b_kernel<128, 128, 2, 2, 64>), dim3(blocks(128, 128)), dim3(256), 0, st, p, ib, wb); break;
+      case 4: hipLaunchKernelGGL((gg2b_kernel<128, 64, 2, 2, 64>), dim3(blocks(128, 64)), dim3(256), 0, st, p, ib, wb); break;
+      default: hipLaunchKernelGGL((gg2b_kernel<64, 64, 2, 2, 64>), dim3(blocks(64, 64)), dim3(256), 0, st, p, ib, wb); break;
     }
   };
   static const int forced = [] { const char* e = getenv("LHG_GGB_VARIANT"); return e ? atoi(e) : -1; }();
