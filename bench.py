@@ -199,7 +199,7 @@ def main():
         gg, wg = prof.result
         traffic = None  # HBM bytes per gather-GEMM launch from the committed PMC passes (tools/pmc_traffic.py)
         try:
-            with open(os.path.join(REPO, "profiles", "r01_pmc_traffic_v2.json")) as f:
+            with open(os.path.join(REPO, "profiles", "r01_pmc_traffic_v3.json")) as f:
                 traffic = json.load(f)["kernels"]["gg"]["hbm_bytes_per_launch_corrected"]
         except (OSError, KeyError, ValueError):
             pass
