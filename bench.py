@@ -9,20 +9,29 @@ forward, fused angular-spectrum reconstruction of hat/target at one random plane
 `d_ratio` critic updates with the gradient penalty (double backward), generator loss + backward,
 both Adam updates — on BASELINE.json configs[1]: 384x384x3, batch 4 per GPU, fp32, synthetic
 random-RGBD inputs resident in HBM, reference-style random-init weights.  Weak scaling: every rank
-runs the same per-GPU batch and gradients are averaged over RCCL.
+runs the same per-GPU batch and gradients are averaged over RCCL (all-reduce overlapped with backward).
 
-Prints ONE JSON line (rank 0).  `roofline` is for the dominant kernel (the MFMA gather-GEMM behind
-every convolution / input-gradient): achieved = algorithmic conv FLOPs it executed / its summed
-launch duration, both measured live over the timed region with HIP events on the launch stream.
-`cpu_baseline` times the CPU oracle (a port of the reference step, oracle/step.py) on the host
-cores for a bounded sample (one frame).
+Prints ONE JSON line (rank 0).
+* The TIMED REGION is un-instrumented: W warm-up steps, barrier + synchronize, K steps, barrier + synchronize, max over ranks.
+* `roofline` (dominant kernel: the MFMA gather-GEMM behind every convolution / input-gradient / conv-transpose) comes from a SEPARATE
+  pass over the same workload right after the timed region, with HIP events recorded on the launch stream around every launch:
+  achieved = algorithmic conv FLOPs the kernel executed / its summed launch durations.  The headline figure is measured under the
+  timed region's conditions (weight-gradient GEMMs running concurrently on the second stream, so durations include time sharing
+  the GPU); `roofline.isolated` repeats it with the second stream off (the kernel's own duration — what rocprofv3 --kernel-trace
+  shows, since the profiler serialises dispatches).
+* `secondary` carries north_star's second target: 4K (3840x2160) batch-1 inference + propagation of the hologram to 8 planes.
+* `cpu_baseline` times the CPU oracle (a port of the reference step, oracle/step.py) on the host cores: 1 warm-up + median of 3
+  runs of a bounded sample.
 """
 
 from __future__ import annotations
 
 import argparse
+import glob
+import hashlib
 import json
 import os
+import statistics
 import sys
 import time
 
@@ -33,6 +42,8 @@ if REPO not in sys.path:
     sys.path.insert(0, REPO)
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md, chip-level parameters)
+BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (same table)
+KERNEL_SOURCES = ("conv_engine.hip", "gg2_kernel.inc", "gg2b_kernel.inc", "wg2_kernel.inc", "wg2b_kernel.inc", "wg3_kernel.inc")
 
 
 def parse():
@@ -47,10 +58,12 @@ def parse():
     ap.add_argument("--d-ratio", type=int, default=1, help="critic updates per generator update (BASELINE.md assembled step: 1)")
     ap.add_argument("--cpu-baseline", type=int, default=1, help="0 skips the CPU oracle timing")
     ap.add_argument("--cpu-rows", type=int, default=0, help="frame size of the CPU sample (0 = same as --rows)")
+    ap.add_argument("--secondary", type=int, default=1, help="0 skips the 4K inference leg (north_star's second target)")
+    ap.add_argument("--profile-steps", type=int, default=5, help="steps of each instrumented pass behind `roofline`")
     ap.add_argument("--graph", type=int, default=0, help="infer mode: replay a captured hipGraph instead of eager launches")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
-                    help="f32 (the benchmark metric): exact fp32 MFMA.  bf16 (BASELINE configs[2]/[4], informational): conv GEMM operands "
-                         "rounded to bf16, fp32 accumulation, fp32 tensors")
+                    help="f32 (the benchmark metric): exact fp32 MFMA.  bf16 (BASELINE configs[2]/[4], informational): bf16 conv-GEMM operands, "
+                         "fp32 accumulation")
     ap.add_argument("--perceptual", type=float, default=0.0,
                     help="weight of the VGG19 perceptual term (reference CLI: 0.1; seeded random VGG weights: throughput only).  The benchmark "
                          "metric follows BASELINE.md's assembled step, which has no VGG term")
@@ -61,8 +74,33 @@ def parse():
     return ap.parse_args()
 
 
+def kernel_source_sha16():
+    h = hashlib.sha256()
+    for name in KERNEL_SOURCES:
+        with open(os.path.join(REPO, "learned_hologram_gan_amd", "csrc", name), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def pmc_traffic():
+    """HBM bytes per gather-GEMM launch from the newest committed PMC passes (tools/pmc_traffic.py), with the revision they belong to."""
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_pmc_traffic*.json")))
+    for path in reversed(files):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            src = {"file": os.path.relpath(path, REPO), "git_sha": d.get("git_sha"), "kernel_src_sha16": d.get("kernel_src_sha16")}
+            src["matches_this_build"] = d.get("kernel_src_sha16") == kernel_source_sha16()
+            return d["kernels"]["gg"]["hbm_bytes_per_launch_corrected"], src
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
+
+
 def cpu_baseline(args):
-    """One frame of the same step through the CPU oracle (checker code timed as the reported baseline)."""
+    """The same train step through the CPU oracle (checker code timed as the reported baseline): 1 warm-up + median of 3 runs
+    (BASELINE.md §3).  Sample: ONE frame (batch 1) — a batch-4 step costs ~4x as much on the CPU (no batch economy there), which would
+    push the default run past the 10-30 s the baseline leg may use; frames/s is per frame either way."""
     from oracle import seeded, step
 
     # the GPU box gives one GPU a 16-CPU share although it reports every core of the host
@@ -74,20 +112,83 @@ def cpu_baseline(args):
     st = step.make_state(rows, cols, args.pad, 0.45, stack, seeded.generator_state_dict(), seeded.critic_state_dict())
     rgbd, amp, phs = seeded.synthetic_batch(1, rows, cols)
     w = step.LossWeights(d_ratio=args.d_ratio)
-    t0 = time.perf_counter()
-    step.train_step(st, rgbd, amp, phs, w, torch.tensor([7]), [torch.full((1, 1, 1, 1), 0.5) for _ in range(max(args.d_ratio, 1))])
-    dt = time.perf_counter() - t0
+    times = []
+    for _ in range(4):
+        t0 = time.perf_counter()
+        step.train_step(st, rgbd, amp, phs, w, torch.tensor([7]), [torch.full((1, 1, 1, 1), 0.5) for _ in range(max(args.d_ratio, 1))])
+        times.append(time.perf_counter() - t0)
+    dt = statistics.median(times[1:])
     return {"value": round(1.0 / dt, 5), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 frame {rows}x{cols} (batch 1), one full train step (G fwd+bwd, {args.d_ratio} critic update(s) with gradient "
-                      f"penalty, Adam x2) through oracle/step.py, {dt:.1f} s"}
+            "sample": f"1 frame {rows}x{cols} (batch 1) per run, one full train step (G fwd+bwd, {args.d_ratio} critic update(s) with gradient "
+                      f"penalty, Adam x2) through oracle/step.py; 1 warm-up ({times[0]:.1f} s) + median of 3 runs ({dt:.2f} s)"}
+
+
+def roofline_block(res, steps, peak):
+    gg, wg = res
+    rate = lambda r: r["algorithmic_flops"] / (r["total_ms"] * 1e-3) / 1e12 if r["total_ms"] > 0 else 0.0  # noqa: E731
+    a = rate(gg)
+    return {"achieved": round(a, 3), "frac": round(a / peak, 4),
+            "algorithmic_flop_per_launch": round(gg["algorithmic_flops"] / max(gg["launches"], 1)),
+            "launches_per_step": gg["launches"] / steps,
+            "avg_launch_us": round(gg["total_ms"] * 1e3 / max(gg["launches"], 1), 2),
+            "algorithmic_gflop_per_step": round(gg["algorithmic_flops"] / steps / 1e9, 2),
+            "executed_gflop_per_step": round(gg["executed_flops"] / steps / 1e9, 2),
+            "kernel_ms_per_step": round(gg["total_ms"] / steps, 3),
+            "wgrad_kernel": {"achieved": round(rate(wg), 3), "unit": "TFLOP/s", "kernel_ms_per_step": round(wg["total_ms"] / steps, 3),
+                             "algorithmic_gflop_per_step": round(wg["algorithmic_flops"] / steps / 1e9, 2)}}
+
+
+def secondary_4k(native, dev, world, sync, peak, planes=8, warmup=2, steps=5):
+    """north_star's second target: RGBD -> POH for one 3840x2160 frame (batch 1, pad 72 -> 2304x4096 transforms) + the hologram
+    propagated to `planes` planes (generatePOH.py --propagate).  Replicas only across GPUs (one frame per GPU)."""
+    from learned_hologram_gan_amd.angular_spectrum_method import bandLimitedAngularSpectrumMethod_for_multiple_distances as Mu
+    from learned_hologram_gan_amd.watermelon_hologram.generator import Generator
+
+    rows, cols, pad = 2160, 3840, 72
+    wl = torch.tensor([638e-9, 520e-9, 450e-9])
+    G = Generator(rows, cols, pad, 0.45, 3, 3.74e-6, wl, torch.tensor([1e-3])).to(dev).eval()
+    d = torch.linspace(4e-4, 10e-4, planes)
+    prop = Mu(sample_row_num=rows, sample_col_num=cols, distances=d, pad_size=pad, filter_radius_coefficient=0.35, pixel_pitch=3.74e-6,
+              wave_length=wl, band_limit=False, cuda=True)
+    x = torch.rand((1, 4, rows, cols), generator=torch.Generator().manual_seed(5)).to(dev)
+
+    def run():
+        poh = G(x)
+        return prop(torch.ones_like(poh), poh, d)
+
+    with torch.no_grad():
+        for _ in range(warmup):
+            run()
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run()
+        sync()
+        dt = time.perf_counter() - t0
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        if world > 1:
+            torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = t.item()
+        with native.kernel_profile() as prof:
+            for _ in range(steps):
+                run()
+            torch.cuda.synchronize()
+    gg = prof.result[0]
+    a = gg["algorithmic_flops"] / (gg["total_ms"] * 1e-3) / 1e12 if gg["total_ms"] > 0 else 0.0
+    return {"metric": "RGBD->POH frames/sec at 3840x2160 bs=1 (eval-mode generator + propagation to 8 planes)",
+            "value": round(world * steps / dt, 4), "unit": "frames/s", "ms_per_frame": round(dt / steps * 1e3, 3), "steps": steps, "warmup": warmup,
+            "config": {"workload": f"{cols}x{rows}x3 bs=1/GPU generator forward (UNet + ASM back-propagation + POH encode, pad {pad} -> "
+                                   f"{rows + 2 * pad}x{cols + 2 * int(pad * cols / rows)} transforms) + {planes}-plane propagate; replicas only"},
+            "roofline": {"kernel": "gather-GEMM (the frame's 12.89 TFLOP of convolutions)", "bound": "mfma", "achieved": round(a, 3), "peak": peak,
+                         "unit": "TFLOP/s", "frac": round(a / peak, 4), "traffic": None,
+                         "kernel_ms_per_frame": round(gg["total_ms"] / steps, 3),
+                         "algorithmic_gflop_per_frame": round(gg["algorithmic_flops"] / steps / 1e9, 1)}}
 
 
 def main():
     args = parse()
-    from learned_hologram_gan_amd import distributed, native
+    from learned_hologram_gan_amd import distributed, hip_ops, native
     from learned_hologram_gan_amd.watermelon_hologram.watermelon import watermelon
-
-    from learned_hologram_gan_amd import hip_ops
 
     rank, world, local = distributed.init_from_env()
     if world != args.gpus and world > 1:
@@ -100,7 +201,7 @@ def main():
     if args.dtype == "bf16":
         hip_ops.set_conv_precision("bf16")
     bf16 = args.dtype == "bf16"
-    mfma_peak = 2500.0 if bf16 else FP32_MFMA_PEAK_TFLOPS  # dense bf16 MFMA peak (MI355X_MICROARCH.md) / fp32 MFMA peak
+    mfma_peak = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
     stack = torch.linspace(-4e-4, 0.0, 21)[:-1]  # trainingModel.py:62
     perceptual = None
     if args.perceptual > 0:
@@ -166,46 +267,54 @@ def main():
                                                      + (", hipGraph replay" if args.graph else "")}}))
         return
 
+    # ---- the timed region: no instrumentation of any kind
     for _ in range(args.warmup):
         W.train_step(rgbd, tamp, tphs)
     sync()
-    with native.kernel_profile() as prof:
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            W.train_step(rgbd, tamp, tphs)
-        sync()
-        elapsed = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        W.train_step(rgbd, tamp, tphs)
+    sync()
+    elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
     if world > 1:
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
     elapsed = t.item()
 
-    # The weight-gradient GEMMs run on a second stream, concurrently with the gather-GEMMs and the HBM-bound kernels of the main
-    # stream, so the per-launch durations measured above include time spent sharing the GPU.  A few extra steps with that overlap
-    # switched off (outside the timed region) give the kernels' own rates, reported as roofline["isolated"].
+    # ---- roofline passes (every rank: the steps contain collectives).  Pass 1: the timed region's conditions.  Pass 2: second stream off.
+    P = max(1, min(args.steps, args.profile_steps))
+    with native.kernel_profile() as prof:
+        for _ in range(P):
+            W.train_step(rgbd, tamp, tphs)
+        torch.cuda.synchronize()
     iso = None
-    if hip_ops.SIDE_WGRAD:  # every rank: the steps contain collectives
+    if hip_ops.SIDE_WGRAD:
         hip_ops.SIDE_WGRAD = False
         W.train_step(rgbd, tamp, tphs)
         torch.cuda.synchronize()
         with native.kernel_profile() as prof_iso:
-            for _ in range(min(args.steps, 5)):
+            for _ in range(P):
                 W.train_step(rgbd, tamp, tphs)
             torch.cuda.synchronize()
         hip_ops.SIDE_WGRAD = True
         iso = prof_iso.result
 
+    out = None
     if rank == 0:
-        gg, wg = prof.result
-        traffic = None  # HBM bytes per gather-GEMM launch from the committed PMC passes (tools/pmc_traffic.py)
-        try:
-            with open(os.path.join(REPO, "profiles", "r01_pmc_traffic_v3.json")) as f:
-                traffic = json.load(f)["kernels"]["gg"]["hbm_bytes_per_launch_corrected"]
-        except (OSError, KeyError, ValueError):
-            pass
-        achieved = gg["algorithmic_flops"] / (gg["total_ms"] * 1e-3) / 1e12 if gg["total_ms"] > 0 else 0.0
+        traffic, traffic_src = (None, None) if bf16 else pmc_traffic()
+        r = {"kernel": "lhg::gg2b_kernel (MFMA bf16 gather-GEMM)" if bf16 else
+                       "lhg::gg2_kernel / gg_kernel (MFMA fp32 gather-GEMM: conv forward / input-gradient / conv-transpose)",
+             "bound": "mfma", "peak": mfma_peak, "unit": "TFLOP/s", "traffic": traffic, "traffic_source": traffic_src}
+        r.update(roofline_block(prof.result, P, mfma_peak))
+        r["measured"] = (f"HIP events around every launch over {P} steps of the same workload right after the (un-instrumented) timed region, "
+                         "under its conditions: weight-gradient GEMMs run concurrently on a second HIP stream, so launch durations include "
+                         "time sharing the GPU")
+        if iso is not None:
+            r["isolated"] = roofline_block(iso, P, mfma_peak)
+            r["isolated"]["measured"] = (f"{P} more steps with the second stream off: the kernel's own duration (what rocprofv3 --kernel-trace "
+                                         "reports, since it serialises dispatches)")
         out = {
-            "metric": "RGBD->POH frames/sec at 384x384 bs=4 (GAN train step)",
+            "metric": "RGBD->POH frames/sec at 384x384 bs=4 (GAN train step)" + (" [bf16 mode, informational]" if bf16 else ""),
             "value": round(B * world * args.steps / elapsed, 4),
             "unit": "frames/s",
             "n_gpus": world,
@@ -220,45 +329,20 @@ def main():
             "config": {"workload": f"{args.rows}x{args.cols}x3 bs={B}/GPU generator+critic train step (d_ratio={args.d_ratio}, "
                                    f"lambda_gp=10, pad {args.pad} -> {args.rows + 2 * args.pad}^2 FFTs, 20-plane stack, "
                                    + (f"VGG19 perceptual term x{args.perceptual} with random weights" if args.perceptual > 0 else "no VGG term") + "), "
-                                   + ("bf16 conv-GEMM operands, fp32 accumulation / tensors / FFT (informational)" if bf16 else "fp32"),
+                                   + ("bf16 conv-GEMM operands, fp32 accumulation / BatchNorm / FFT / Adam (informational)" if bf16 else "fp32"),
                        "global_batch": B * world, "parallelism": f"dp{world}"},
-            "roofline": {
-                "kernel": "lhg::gg2b_kernel (MFMA bf16 gather-GEMM)" if bf16 else
-                          "lhg::gg_kernel (MFMA fp32 gather-GEMM: conv forward / input-gradient / conv-transpose)",
-                "bound": "mfma", "achieved": round(achieved, 3), "peak": mfma_peak, "unit": "TFLOP/s",
-                "frac": round(achieved / mfma_peak, 4), "traffic": None if bf16 else traffic,
-                "algorithmic_flop_per_launch": round(gg["algorithmic_flops"] / max(gg["launches"], 1)),
-                "launches_per_step": gg["launches"] / args.steps,
-                "avg_launch_us": round(gg["total_ms"] * 1e3 / max(gg["launches"], 1), 2),
-                "algorithmic_gflop_per_step": round(gg["algorithmic_flops"] / args.steps / 1e9, 2),
-                "executed_gflop_per_step": round(gg["executed_flops"] / args.steps / 1e9, 2),
-                "kernel_ms_per_step": round(gg["total_ms"] / args.steps, 3),
-                "wgrad_kernel": {"achieved": round(wg["algorithmic_flops"] / max(wg["total_ms"], 1e-9) / 1e9, 3), "unit": "TFLOP/s",
-                                 "kernel_ms_per_step": round(wg["total_ms"] / args.steps, 3),
-                                 "algorithmic_gflop_per_step": round(wg["algorithmic_flops"] / args.steps / 1e9, 2)},
-            },
+            "roofline": r,
         }
-        if iso is not None:
-            # headline roofline = the kernel's own rate (second stream off: durations are not shared with a concurrent GEMM; this is also
-            # what rocprofv3 --kernel-trace reports, since it serialises dispatches); the figures of the timed region go underneath
-            ig, iw = iso
-            k = min(args.steps, 5)
-            ia = ig["algorithmic_flops"] / (ig["total_ms"] * 1e-3) / 1e12 if ig["total_ms"] > 0 else 0.0
-            r = out["roofline"]
-            r["timed_region"] = {"achieved": r["achieved"], "frac": r["frac"], "avg_launch_us": r["avg_launch_us"],
-                                 "kernel_ms_per_step": r["kernel_ms_per_step"], "wgrad_kernel_achieved": r["wgrad_kernel"]["achieved"],
-                                 "note": "weight-gradient GEMMs run on a second HIP stream concurrently with this kernel: launch durations "
-                                         "include time sharing the GPU"}
-            r.update({"achieved": round(ia, 3), "frac": round(ia / mfma_peak, 4),
-                      "avg_launch_us": round(ig["total_ms"] * 1e3 / max(ig["launches"], 1), 2),
-                      "kernel_ms_per_step": round(ig["total_ms"] / k, 3),
-                      "measured": f"HIP events around every launch over {k} steps of the same workload right after the timed region, second stream "
-                                  "off (kernel's own duration)"})
-            r["wgrad_kernel"] = {"achieved": round(iw["algorithmic_flops"] / max(iw["total_ms"], 1e-9) / 1e9, 3), "unit": "TFLOP/s",
-                                 "kernel_ms_per_step": round(iw["total_ms"] / k, 3),
-                                 "algorithmic_gflop_per_step": round(iw["algorithmic_flops"] / k / 1e9, 2)}
-        if bf16:
-            out["metric"] += " [bf16 operand mode, informational]"
+
+    # ---- free the trainer, then north_star's second target (4K bs=1 inference + 8 planes), replicas only
+    sec = None
+    if args.secondary and not bf16:
+        del W
+        torch.cuda.empty_cache()
+        sec = secondary_4k(native, dev, world, sync, mfma_peak)
+    if rank == 0:
+        if sec is not None:
+            out["secondary"] = sec
         if world == 1 and args.cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
         print(json.dumps(out), flush=True)

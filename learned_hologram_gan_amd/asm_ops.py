@@ -125,14 +125,17 @@ def propagate_raw(a, b, spec: Spec, want_complex_copy=False):
     if tuple(a.shape[-2:]) != (g.rows0, g.cols0):
         raise ValueError(f"field has extent {tuple(a.shape[-2:])}, geometry says {(g.rows0, g.cols0)}")
     dev = a.device
+    # contiguous copies are bound to locals that live until after the launch: a temporary's block could be handed to the
+    # workspace / output allocations below and be overwritten while the kernel still reads it
     a = a.contiguous()
+    b = b.contiguous() if b is not None else None
     if spec.in_mode == IN_COMPLEX:
         if a.dtype != torch.complex64:
             raise TypeError("IN_COMPLEX needs complex64")
         pa, pb = ptr(torch.view_as_real(a)), None
     else:
         pa = ptr(a)
-        pb = ptr(b.contiguous()) if b is not None else None
+        pb = ptr(b) if b is not None else None
         if spec.in_mode == IN_POLAR and b is None:
             raise ValueError("IN_POLAR needs amplitude and phase")
     st, keep = _filter_struct(spec.factors, planes, g)
@@ -160,10 +163,11 @@ def to_spectrum_raw(a, b, spec: Spec):
         planes *= d
     dev = a.device
     a = a.contiguous()
+    b = b.contiguous() if b is not None else None  # kept alive until after the launch (see propagate_raw)
     if spec.in_mode == IN_COMPLEX:
         pa, pb = ptr(torch.view_as_real(a)), None
     else:
-        pa, pb = ptr(a), (ptr(b.contiguous()) if b is not None else None)
+        pa, pb = ptr(a), (ptr(b) if b is not None else None)
     st, keep = _filter_struct(spec.factors, planes, g)
     ws, nbytes = _workspace(planes, g, dev, 1)
     out = torch.empty(tuple(lead) + (g.rows, g.cols), dtype=torch.complex64, device=dev)

@@ -1,7 +1,7 @@
 // PSNR and SSIM of reconstructed amplitudes against the targets, as recorded every batch by the reference's training and
 // validation loops (watermelon.py:134-135, 447-456: torchmetrics PeakSignalNoiseRatio() / StructuralSimilarityIndexMeasure()
 // with their defaults; torchmetrics itself is not vendored in the reference, so its published definitions are restated):
-//   PSNR = 10 log10( (max t - min t)^2 / mean (h - t)^2 )                      over the whole batch tensor
+//   PSNR = 10 log10( (max(max t, 0) - min(min t, 0))^2 / mean (h - t)^2 )                      over the whole batch tensor
 //   SSIM : 11x11 Gaussian window (sigma 1.5), data range L = max(range h, range t), c1 = (0.01 L)^2, c2 = (0.03 L)^2,
 //          the map is kept where the window lies inside the image (the reflect padding of the definition only reaches the
 //          5-pixel border that it crops away again) and averaged over all kept pixels of all planes.
@@ -139,7 +139,8 @@ __global__ __launch_bounds__(64) void metric_final_kernel(const double* __restri
   for (int b = threadIdx.x; b < nblk; b += 64) s += part[b];
   s = wave_sum(s);
   if (threadIdx.x == 0) {
-    const double range_t = (double)scal[3] - (double)scal[2];
+    // torchmetrics keeps min_target / max_target states that start at 0.0: range = max(max t, 0) - min(min t, 0)
+    const double range_t = fmax((double)scal[3], 0.0) - fmin((double)scal[2], 0.0);
     out2[0] = (float)(10.0 * log10(range_t * range_t / (*sse_total / n_total)));
     out2[1] = (float)(s / n_kept);
   }

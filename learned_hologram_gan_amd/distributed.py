@@ -54,22 +54,29 @@ def broadcast_module_state(module: torch.nn.Module, flat_data: torch.Tensor | No
 
 
 class GradSynchronizer:
-    """Average the gradients held in one flat buffer across ranks.
+    """Average the gradients held in one flat buffer across ranks, overlapped with backward.
 
-    The flat gradient buffer (optim.FlatParams.grad) is cut into ``n_buckets`` contiguous
-    buckets in REVERSE parameter order (the last layers' gradients are produced first by
-    backward).  A post-accumulate hook on every parameter counts arrivals; when a bucket is
-    complete its all-reduce is launched asynchronously — on RCCL that runs on the communicator's
-    own stream, overlapping the rest of backward.  ``finish()`` waits and divides by the world
-    size.  xGMI is point-to-point (7 links x ~153 GB/s per GPU), so a few large buckets
-    (tens of MB) are preferred over many small ones.
+    The flat gradient buffer (optim.FlatParams.grad) is cut into ``n_buckets`` contiguous buckets in REVERSE parameter order (the
+    last layers' gradients are produced first by backward).  A bucket's all-reduce is launched — asynchronously, from inside
+    backward — as soon as the gradient of its last parameter has been ENQUEUED.  Two kinds of arrival feed that count:
+
+    * gradients that autograd accumulates (BatchNorm affine parameters, non-zero biases): a post-accumulate hook;
+    * gradients that never pass through autograd (hip_ops._weight_grad accumulates conv / conv-transpose weight gradients straight
+      into the flat buffer from the weight-gradient stream and hands autograd ``None``; biases in front of a train-mode BatchNorm
+      have an exactly-zero gradient): hip_ops counts the recorded uses of the parameter and calls the listener registered here when
+      the last contribution has been enqueued.
+
+    On the GPU the collective is issued with the weight-gradient stream current, after that stream has been made to wait for the main
+    stream's work so far: RCCL's stream then starts the reduction behind this bucket's last weight-gradient GEMM while both compute
+    streams carry on with the rest of backward.  ``finish()`` launches what is left, waits and divides by the world size.  xGMI is
+    point-to-point (7 links x ~153 GB/s per GPU), so a few large buckets (tens of MB) are preferred over many small ones.
+    Every rank records the same graph, so buckets complete — and collectives are issued — in the same order everywhere.
     """
 
     def __init__(self, params, offsets, flat_grad: torch.Tensor, n_buckets: int = 4, group=None):
         self.params, self.flat_grad, self.group = list(params), flat_grad, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         n = len(self.params)
-        ends = [offsets[i + 1] if i + 1 < n else flat_grad.numel() for i in range(n)]
         total = flat_grad.numel()
         target = max(1, total // max(1, n_buckets))
         # walk parameters from last to first, closing a bucket every `target` elements
@@ -83,38 +90,69 @@ class GradSynchronizer:
                 self.ranges.append((lo, hi))
                 self.expected.append(count)
                 hi, count, b = lo, 0, b + 1
-        del ends
         self._arrived = [0] * len(self.ranges)
+        self._seen = [False] * n
+        self._launched = [False] * len(self.ranges)
         self._work = []
         self._hooks = []
+        self.launch_log = []  # (bucket, hip_ops.CONTRIBUTIONS at launch, launched from finish()?) of the last pass: read by the tests
         self.enabled = self.world > 1
         if self.enabled:
+            from . import hip_ops
+
             for i, p in enumerate(self.params):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+                hip_ops.set_arrival_listener(p, self._make_listener(i))
+
+    def _arrive(self, i):
+        if not self._armed:
+            return
+        b = self.bucket_of[i]
+        if self._seen[i]:
+            return
+        if self._launched[b]:
+            raise RuntimeError("a gradient arrived for a bucket whose all-reduce had already been launched: a parameter received "
+                               "contributions both through autograd and through the flat-buffer path in one backward pass")
+        self._seen[i] = True
+        self._arrived[b] += 1
+        if self._arrived[b] == self.expected[b]:
+            self._launch(b, False)
 
     def _make_hook(self, i):
-        def hook(_param):
-            if not self._armed:
-                return
-            b = self.bucket_of[i]
-            self._arrived[b] += 1
-            if self._arrived[b] == self.expected[b]:
-                self._launch(b)
-        return hook
+        return lambda _param: self._arrive(i)
+
+    def _make_listener(self, i):
+        return lambda: self._arrive(i)
 
     _armed = False
 
-    def _launch(self, b):
+    def _launch(self, b, from_finish):
         lo, hi = self.ranges[b]
-        self._work.append(dist.all_reduce(self.flat_grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True))
+        from . import hip_ops
+
+        side = hip_ops.side_stream(self.flat_grad.device) if self.flat_grad.is_cuda else None
+        if side is not None:
+            side.wait_stream(torch.cuda.current_stream(self.flat_grad.device))  # gradients accumulated by autograd on the main stream
+            with torch.cuda.stream(side):  # the collective queues behind this bucket's last weight-gradient GEMM
+                work = dist.all_reduce(self.flat_grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        else:
+            work = dist.all_reduce(self.flat_grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+        self._work.append(work)
         self._launched[b] = True
+        self.launch_log.append((b, hip_ops.CONTRIBUTIONS, from_finish))
 
     def start(self):
         """Call right before ``loss.backward()``."""
         self._arrived = [0] * len(self.ranges)
+        self._seen = [False] * len(self.params)
         self._launched = [False] * len(self.ranges)
         self._work = []
+        self.launch_log = []
         self._armed = self.enabled
+        if self.flat_grad.is_cuda:
+            from . import hip_ops
+
+            hip_ops.reset_backward_state()
 
     def finish(self):
         """Call after backward: launches buckets whose parameters got no gradient this pass,
@@ -122,18 +160,23 @@ class GradSynchronizer:
         if not self.enabled:
             return
         self._armed = False
-        if self.flat_grad.is_cuda:
-            from . import hip_ops
+        from . import hip_ops
 
-            hip_ops.join_side_stream(self.flat_grad.device)  # conv weight gradients are accumulated on a side stream
+        hip_ops.clear_pending_uses(self.params)
         for b, done in enumerate(self._launched):
             if not done:
-                self._launch(b)
+                self._launch(b, True)
         for w in self._work:
-            w.wait()
+            w.wait()  # the current stream waits for the collective
+        if self.flat_grad.is_cuda:
+            hip_ops.join_side_stream(self.flat_grad.device)  # weight gradients of buckets that autograd never completed
         self.flat_grad.div_(self.world)
 
     def remove(self):
+        from . import hip_ops
+
         for h in self._hooks:
             h.remove()
         self._hooks = []
+        for p in self.params:
+            hip_ops.set_arrival_listener(p, None)

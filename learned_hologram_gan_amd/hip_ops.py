@@ -110,10 +110,105 @@ def _dense(t):
 # stream and ACCUMULATED straight into the slot; autograd gets None for it.  The main stream's HBM-bound kernels then run under the
 # side stream's GEMMs.  A callback queued on the autograd engine joins the two streams when the backward pass ends, so reading
 # .grad after backward() is as safe as without the second stream (join_side_stream() is that fence).  LHG_SIDE_WGRAD=0 disables.
+#
+# Single host thread by contract (the reference is single-threaded): the registries below are plain module globals.
 _GRAD_SLOTS: dict = {}
 _JOIN_QUEUED = False
 _SIDE_STREAMS: dict = {}
 SIDE_WGRAD = os.environ.get("LHG_SIDE_WGRAD", "1") != "0"
+SLOT_ACCUMULATE = True  # False: weight gradients go back through autograd's own accumulation (A/B tests of the slot path)
+
+# Gradients that never pass through autograd's AccumulateGrad (slot-accumulated weight gradients, analytically-zero biases) are
+# invisible to post-accumulate hooks.  distributed.GradSynchronizer registers a listener per parameter; every recorded use of such a
+# parameter is counted at forward time (note_use) and every contribution at backward time (note_contribution): when the count
+# returns to zero the parameter's gradient is complete and the listener fires, so a bucket's all-reduce can start while backward is
+# still running.
+_ARRIVAL_LISTENERS: dict = {}  # data_ptr -> callable()
+_PENDING_USES: dict = {}       # data_ptr -> recorded uses whose backward has not run yet
+CONTRIBUTIONS = 0              # contributions seen so far (host-side sequence number, read by the overlap tests)
+_PARAM_GRADS_OFF = 0
+
+
+class only_input_gradients:
+    """Context: backward passes inside it skip every parameter gradient.  ``autograd.grad(outputs, inputs=x)`` still runs each node's
+    full backward and then drops what it did not ask for — for the WGAN-GP penalty (watermelon.py:466-473: d D(x^)/d x^ with
+    create_graph=True) that is one dead weight-gradient GEMM per critic layer.  Values that the caller receives are unchanged."""
+
+    def __enter__(self):
+        global _PARAM_GRADS_OFF
+        _PARAM_GRADS_OFF += 1
+
+    def __exit__(self, *exc):
+        global _PARAM_GRADS_OFF
+        _PARAM_GRADS_OFF -= 1
+        return False
+
+
+def param_grads_wanted() -> bool:
+    return _PARAM_GRADS_OFF == 0
+
+
+def set_arrival_listener(param: torch.Tensor, fn) -> None:
+    if fn is None:
+        _ARRIVAL_LISTENERS.pop(param.data_ptr(), None)
+        _PENDING_USES.pop(param.data_ptr(), None)
+    else:
+        _ARRIVAL_LISTENERS[param.data_ptr()] = fn
+        _PENDING_USES[param.data_ptr()] = 0
+
+
+_RECORDING = False
+
+
+class TrackedFunction(Function):
+    """autograd.Function whose ``apply`` remembers whether the call is being recorded: grad mode is always off INSIDE ``forward`` and
+    ``ctx.needs_input_grad`` ignores it, so ``note_use`` could not tell an inference call from a recorded one."""
+
+    @classmethod
+    def apply(cls, *args):
+        global _RECORDING
+        prev, _RECORDING = _RECORDING, torch.is_grad_enabled()
+        try:
+            return super().apply(*args)
+        finally:
+            _RECORDING = prev
+
+
+def note_use(param, needed: bool = True) -> None:
+    """Forward of an op whose backward will contribute to `param` outside autograd; counted only while the graph is being recorded
+    (`needed` = ctx.needs_input_grad[i])."""
+    if param is not None and needed and _RECORDING and _ARRIVAL_LISTENERS:
+        k = param.data_ptr()
+        if k in _PENDING_USES:
+            _PENDING_USES[k] += 1
+
+
+def note_contribution(param) -> None:
+    global CONTRIBUTIONS
+    CONTRIBUTIONS += 1
+    if param is None or not _ARRIVAL_LISTENERS:
+        return
+    k = param.data_ptr()
+    left = _PENDING_USES.get(k)
+    if left is None:
+        return
+    _PENDING_USES[k] = left - 1
+    if left - 1 <= 0:
+        _ARRIVAL_LISTENERS[k]()
+
+
+def clear_pending_uses(params) -> None:
+    """End of a backward pass over `params`: every recorded use has contributed (or belonged to a graph that was dropped)."""
+    for p_ in params:
+        if p_.data_ptr() in _PENDING_USES:
+            _PENDING_USES[p_.data_ptr()] = 0
+
+
+def reset_backward_state() -> None:
+    """Start of a top-level backward: if an earlier backward raised after queueing the end-of-backward join, its callback never ran
+    and the flag would suppress every later join."""
+    global _JOIN_QUEUED
+    _JOIN_QUEUED = False
 
 
 def register_grad_slot(param: torch.Tensor, grad_view: torch.Tensor) -> None:
@@ -146,6 +241,13 @@ def _side_stream(device):
     return _SIDE_STREAMS[key]
 
 
+def side_stream(device):
+    """The stream weight gradients are accumulated on (None when the second stream is switched off or `device` is not a GPU)."""
+    if not SIDE_WGRAD or torch.device(device).type != "cuda":
+        return None
+    return _side_stream(device)
+
+
 def join_side_stream(device=None) -> None:
     """Make the current stream wait for every weight gradient launched on the side stream so far."""
     for key, st in _SIDE_STREAMS.items():
@@ -155,9 +257,13 @@ def join_side_stream(device=None) -> None:
 
 def _weight_grad(w, inputs, fn):
     """fn() -> weight gradient from `inputs`.  Plain backward into a registered slot: run on the side stream, accumulate, return None."""
-    slot = _grad_slot(w) if (SIDE_WGRAD and not torch.is_grad_enabled()) else None
+    slot = _grad_slot(w) if (SLOT_ACCUMULATE and not torch.is_grad_enabled()) else None
     if slot is None:
         return fn()
+    if not (SIDE_WGRAD and w.is_cuda):  # same accumulate-into-the-slot contract on the caller's stream
+        slot.add_(fn())
+        note_contribution(w)
+        return None
     main, side = torch.cuda.current_stream(w.device), _side_stream(w.device)
     global _JOIN_QUEUED
     if not _JOIN_QUEUED:  # when this backward pass ends, its stream waits for the side stream: .grad is then safe to read as usual
@@ -174,6 +280,7 @@ def _weight_grad(w, inputs, fn):
         t.record_stream(side)  # keep their memory out of main-stream reuse until the side stream is done with it
     with torch.cuda.stream(side):
         slot.add_(fn())
+    note_contribution(w)
     return None
 
 
@@ -340,7 +447,7 @@ def _padded_gy(gy, k_multiple=32):
     return out
 
 
-class Conv2dFn(Function):
+class Conv2dFn(TrackedFunction):
     """y = conv2d(x, w, stride, padding=k//2) + bias.  x NHWC with C padded to 32; w OIHW.
 
     ``out`` is None, an OutSlot, or the string "feeds_bn": the conv output goes straight into a train-mode
@@ -355,6 +462,9 @@ class Conv2dFn(Function):
             out = None
         ctx.save_for_backward(x, w)
         ctx.stride, ctx.has_bias = stride, bias is not None
+        note_use(w, ctx.needs_input_grad[1])
+        ctx.zero_bias = bias if (ctx.bias_grad_is_zero and bias is not None and ctx.needs_input_grad[2]) else None
+        note_use(ctx.zero_bias)
         return conv2d_forward_raw(x, w, bias, stride, out=out)
 
     @staticmethod
@@ -364,22 +474,27 @@ class Conv2dFn(Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = Conv2dInputGradFn.apply(gy, w, ctx.stride, x.shape[1], x.shape[2], x.shape[3])
+        if not param_grads_wanted():  # inside only_input_gradients(): the caller differentiates with respect to activations only
+            return gx, None, None, None, None
         if ctx.needs_input_grad[1]:
             gw = _weight_grad(w, (x, gy), lambda: Conv2dWeightGradFn.apply(x, gy, w.shape, ctx.stride))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             # exactly-zero gradient: None (autograd's zero) instead of a zero tensor saves a fill and an accumulate launch per layer
-            gb = None if (ctx.bias_grad_is_zero and not torch.is_grad_enabled()) else (
-                torch.zeros(w.shape[0], dtype=torch.float32, device=w.device) if ctx.bias_grad_is_zero else channel_sum(gy))
+            if ctx.bias_grad_is_zero and not torch.is_grad_enabled():
+                note_contribution(ctx.zero_bias)
+            else:
+                gb = torch.zeros(w.shape[0], dtype=torch.float32, device=w.device) if ctx.bias_grad_is_zero else channel_sum(gy)
         return gx, gw, gb, None, None
 
 
-class Conv2dInputGradFn(Function):
+class Conv2dInputGradFn(TrackedFunction):
     """gx = d conv2d / d x contracted with gy.  Returns (N, H, W, pad32(Ci))."""
 
     @staticmethod
     def forward(ctx, gy, w, stride, H, W, Cx):
         ctx.save_for_backward(gy, w)
         ctx.stride = stride
+        note_use(w, ctx.needs_input_grad[1])
         Co, Ci, KH, KW = w.shape
         if KH == KW and gy.shape[-1] >= Co and thin_mode(Ci, Co, KH, stride):
             gyv = _as_nhwc_view(gy)  # keep the (possibly temporary) dense copy alive until the launch
@@ -409,7 +524,7 @@ class Conv2dInputGradFn(Function):
         g_gy = g_w = None
         if ctx.needs_input_grad[0]:
             g_gy = Conv2dFn.apply(ggx, w, None, ctx.stride, None)
-        if ctx.needs_input_grad[1]:
+        if ctx.needs_input_grad[1] and param_grads_wanted():
             g_w = _weight_grad(w, (ggx, gy), lambda: Conv2dWeightGradFn.apply(ggx, gy, w.shape, ctx.stride))
         return g_gy, g_w, None, None, None, None
 
@@ -455,13 +570,14 @@ class Conv2dWeightGradFn(Function):
         return g_x, g_gy, None, None
 
 
-class ConvTranspose2x2Fn(Function):
+class ConvTranspose2x2Fn(TrackedFunction):
     """y = conv_transpose2d(x, w, stride=2) + bias with kernel 2.  w IOHW (Cin, Cout, 2, 2)."""
 
     @staticmethod
     def forward(ctx, x, w, bias, out):
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
+        note_use(w, ctx.needs_input_grad[1])
         px, N, H, W, Ci, ldx = nhwc(x)
         Ciw, Co, KH, KW = w.shape
         assert (KH, KW) == (2, 2) and Ciw == Ci, "conv_transpose2x2: weight/input mismatch"
@@ -485,6 +601,8 @@ class ConvTranspose2x2Fn(Function):
             pgx, _, _, _, _, ldgx = nhwc(gx)
             native.count_flops(0, 2.0 * N * (H2 // 2) * (W2 // 2) * 4 * Ci * Co)
             call("lhg_conv_transpose2x2_backward_input", pg, N, H2 // 2, W2 // 2, Cg, ldg, ptr(wp), wp.shape[1], pgx, Ci, ldgx, stream_ptr())
+        if not param_grads_wanted():
+            return gx, None, None, None
         if ctx.needs_input_grad[1]:
             def wgrad():
                 px, N, H, W, Cx, ldx = nhwc(x)
@@ -546,7 +664,7 @@ class ActGradFn(Function):
         return ActGradFn.apply(gg, y, ctx.act, ctx.slope), None, None, None
 
 
-class ConvBiasActFn(Function):
+class ConvBiasActFn(TrackedFunction):
     """y = act(conv2d(x, w) + bias) with the activation fused in the GEMM epilogue
     (critic block1, ref: discriminator.py:16-19)."""
 
@@ -555,6 +673,7 @@ class ConvBiasActFn(Function):
         y = conv2d_forward_raw(x, w, bias, stride, act=act, slope=slope)
         ctx.save_for_backward(x, w, y)
         ctx.stride, ctx.act, ctx.slope, ctx.has_bias = stride, act, slope, bias is not None
+        note_use(w, ctx.needs_input_grad[1])
         return y
 
     @staticmethod
@@ -564,6 +683,8 @@ class ConvBiasActFn(Function):
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:
             gx = Conv2dInputGradFn.apply(g, w, ctx.stride, x.shape[1], x.shape[2], x.shape[3])
+        if not param_grads_wanted():
+            return gx, None, None, None, None, None
         if ctx.needs_input_grad[1]:
             gw = _weight_grad(w, (x, g), lambda: Conv2dWeightGradFn.apply(x, g, w.shape, ctx.stride))
         if ctx.has_bias and ctx.needs_input_grad[2]:
@@ -674,7 +795,7 @@ class MaxPool2x2Fn(Function):
 
 
 # --------------------------------------------------------------------------- sigmoid head (planar output)
-class SigmoidHeadFn(Function):
+class SigmoidHeadFn(TrackedFunction):
     """y (N, Co, H, W) = sigmoid(conv1x1(x) + bias), written planar by the GEMM epilogue.
     ref: neural_network_components.py:292-295."""
 
@@ -682,6 +803,7 @@ class SigmoidHeadFn(Function):
     def forward(ctx, x, w, bias):
         y = conv2d_forward_raw(x, w, bias, 1, act=ACT_SIGMOID, planar=True)
         ctx.save_for_backward(x, w, y)
+        note_use(w, ctx.needs_input_grad[1])
         return y
 
     @staticmethod

@@ -34,13 +34,14 @@ class FlatParams:
                 self.data[o:o + p.numel()].copy_(p.detach().reshape(-1))
                 p.data = self.data[o:o + p.numel()].view_as(p)
                 p.grad = self.grad[o:o + p.numel()].view_as(p)
-                if p.dim() == 4 and p.is_cuda:  # conv / conv-transpose weights: gradient GEMMs may write here from a side stream
+                if p.dim() == 4:  # conv / conv-transpose weights: gradient GEMMs accumulate here (from a side stream on the GPU)
                     hip_ops.register_grad_slot(p, p.grad)
 
     def zero_grad(self):
         """Keep .grad bound to the flat buffer (set_to_none would drop the views)."""
         if self.grad.is_cuda:
             hip_ops.join_side_stream(self.grad.device)
+            hip_ops.reset_backward_state()
         self.grad.zero_()
         for p, o in zip(self.params, self.offsets):
             if p.grad is None or p.grad.data_ptr() != self.grad.data_ptr() + 4 * o:

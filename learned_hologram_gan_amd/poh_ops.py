@@ -41,9 +41,10 @@ class PohEncodeFn(Function):
         B, Cc, H, W = field.shape
         planes = B * Cc
         nblk = native.load().lhg_poh_partial_blocks(H, W)
+        g_poh = g_poh.contiguous()  # bound to a local: a temporary's block could be reused by the allocations below
         g_mod = torch.empty_like(field)
         ws = torch.empty((planes * nblk,), dtype=torch.float32, device=field.device)
-        call("lhg_double_phase_encode_backward", ptr(g_poh.contiguous()), ptr(torch.view_as_real(mod)), ptr(peak), planes, H, W,
+        call("lhg_double_phase_encode_backward", ptr(g_poh), ptr(torch.view_as_real(mod)), ptr(peak), planes, H, W,
              ptr(torch.view_as_real(g_mod)), ptr(ws), stream_ptr())
         g_field = torch.empty_like(field)
         partial = torch.empty((B, Cc, nblk, 4), dtype=torch.float32, device=field.device)
@@ -75,8 +76,9 @@ class ReconLossFn(Function):
     def backward(ctx, g):
         ha, ta, hp, tp, sums = ctx.saved_tensors
         B, Cc, H, W = ha.shape
+        g = g.contiguous().float()  # bound to a local before the allocations below
         g_ha, g_hp = torch.empty_like(ha), torch.empty_like(hp)
-        call("lhg_recon_loss_backward", ptr(ha), ptr(ta), ptr(hp), ptr(tp), B * Cc, H, W, ptr(sums), ptr(g.contiguous().float()),
+        call("lhg_recon_loss_backward", ptr(ha), ptr(ta), ptr(hp), ptr(tp), B * Cc, H, W, ptr(sums), ptr(g),
              ptr(g_ha), ptr(g_hp), stream_ptr())
         return g_ha, None, g_hp, None
 

@@ -105,10 +105,11 @@ def complex_plain(amplitude_tensor, phase_tensor):
     return amplitude_tensor * torch.exp(1j * phase_tensor)
 
 
-def save_planes_as_png(planes01: torch.Tensor, save_dir: str, rgb_img: bool = True) -> None:
-    """Write (K,3,H,W) tensors in [0,1] as <k>.png (8-bit, truncated like the reference's
-    plotter output).  Minimal stand-in for multi_sample_plotter (utilities.py:160-203)
-    so that generatePOH.py --propagate keeps its documented artefacts."""
+def save_planes_as_png(planes01: torch.Tensor, save_dir: str, rgb_img: bool = True, titles=None) -> None:
+    """Write (K,3,H,W) tensors in [0,1] as <title>.png, titles defaulting to 0..K-1 (8-bit, truncated like the
+    reference's plotter output).  Minimal stand-in for multi_sample_plotter (utilities.py:160-203: one
+    ``plt.imsave(save_dir/<title>.png)`` per sample) so that generatePOH.py --propagate and the trainer's
+    visualisation dumps keep their documented artefacts."""
     import os
 
     from PIL import Image
@@ -116,4 +117,5 @@ def save_planes_as_png(planes01: torch.Tensor, save_dir: str, rgb_img: bool = Tr
     os.makedirs(save_dir, exist_ok=True)
     arr = (planes01.detach().clamp(0, 1) * 255.0).to("cpu").permute(0, 2, 3, 1).numpy().astype(np.uint8)
     for k in range(arr.shape[0]):
-        Image.fromarray(arr[k] if rgb_img else arr[k, ..., 0]).save(os.path.join(save_dir, f"{k}.png"))
+        name = k if titles is None else titles[k]
+        Image.fromarray(arr[k] if rgb_img else arr[k, ..., 0]).save(os.path.join(save_dir, f"{name}.png"))

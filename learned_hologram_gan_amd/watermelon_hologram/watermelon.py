@@ -13,17 +13,19 @@ file, so the trainer takes it as a constructor argument and ``perceptual_loss_we
 
 from __future__ import annotations
 
+import contextlib
 import json
 
 import torch
 import torch.autograd as autograd
 import torch.nn.functional as F
 
+from .. import hip_ops
 from ..angular_spectrum_method import bandLimitedAngularSpectrumMethod_for_multiple_distances
 from ..distributed import GradSynchronizer, broadcast_module_state
 from ..optim import FlatParams, FusedAdam
 from ..poh_ops import ReconLossFn, psnr_ssim
-from ..utilities import try_gpu
+from ..utilities import save_planes_as_png, tensor_normalizor_2D, try_gpu
 from .discriminator import WGANGPDiscriminator192, fakeDiscriminator
 from .generator import Generator
 from .loss_func import fakePerceptualLoss, focal_sincos_phase_gradient_loss, total_variation_loss
@@ -48,8 +50,10 @@ class _frozen:
 
 
 def psnr(hat, target):
-    """torchmetrics PeakSignalNoiseRatio() defaults: data_range = max(target) - min(target)."""
-    rng = target.max() - target.min()
+    """torchmetrics PeakSignalNoiseRatio() defaults as the reference calls it (one ``forward`` per batch, watermelon.py:447-456):
+    the min/max target states start at 0.0, so data_range = max(max t, 0) - min(min t, 0)."""
+    zero = torch.zeros((), dtype=target.dtype, device=target.device)
+    rng = torch.maximum(target.max(), zero) - torch.minimum(target.min(), zero)
     return 10.0 * torch.log10(rng * rng / F.mse_loss(hat, target))
 
 
@@ -134,8 +138,10 @@ class watermelon:
             alpha = torch.rand(real_samples.size(0), 1, 1, 1).to(self.device)
         interpolates = (alpha * real_samples + ((1 - alpha) * fake_samples)).requires_grad_(True)
         d_interpolates = self.discriminator(interpolates)
-        gradients = autograd.grad(outputs=d_interpolates, inputs=interpolates, grad_outputs=torch.ones_like(d_interpolates),
-                                  create_graph=True, retain_graph=True, only_inputs=True)[0]
+        # only d D / d x^ is asked for: the critic's parameter gradients of THIS pass would be computed and dropped by the engine
+        with (hip_ops.only_input_gradients() if interpolates.is_cuda else contextlib.nullcontext()):
+            gradients = autograd.grad(outputs=d_interpolates, inputs=interpolates, grad_outputs=torch.ones_like(d_interpolates),
+                                      create_graph=True, retain_graph=True, only_inputs=True)[0]
         gradients = gradients.view(gradients.size(0), -1)
         return ((gradients.norm(2, dim=1) - 1) ** 2).mean()
 
@@ -250,9 +256,27 @@ class watermelon:
                                                      self.dict_for_losses_metrics)
                     losses_last, metrics_last = self.train_losses_tensor.clone(), self.train_metrics_tensor.clone()
                     n_batch_last = n_batch
+                if n_batch % info_plot_interval == 0 and visualization_RGBD_AP is not None:
+                    self._visualize(visualization_RGBD_AP, save_path_img, f"in epoch {epoch}, batch {n_batch_in_epoch + 1}")
+                    print(f"visualization saved at epoch {epoch}, batch {n_batch_in_epoch + 1}")
             if epoch % checkpoint_iterval == 0:
                 self._checkpoint(save_path_G, save_path_D, loss_metrics_file, suffix=f"_epoch{epoch}")
+                if visualization_RGBD_AP is not None:
+                    self._visualize(visualization_RGBD_AP, save_path_img, f"in epoch {epoch}")
+                    print(f"visualization saved at epoch {epoch}")
         self._checkpoint(save_path_G, save_path_D, loss_metrics_file, suffix="")
+
+    def _visualize(self, sample, save_path_img, when):
+        """``amp_hat <when>.png`` / ``phs_hat <when>.png``: the reconstruction of one validation sample at the generator's fixed
+        distance, each plane normalised to [0, 1] (ref: watermelon.py:325-355 every ``info_plot_interval`` batches in the network's
+        current mode, :376-404 at every checkpoint epoch under no_grad).  Written when ``save_path_img`` is given."""
+        if save_path_img is None:
+            return
+        with torch.no_grad():
+            POH = self.generator(sample[0].unsqueeze(0).to(self.device))
+            amp_hat, phs_hat = self.generator.part2.propagator.propagate_POH2AP_forward(POH)
+        save_planes_as_png(tensor_normalizor_2D(torch.cat((amp_hat, phs_hat), dim=0)), save_path_img, True,
+                           titles=[f"amp_hat {when}", f"phs_hat {when}"])
 
     def _checkpoint(self, save_path_G, save_path_D, loss_metrics_file, suffix):
         """<save_path> and <save_path minus .pth>_epoch{n}.pth (watermelon.py:361-374, 406-412)."""
@@ -317,5 +341,9 @@ class watermelon_without_GAN(watermelon):
         return fakeDiscriminator(pretrained_model_path=None, feature_d=32, cuda=True)
 
     def train(self, data_loader_train, data_loader_val, **kw):
+        """ref: watermelon.py:667-715 — forces the critic terms to zero and does NOT forward ``save_path_D``, ``lr_D`` or
+        ``step_scheduler_D_gamma`` to the base loop: no critic checkpoint is written (the base loop prints its warning)."""
+        for dropped in ("save_path_D", "lr_D", "step_scheduler_D_gamma"):
+            kw.pop(dropped, None)
         kw.update(discriminator_loss_weight=0.0, discriminator_train_ratio=0, discriminator_lambda=0.0)
         super().train(data_loader_train, data_loader_val, **kw)

@@ -47,10 +47,13 @@ def pixel_loss(hat, target):
 
 
 def psnr(hat, target):
-    """torchmetrics PeakSignalNoiseRatio() default: data_range = max(target) - min(target),
-    10*log10(range^2 / mse) over the whole batch. ref: watermelon.py:134, 447-456
-    (torchmetrics is not installed here: parity of this metric is unpinned)."""
-    rng = target.max() - target.min()
+    """torchmetrics PeakSignalNoiseRatio() with data_range=None, called once per batch through ``Metric.forward`` as the reference
+    does (watermelon.py:134, 447-456): the ``min_target`` / ``max_target`` states start from their DEFAULT 0.0 for the batch value
+    and are updated with ``minimum(target.min(), state)`` / ``maximum(target.max(), state)``, so
+    data_range = max(max t, 0) - min(min t, 0); then 10*log10(range^2 / mse) over the whole batch.
+    (torchmetrics is not installed here: restated from its published source, parity of this metric is unpinned.)"""
+    zero = torch.zeros((), dtype=target.dtype, device=target.device)
+    rng = torch.maximum(target.max(), zero) - torch.minimum(target.min(), zero)
     return 10.0 * torch.log10(rng**2 / F.mse_loss(hat, target))
 
 

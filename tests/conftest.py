@@ -36,6 +36,26 @@ def golden():
     return load
 
 
+@pytest.fixture(scope="session")
+def oracle_full_step():
+    """BASELINE configs[1] at full size through the CPU oracle, computed once per session: 384x384, batch 4, pad 320 (1024^2 FFTs),
+    20-plane stack, one critic update with the gradient penalty, generator loss / backward, both Adam steps (oracle/step.py).
+    Returns (inputs, outputs); shared by the fp32 and the bf16-mode parity tests."""
+    from oracle import seeded, step
+
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    rows = cols = 384
+    pad, coef, B = 320, 0.45, 4
+    stack = torch.linspace(-4e-4, 0.0, 21)[:-1]
+    rgbd, tamp, tphs = seeded.smooth_batch(B, rows, cols, seed=51)
+    idx = torch.tensor([17, 3, 11, 6])
+    alphas = [torch.tensor([0.2, 0.9, 0.55, 0.4]).view(B, 1, 1, 1)]
+    st = step.make_state(rows, cols, pad, coef, stack, seeded.generator_state_dict(), seeded.critic_state_dict())
+    ref = step.train_step(st, rgbd, tamp, tphs, step.LossWeights(d_ratio=1), idx, alphas)
+    cfg = dict(rows=rows, cols=cols, pad=pad, coef=coef, stack=stack, rgbd=rgbd, tamp=tamp, tphs=tphs, idx=idx, alphas=alphas)
+    return cfg, ref
+
+
 def rel_err(a, b):
     """max|a-b| / max|b| — the fp32 parity measure used throughout (north_star: 1e-4)."""
     a, b = torch.as_tensor(a), torch.as_tensor(b)

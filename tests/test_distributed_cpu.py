@@ -77,6 +77,116 @@ def _worker(rank, world, port, q):
     dist.destroy_process_group()
 
 
+def _tracked_base():
+    from learned_hologram_gan_amd import hip_ops
+
+    return hip_ops.TrackedFunction
+
+
+class _SlotScaleFn(_tracked_base()):
+    """y = x * w.sum() + bias * 0 — a stand-in for the conv ops' contract: the weight gradient is ACCUMULATED into the flat slot by
+    hip_ops._weight_grad (autograd receives None) and the bias gradient is an exact zero reported through note_contribution."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias):
+        from learned_hologram_gan_amd import hip_ops
+
+        ctx.save_for_backward(x, w)
+        ctx.bias = bias
+        hip_ops.note_use(w, ctx.needs_input_grad[1])
+        hip_ops.note_use(bias, ctx.needs_input_grad[2])
+        return x * w.sum()
+
+    @staticmethod
+    def backward(ctx, g):
+        from learned_hologram_gan_amd import hip_ops
+
+        x, w = ctx.saved_tensors
+        gw = hip_ops._weight_grad(w, (x, g), lambda: (g * x).sum() * torch.ones_like(w))
+        hip_ops.note_contribution(ctx.bias)
+        return g * w.sum(), gw, None
+
+
+class _SlotNet(torch.nn.Module):
+    """lin0 -> scale (used TWICE: two contributions to one slot) -> lin1.  Parameter order is w, zero_bias, pad, lin0.*, lin1.*, so
+    with three buckets (filled from the last parameter backwards) the slot-accumulated weight sits alone in the last bucket, the
+    zero-gradient bias shares one with the never-used `pad`, and the first bucket completes through autograd's hooks."""
+
+    def __init__(self):
+        super().__init__()
+        self.lin0 = torch.nn.Linear(8, 8)
+        self.w = torch.nn.Parameter(torch.full((2, 2, 1, 1), 0.3))  # 4-D: FlatParams registers a gradient slot for it
+        self.zero_bias = torch.nn.Parameter(torch.zeros(8))
+        self.pad = torch.nn.Parameter(torch.zeros(40))  # never used: only finish() can complete its bucket
+        self.lin1 = torch.nn.Linear(8, 4)
+
+    def forward(self, x):
+        h = torch.tanh(self.lin0(x))
+        h = _SlotScaleFn.apply(h, self.w, self.zero_bias)
+        h = _SlotScaleFn.apply(torch.tanh(h), self.w, self.zero_bias)
+        return self.lin1(h)
+
+
+def _overlap_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from learned_hologram_gan_amd import distributed, hip_ops
+    from learned_hologram_gan_amd.optim import FlatParams
+
+    distributed.init_from_env("gloo")
+    torch.manual_seed(7)
+    net = _SlotNet()
+    flat = FlatParams(net)
+    names = [n for n, _ in net.named_parameters()]
+    sync = distributed.GradSynchronizer(flat.params, flat.offsets, flat.grad, n_buckets=3)
+    data = [torch.randn(6, 8, generator=torch.Generator().manual_seed(50 + k)) for k in range(world)]
+    ok = True
+    for it in range(2):
+        expect = torch.zeros_like(flat.grad)
+        for k in range(world):  # reference: plain autograd on a copy with the same maths
+            ref = _SlotNet()
+            ref.load_state_dict(net.state_dict())
+            h = torch.tanh(ref.lin0(data[k]))
+            h = h * ref.w.sum()
+            h = torch.tanh(h) * ref.w.sum()
+            (ref.lin1(h) ** 2).mean().backward()
+            for n, p_ref, o in zip(names, ref.parameters(), flat.offsets):
+                if p_ref.grad is not None:
+                    expect[o:o + p_ref.numel()] += p_ref.grad.reshape(-1) / world
+        flat.zero_grad()
+        sync.start()
+        before = hip_ops.CONTRIBUTIONS
+        (net(data[rank]) ** 2).mean().backward()
+        in_backward = [(b, c - before) for b, c, from_finish in sync.launch_log if not from_finish]
+        sync.finish()
+        ok = ok and torch.allclose(flat.grad, expect, rtol=1e-5, atol=1e-7)
+        # the slot weight's bucket was launched from INSIDE backward, by the weight's SECOND contribution (the third contribution of
+        # the pass: weight, bias, weight) and not by its first; the bucket holding the unused parameter only by finish()
+        b_w, b_pad = sync.bucket_of[names.index("w")], sync.bucket_of[names.index("pad")]
+        ok = ok and (b_w, 3) in in_backward and len(in_backward) == 2
+        ok = ok and [b for b, _, from_finish in sync.launch_log if from_finish] == [b_pad] and all(sync._launched)
+        ok = ok and net.w.grad.data_ptr() == flat.grad.data_ptr() + 4 * flat.offsets[names.index("w")]
+    dist.barrier()
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_slot_accumulated_gradients_launch_their_bucket_inside_backward_world2():
+    """The conv weight gradients never pass through autograd (hip_ops._weight_grad accumulates them into the flat buffer and returns
+    None) and biases in front of a BatchNorm have an exact-zero gradient: their buckets must still be reduced from INSIDE backward."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_overlap_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=240) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(results) == [(0, True), (1, True)]
+
+
 @pytest.mark.timeout(300)
 def test_bucketed_grad_allreduce_world2():
     ctx = mp.get_context("spawn")

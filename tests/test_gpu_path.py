@@ -442,22 +442,14 @@ def test_non_power_of_two_extent_uses_rocfft_route():
     assert rel_err(a.cpu(), optics.poh_to_amp_phase(o, Hf, phs)[0]) < PARITY
 
 
-def test_full_size_train_step_vs_oracle():
+def test_full_size_train_step_vs_oracle(oracle_full_step):
     """BASELINE configs[1] at full size: 384x384, batch 4, pad 320 (1024^2 FFTs), 20-plane stack, one critic update with the
     gradient penalty, generator loss/backward, both Adam steps — HIP path vs the CPU oracle on identical seeded inputs."""
-    import os
-
     from learned_hologram_gan_amd.watermelon_hologram.watermelon import watermelon
 
-    torch.set_num_threads(min(16, os.cpu_count() or 1))
-    rows = cols = 384
-    pad, coef, B = 320, 0.45, 4
-    stack = torch.linspace(-4e-4, 0.0, 21)[:-1]
-    rgbd, tamp, tphs = seeded.smooth_batch(B, rows, cols, seed=51)
-    idx = torch.tensor([17, 3, 11, 6])
-    alphas = [torch.tensor([0.2, 0.9, 0.55, 0.4]).view(B, 1, 1, 1)]
-    st = step.make_state(rows, cols, pad, coef, stack, seeded.generator_state_dict(), seeded.critic_state_dict())
-    ref = step.train_step(st, rgbd, tamp, tphs, step.LossWeights(d_ratio=1), idx, alphas)
+    cfg, ref = oracle_full_step
+    rows, cols, pad, coef, stack = cfg["rows"], cfg["cols"], cfg["pad"], cfg["coef"], cfg["stack"]
+    rgbd, tamp, tphs, idx, alphas = cfg["rgbd"], cfg["tamp"], cfg["tphs"], cfg["idx"], cfg["alphas"]
     W = watermelon(filter_radius_coefficient=coef, pad_size=pad, distance_stack=stack, input_shape=(1, 4, rows, cols))
     W.generator.load_state_dict(seeded.generator_state_dict())
     W.discriminator.load_state_dict(seeded.critic_state_dict())
@@ -763,13 +755,58 @@ def test_two_rank_bench_rehearsal():
     env = dict(os.environ, LHG_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rows", "64",
-           "--cols", "64", "--pad", "32", "--cpu-baseline", "0"]
+           "--cols", "64", "--pad", "32", "--cpu-baseline", "0", "--secondary", "0"]
     res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=280)
     assert res.returncode == 0, res.stderr[-2000:]
     line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
     out = json.loads(line)
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0 and out["config"]["global_batch"] == 8
     assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
+
+
+def _run_dist_worker(mode, nproc, env_extra=None, timeout=280):
+    import json
+    import os
+    import socket
+    import subprocess
+    import sys
+
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), **(env_extra or {}))
+    worker = os.path.join(root, "tests", "_dist_gpu_worker.py")
+    if nproc == 1:
+        cmd = [sys.executable, worker, mode]
+    else:
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(nproc), "--master-addr", "127.0.0.1",
+               "--master-port", str(port), worker, mode]
+    res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
+    assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-2500:])
+    return [json.loads(ln) for ln in res.stdout.splitlines() if ln.startswith("{")]
+
+
+def test_rccl_backend_initialises_and_reduces_world1():
+    """backend="nccl" is RCCL on ROCm: a world of one on this box's GPU must initialise, all-reduce (async, as GradSynchronizer
+    issues it), broadcast and barrier.  (More than one rank needs one GPU per rank: the driver's 8-GPU run.)"""
+    out = _run_dist_worker("rccl", 1)
+    assert out and out[-1]["rccl"] is True and out[-1]["backend"] == "nccl"
+
+
+def test_gradient_buckets_are_reduced_inside_backward_two_ranks():
+    """Two ranks share this GPU over gloo.  Conv weight gradients never pass through autograd (accumulated into the flat buffer on the
+    weight-gradient stream), yet every bucket except the last must have its all-reduce ENQUEUED from inside backward — the first one
+    before most of the pass's weight-gradient contributions exist — and the reduced gradients equal the mean of the local ones."""
+    out = sorted(_run_dist_worker("overlap", 2), key=lambda r: r["rank"])
+    assert [r["rank"] for r in out] == [0, 1]
+    for r in out:
+        assert r["err"] < 1e-5, r
+        in_backward = [(b, c) for b, c, from_finish in r["launch_log"] if not from_finish]
+        assert len(in_backward) >= r["buckets"] - 1, r          # at most the first-layer bucket is left to finish()
+        assert in_backward[0][1] < 0.5 * r["contributions"], r   # bucket 0 went out before half of the contributions were enqueued
+        assert [b for b, _, _ in r["launch_log"]] == sorted(b for b, _, _ in r["launch_log"]), r  # same order on every rank
+    assert out[0]["launch_log"] == out[1]["launch_log"]
 
 
 # ----------------------------------------------------------------------------- second stream for the weight gradients
@@ -788,7 +825,7 @@ def test_side_stream_weight_gradients_match_single_stream():
     alphas = [torch.tensor([0.3, 0.8]).view(2, 1, 1, 1).to(DEV)]
 
     def run(side):
-        hip_ops.SIDE_WGRAD = side
+        hip_ops.SIDE_WGRAD = hip_ops.SLOT_ACCUMULATE = side
         W = watermelon(filter_radius_coefficient=0.45, pad_size=32, distance_stack=stack, input_shape=(1, 4, rows, cols))
         W.generator.load_state_dict(seeded.generator_state_dict())
         W.discriminator.load_state_dict(seeded.critic_state_dict())
@@ -818,7 +855,7 @@ def test_side_stream_weight_gradients_match_single_stream():
             assert (g1["D"] - g0["D"]).norm() <= 1e-5 * g0["D"].norm()
             assert g0["G"].abs().max() > 0 and g0["D"].abs().max() > 0
     finally:
-        hip_ops.SIDE_WGRAD = keep
+        hip_ops.SIDE_WGRAD, hip_ops.SLOT_ACCUMULATE = keep, True
 
 
 # ----------------------------------------------------------------------------- the C ABI without Python

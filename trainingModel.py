@@ -81,7 +81,7 @@ def train_gan(a):
               save_path_G=only0(a.save_path_G), save_path_D=only0(a.save_path_D), info_print_interval=50, info_plot_interval=50,
               loss_metrics_file=only0(a.loss_metrics_file), save_path_img=a.save_path_img, checkpoint_iterval=1,
               discriminator_train_ratio=5, discriminator_lambda=10, step_scheduler_G_gamma=0.9999, step_scheduler_D_gamma=0.9999,
-              visualization_RGBD_AP=None)
+              visualization_RGBD_AP=(val_set[0] if rank == 0 else None))  # trainingModel.py:96: dataset_validate[0]
 
 
 if __name__ == "__main__":
