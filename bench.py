@@ -43,7 +43,8 @@ if REPO not in sys.path:
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md, chip-level parameters)
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (same table)
-KERNEL_SOURCES = ("conv_engine.hip", "gg2_kernel.inc", "gg2b_kernel.inc", "wg2_kernel.inc", "wg2b_kernel.inc", "wg3_kernel.inc")
+KERNEL_SOURCES = ("conv_engine.hip", "gg2_kernel.inc", "gg2b_kernel.inc", "gg3s_kernel.inc", "wg2_kernel.inc", "wg2b_kernel.inc", "wg2s_kernel.inc",
+                  "wg3_kernel.inc")
 
 
 def parse():
@@ -64,6 +65,9 @@ def parse():
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
                     help="f32 (the benchmark metric): exact fp32 MFMA.  bf16 (BASELINE configs[2]/[4], informational): bf16 conv-GEMM operands, "
                          "fp32 accumulation")
+    ap.add_argument("--precision", choices=("default", "fp32", "fp32_split", "fp32_split2", "bf16"), default="default",
+                    help="conv-GEMM arithmetic (hip_ops.set_conv_precision); default: fp32 tensors with the library's default fp32 GEMM mode, "
+                         "or bf16 with --dtype bf16")
     ap.add_argument("--perceptual", type=float, default=0.0,
                     help="weight of the VGG19 perceptual term (reference CLI: 0.1; seeded random VGG weights: throughput only).  The benchmark "
                          "metric follows BASELINE.md's assembled step, which has no VGG term")
@@ -198,7 +202,10 @@ def main():
     dev = torch.device("cuda", local)
     torch.manual_seed(122731 + rank)
 
-    if args.dtype == "bf16":
+    if args.precision != "default":
+        hip_ops.set_conv_precision(args.precision)
+        args.dtype = "bf16" if args.precision == "bf16" else "f32"
+    elif args.dtype == "bf16":
         hip_ops.set_conv_precision("bf16")
     bf16 = args.dtype == "bf16"
     mfma_peak = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS

@@ -39,7 +39,7 @@ enum {
 };
 
 enum { LHG_ACT_NONE = 0, LHG_ACT_RELU = 1, LHG_ACT_LEAKY = 2, LHG_ACT_SIGMOID = 3 };
-enum { LHG_PRECISION_F32 = 0, LHG_PRECISION_BF16 = 1 };
+enum { LHG_PRECISION_F32 = 0, LHG_PRECISION_BF16 = 1, LHG_PRECISION_F32_SPLIT = 2, LHG_PRECISION_F32_SPLIT2 = 3 };
 
 typedef void* lhg_stream_t; /* hipStream_t */
 
@@ -64,13 +64,25 @@ int lhg_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, i
 /* NHWC (first C of ld channels) -> NCHW.  Adjoint of the above. */
 int lhg_nhwc_to_nchw(const float* src, int ld, float* dst, int N, int C, int H, int W, lhg_stream_t s);
 
-/* Operand precision of the gather-GEMM behind conv / conv-transpose forward and input-gradient (process-wide, default
- * LHG_PRECISION_F32 = exact fp32 MFMA).  LHG_PRECISION_BF16 (BASELINE configs[2], [4]): tensors stay fp32 in memory, the GEMM
+/* Operand precision of the gather-GEMM behind conv / conv-transpose forward and input-gradient (process-wide; see
+ * lhg_default_conv_precision).  LHG_PRECISION_F32 = exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  LHG_PRECISION_BF16 (BASELINE configs[2], [4]): tensors stay fp32 in memory, the GEMM
  * rounds its operands to bf16 (nearest even) and accumulates in fp32 on v_mfma_f32_32x32x16_bf16; lhg_pack_weight then writes
  * bf16 panels into `dst`, so panels must be re-packed after a mode change.  The weight-gradient GEMMs round x and gy the same
- * way (lhg_conv2d_wgrad_splits depends on the mode).  Thin convolutions and every non-GEMM kernel are unaffected. */
+ * way (lhg_conv2d_wgrad_splits depends on the mode).  Thin convolutions and every non-GEMM kernel are unaffected.
+ *
+ * LHG_PRECISION_F32_SPLIT: fp32 tensors, fp32-faithful results on the bf16 matrix pipe.  Every operand is split exactly into three
+ * bf16 terms (x = x0 + x1 + x2) and a product is the sum of the six bf16 products a_i*b_j with i + j < 3 (each exact in fp32; the
+ * dropped ones are below 2^-24 |a b|), accumulated in fp32: 6/16 of the exact kernel's matrix time, results within a few fp32 ulps
+ * of the accumulated sum of the exact kernel.  Applies to the gather-GEMM and to the weight-gradient GEMMs; lhg_pack_weight writes
+ * split panels of lhg_packed_weight_floats() floats.  LHG_PRECISION_F32_SPLIT2 keeps two terms (three products, ~2^-16 relative):
+ * for measurements only. */
 int lhg_set_conv_precision(int precision);
 int lhg_get_conv_precision(void);
+/* the mode the library starts in: LHG_PRECISION_F32_SPLIT unless the environment variable LHG_CONV_PRECISION
+ * (fp32 | fp32_split | fp32_split2 | bf16) names another one */
+int lhg_default_conv_precision(void);
+/* floats the caller must allocate for lhg_pack_weight's `dst` in the current precision mode */
+long long lhg_packed_weight_floats(int taps, int rows_pad, int k_pad);
 
 /* Pack a PyTorch 4-D weight w[D0][D1][KH][KW] into GEMM panels dst[KH*KW][rows_pad][k_pad],
  * K contiguous, zero padded.  rows_from_d0 = 1: rows = D0, K = D1 (Conv2d forward,

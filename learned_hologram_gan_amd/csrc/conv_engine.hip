@@ -26,6 +26,7 @@
 #include <array>
 #include <cstdlib>
 #include <map>
+#include <string>
 #include <utility>
 #include <vector>
 
@@ -236,6 +237,7 @@ __global__ __launch_bounds__(256, 2) void gg_kernel(const GGParams p) {
 
 #include "gg2_kernel.inc"
 #include "gg2b_kernel.inc"
+#include "gg3s_kernel.inc"
 
 // ------------------------------------------------------------------------------------ wg_kernel
 constexpr int WG_TILE = 64;
@@ -325,6 +327,7 @@ __global__ __launch_bounds__(256, 2) void wg_kernel(const WGParams p) {
 
 #include "wg2_kernel.inc"
 #include "wg2b_kernel.inc"
+#include "wg2s_kernel.inc"
 #include "wg3_kernel.inc"
 
 // ------------------------------------------------------------------------------------ small kernels
@@ -359,6 +362,32 @@ __global__ void pack_weight_bf16_kernel(const float* __restrict__ w, int D0, int
       v = w[((size_t)d0 * D1 + d1) * T + t];
     }
     dst[i] = (__bf16)v;  // round to nearest even
+  }
+}
+
+// Split panels for gg3s_kernel: dst[t][row][k chunk][plane][32 k] bf16, plane q of w = q-th term of the exact bf16 expansion.
+template <int NP>
+__global__ void pack_weight_split_kernel(const float* __restrict__ w, int D0, int D1, int T, int rows_from_d0,
+                                         __bf16* __restrict__ dst, int rows_pad, int k_pad) {
+  const size_t total = (size_t)T * rows_pad * k_pad;
+  const int kch = k_pad / 32;
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
+    const int k = (int)(i % k_pad);
+    const int row = (int)((i / k_pad) % rows_pad);
+    const int t = (int)(i / ((size_t)k_pad * rows_pad));
+    const int rows = rows_from_d0 ? D0 : D1, K = rows_from_d0 ? D1 : D0;
+    float v = 0.f;
+    if (row < rows && k < K) {
+      const int d0 = rows_from_d0 ? row : k, d1 = rows_from_d0 ? k : row;
+      v = w[((size_t)d0 * D1 + d1) * T + t];
+    }
+    __bf16* out = dst + ((((size_t)t * rows_pad + row) * kch + k / 32) * NP) * 32 + (k & 31);
+#pragma unroll
+    for (int q = 0; q < NP; ++q) {
+      const __bf16 h = (__bf16)v;  // round to nearest even
+      out[q * 32] = h;
+      v -= (float)h;               // exact
+    }
   }
 }
 
@@ -474,16 +503,34 @@ static int xcd_order() {
   return on;
 }
 
-// process-wide operand precision of the gather-GEMM (lhg_set_conv_precision); weight gradients always run in fp32
-static int g_precision = LHG_PRECISION_F32;
+// process-wide arithmetic of the conv GEMMs (lhg_set_conv_precision).  Default: fp32-faithful split kernels; the environment
+// variable LHG_CONV_PRECISION = fp32 | fp32_split | fp32_split2 | bf16 overrides it for programs whose flags must stay the reference's.
+static int default_precision() {
+  static const int d = [] {
+    const char* e = getenv("LHG_CONV_PRECISION");
+    if (!e) return (int)LHG_PRECISION_F32_SPLIT;
+    const std::string v(e);
+    if (v == "fp32" || v == "f32") return (int)LHG_PRECISION_F32;
+    if (v == "bf16") return (int)LHG_PRECISION_BF16;
+    if (v == "fp32_split2") return (int)LHG_PRECISION_F32_SPLIT2;
+    return (int)LHG_PRECISION_F32_SPLIT;
+  }();
+  return d;
+}
+static int g_precision = default_precision();
 
 static int launch_gg_bf16(GGParams& p, hipStream_t st);
+static int launch_gg_split(GGParams& p, hipStream_t st);
+
+static inline bool split_mode() { return g_precision == LHG_PRECISION_F32_SPLIT || g_precision == LHG_PRECISION_F32_SPLIT2; }
+static inline int split_planes() { return g_precision == LHG_PRECISION_F32_SPLIT2 ? 2 : 3; }
 
 static int launch_gg(GGParams& p, hipStream_t st) {
   const Geom& g = p.g;
   if (g.M <= 0) return LHG_OK;
   p.xcd = xcd_order();
   if (g_precision == LHG_PRECISION_BF16) return launch_gg_bf16(p, st);
+  if (split_mode()) return launch_gg_split(p, st);
   LHG_REQUIRE(g.Ci % BK == 0 && g.Ci > 0, "gather-GEMM: K channels (%d) must be a positive multiple of 32", g.Ci);
   LHG_REQUIRE(g.ldi % 4 == 0 && (reinterpret_cast<uintptr_t>(p.in) & 15) == 0, "gather-GEMM: input must be 16-byte aligned (ld %d)", g.ldi);
   LHG_REQUIRE((reinterpret_cast<uintptr_t>(p.wp) & 15) == 0, "gather-GEMM: packed weights must be 16-byte aligned");
@@ -573,6 +620,52 @@ static int launch_gg_bf16(GGParams& p, hipStream_t st) {
   return check_launch("gg2b_kernel");
 }
 
+// fp32 operands as exact sums of bf16 terms (gg3s_kernel): `p.wp` holds split panels (lhg_pack_weight in the same mode).
+static int launch_gg_split(GGParams& p, hipStream_t st) {
+  const Geom& g = p.g;
+  const int NP = split_planes();
+  LHG_REQUIRE(g.Ci % BK == 0 && g.Ci > 0, "gather-GEMM: K channels (%d) must be a positive multiple of 32", g.Ci);
+  LHG_REQUIRE(g.ldi % 4 == 0 && (reinterpret_cast<uintptr_t>(p.in) & 15) == 0, "gather-GEMM: input must be 16-byte aligned (ld %d)", g.ldi);
+  LHG_REQUIRE((reinterpret_cast<uintptr_t>(p.wp) & 15) == 0, "gather-GEMM: packed weights must be 16-byte aligned");
+  LHG_REQUIRE(p.rows_pad % 64 == 0 && p.rows_pad >= g.Co, "gather-GEMM: rows_pad %d must be a multiple of 64 covering Co=%d", p.rows_pad, g.Co);
+  LHG_REQUIRE((long long)g.N * g.Ho * g.Wo < (1ll << 31) && (long long)g.N * g.Hi * g.Wi < (1ll << 31), "gather-GEMM: more than 2^31 pixels");
+  int max_ws = 0;
+  for (int t = 0; t < g.T; ++t) max_ws = std::max(max_ws, g.ws[t]);
+  const unsigned long long ib = (((unsigned long long)g.N * g.Hi * g.Wi - 1) * g.ldi + g.Ci) * 4ull;
+  const unsigned long long wp_bytes = (unsigned long long)(max_ws + 1) * p.rows_pad * g.Ci * 2ull * NP;
+  LHG_REQUIRE(wp_bytes < (1ull << 32) - 64, "gather-GEMM (split mode): weight panels of 4 GiB and more are not supported");
+  const unsigned wb = (unsigned)wp_bytes;
+  auto blocks = [&](int bm, int bn) { return (unsigned)(((g.M + bm - 1) / bm) * (p.rows_pad / bn)); };
+  const bool n128 = p.rows_pad % 128 == 0;
+  constexpr int NV = 3;
+  auto valid = [&](int v) { return v == 0 ? n128 : true; };
+  auto run = [&](int v) {
+    if (NP == 3) {
+      switch (v) {
+        case 0: hipLaunchKernelGGL((gg3s_kernel<128, 128, 3, 2>), dim3(blocks(128, 128)), dim3(512), 0, st, p, ib, wb); break;
+        case 1: hipLaunchKernelGGL((gg3s_kernel<128, 64, 3, 2>), dim3(blocks(128, 64)), dim3(512), 0, st, p, ib, wb); break;
+        default: hipLaunchKernelGGL((gg3s_kernel<64, 64, 3, 2>), dim3(blocks(64, 64)), dim3(512), 0, st, p, ib, wb); break;
+      }
+    } else {
+      switch (v) {
+        case 0: hipLaunchKernelGGL((gg3s_kernel<128, 128, 2, 2>), dim3(blocks(128, 128)), dim3(512), 0, st, p, ib, wb); break;
+        case 1: hipLaunchKernelGGL((gg3s_kernel<128, 64, 2, 2>), dim3(blocks(128, 64)), dim3(512), 0, st, p, ib, wb); break;
+        default: hipLaunchKernelGGL((gg3s_kernel<64, 64, 2, 2>), dim3(blocks(64, 64)), dim3(512), 0, st, p, ib, wb); break;
+      }
+    }
+  };
+  static const int forced = [] { const char* e = getenv("LHG_GGS_VARIANT"); return e ? atoi(e) : -1; }();
+  int choice = (forced >= 0 && forced < NV && valid(forced)) ? forced : -1;
+  if (choice < 0 && g_autotune_enabled) {
+    const std::array<int, 12> key = {g.M, p.rows_pad, g.Ci, g.Co, g.T, g.istep, g.ostep, g.Hi, g.Wi, g.ldi, g.ldo, p.planar_out + 4 * g_precision};
+    choice = autotuned_variant(g_gg_choice, key, NV, valid, run, st);
+  }
+  if (choice < 0) choice = n128 && blocks(128, 128) >= 200 ? 0 : (blocks(128, 64) >= 256 ? 1 : 2);
+  ScopedKernelTime timed(0, st, 2.0 * g.M * (double)p.rows_pad * g.Ci * g.T);
+  run(choice);
+  return check_launch("gg3s_kernel");
+}
+
 static int launch_wg(WGParams& p, int S, hipStream_t st, const WG3Params* p3 = nullptr) {
   const Geom& g = p.g;
   p.xcd = xcd_order();
@@ -587,10 +680,14 @@ static int launch_wg(WGParams& p, int S, hipStream_t st, const WG3Params* p3 = n
   const bool small = in_bytes < (1ull << 32) - 64 && go_bytes < (1ull << 32) - 64;
   const unsigned ib = (unsigned)in_bytes, gb = (unsigned)go_bytes;
   const bool m128 = p.m_pad % 128 == 0, n128 = p.n_pad % 128 == 0;
-  constexpr int NV = 10;  // 5: nine-tap fused kernel for 3x3 stride 1; 6..9: bf16-operand kernels (lhg_set_conv_precision)
+  constexpr int NV = 14;  // 5: nine-tap fused kernel for 3x3 stride 1; 6..9: bf16-operand kernels; 10..13: split (fp32-faithful) kernels
   const bool bf16 = g_precision == LHG_PRECISION_BF16;
-  if (bf16) LHG_REQUIRE(small, "wgrad (bf16 mode): tensors of 4 GiB and more are not supported");
+  const bool split = split_mode();
+  const int NP = split_planes();
+  if (bf16 || split) LHG_REQUIRE(small, "wgrad (bf16 / split mode): tensors of 4 GiB and more are not supported");
   auto valid = [&](int v) {
+    if (split) return v >= 10 && (v == 10 ? m128 && n128 : v == 11 ? m128 : v == 12 ? n128 : true);
+    if (v >= 10) return false;
     if (bf16) return v >= 6 && (v == 6 ? m128 && n128 : v == 7 ? m128 : v == 8 ? n128 : true);
     if (v >= 6) return false;
     if (v == 5) return p3 != nullptr && small;
@@ -613,6 +710,22 @@ static int launch_wg(WGParams& p, int S, hipStream_t st, const WG3Params* p3 = n
       case 7: hipLaunchKernelGGL((wg2b_kernel<128, 64>), grid(128, 64), dim3(256), 0, st, p, ib, gb); break;
       case 8: hipLaunchKernelGGL((wg2b_kernel<64, 128>), grid(64, 128), dim3(256), 0, st, p, ib, gb); break;
       case 9: hipLaunchKernelGGL((wg2b_kernel<64, 64>), grid(64, 64), dim3(256), 0, st, p, ib, gb); break;
+      case 10:
+        if (NP == 3) hipLaunchKernelGGL((wg2s_kernel<128, 128, 3, 1>), grid(128, 128), dim3(256), 0, st, p, ib, gb);
+        else hipLaunchKernelGGL((wg2s_kernel<128, 128, 2, 2>), grid(128, 128), dim3(256), 0, st, p, ib, gb);
+        break;
+      case 11:
+        if (NP == 3) hipLaunchKernelGGL((wg2s_kernel<128, 64, 3, 2>), grid(128, 64), dim3(256), 0, st, p, ib, gb);
+        else hipLaunchKernelGGL((wg2s_kernel<128, 64, 2, 2>), grid(128, 64), dim3(256), 0, st, p, ib, gb);
+        break;
+      case 12:
+        if (NP == 3) hipLaunchKernelGGL((wg2s_kernel<64, 128, 3, 2>), grid(64, 128), dim3(256), 0, st, p, ib, gb);
+        else hipLaunchKernelGGL((wg2s_kernel<64, 128, 2, 2>), grid(64, 128), dim3(256), 0, st, p, ib, gb);
+        break;
+      case 13:
+        if (NP == 3) hipLaunchKernelGGL((wg2s_kernel<64, 64, 3, 2>), grid(64, 64), dim3(256), 0, st, p, ib, gb);
+        else hipLaunchKernelGGL((wg2s_kernel<64, 64, 2, 2>), grid(64, 64), dim3(256), 0, st, p, ib, gb);
+        break;
       default: hipLaunchKernelGGL(wg_kernel, grid(64, 64), dim3(256), 0, st, p); break;
     }
   };
@@ -624,6 +737,7 @@ static int launch_wg(WGParams& p, int S, hipStream_t st, const WG3Params* p3 = n
     const std::array<int, 12> key = {g.M, p.m_pad, p.n_pad, g.T, S, g.istep, g.ostep, g.Hi, g.Wi, g.ldi, g.ldo, g.ws[0] + 100 * g_precision};
     choice = autotuned_variant(g_wg_choice, key, NV, valid, run, st);
   }
+  if (choice < 0 && split) choice = m128 && n128 && (p.m_pad / 128) * (p.n_pad / 128) * g.T * S >= 200 ? 10 : 13;
   if (choice < 0 && bf16) choice = m128 && n128 && (p.m_pad / 128) * (p.n_pad / 128) * g.T * S >= 400 ? 6 : 9;
   if (choice < 0) choice = small ? (p3 ? 5 : (m128 && n128 && (p.m_pad / 128) * (p.n_pad / 128) * g.T * S >= 400 ? 0 : 3)) : 4;
   ScopedKernelTime timed(1, st, 2.0 * g.M * (double)p.m_pad * p.n_pad * g.T);
@@ -707,7 +821,13 @@ int lhg_pack_weight(const float* w, int D0, int D1, int KH, int KW, int rows_fro
   LHG_REQUIRE(rows_pad >= rows && k_pad >= K && rows_pad % 64 == 0 && k_pad % 32 == 0, "pack_weight: bad padding (%d>=%d, %d>=%d)", rows_pad, rows, k_pad, K);
   const size_t total = (size_t)KH * KW * rows_pad * k_pad;
   const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
-  if (g_precision == LHG_PRECISION_BF16)
+  if (g_precision == LHG_PRECISION_F32_SPLIT)
+    hipLaunchKernelGGL(pack_weight_split_kernel<3>, dim3(blocks), dim3(256), 0, as_stream(s), w, D0, D1, KH * KW, rows_from_d0,
+                       reinterpret_cast<__bf16*>(dst), rows_pad, k_pad);
+  else if (g_precision == LHG_PRECISION_F32_SPLIT2)
+    hipLaunchKernelGGL(pack_weight_split_kernel<2>, dim3(blocks), dim3(256), 0, as_stream(s), w, D0, D1, KH * KW, rows_from_d0,
+                       reinterpret_cast<__bf16*>(dst), rows_pad, k_pad);
+  else if (g_precision == LHG_PRECISION_BF16)
     hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3(blocks), dim3(256), 0, as_stream(s), w, D0, D1, KH * KW, rows_from_d0,
                        reinterpret_cast<__bf16*>(dst), rows_pad, k_pad);
   else
@@ -716,12 +836,22 @@ int lhg_pack_weight(const float* w, int D0, int D1, int KH, int KW, int rows_fro
 }
 
 int lhg_set_conv_precision(int precision) {
-  LHG_REQUIRE(precision == LHG_PRECISION_F32 || precision == LHG_PRECISION_BF16, "set_conv_precision: unknown precision %d", precision);
+  LHG_REQUIRE(precision >= LHG_PRECISION_F32 && precision <= LHG_PRECISION_F32_SPLIT2, "set_conv_precision: unknown precision %d", precision);
   g_precision = precision;
   return LHG_OK;
 }
 
 int lhg_get_conv_precision(void) { return g_precision; }
+int lhg_default_conv_precision(void) { return default_precision(); }
+
+long long lhg_packed_weight_floats(int taps, int rows_pad, int k_pad) {
+  const long long elems = (long long)taps * rows_pad * k_pad;
+  switch (g_precision) {
+    case LHG_PRECISION_F32_SPLIT: return elems * 3 / 2;   // three bf16 planes
+    case LHG_PRECISION_F32_SPLIT2: return elems;          // two bf16 planes
+    default: return elems;                                // fp32 panels (bf16 panels use half of it)
+  }
+}
 
 int lhg_conv2d_forward(const float* x, int N, int H, int W, int Ci, int ldx, const float* wp, int rows_pad, int KH, int KW, int stride,
                        float* y, int Co, int ldy, const float* bias, const float* scale, const float* shift,

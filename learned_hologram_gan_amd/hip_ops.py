@@ -285,29 +285,46 @@ def _weight_grad(w, inputs, fn):
 
 
 # --------------------------------------------------------------------------- operand precision of the conv GEMMs
-_PRECISIONS = {"fp32": 0, "f32": 0, "bf16": 1}
-_precision = 0
+_PRECISIONS = {"fp32": 0, "f32": 0, "bf16": 1, "fp32_split": 2, "fp32_split2": 3}
+_PRECISION_NAMES = {0: "fp32", 1: "bf16", 2: "fp32_split", 3: "fp32_split2"}
+_precision = None  # read from the library on first use (it starts in lhg_default_conv_precision())
+
+
+def _mode() -> int:
+    global _precision
+    if _precision is None:
+        _precision = int(native.load().lhg_get_conv_precision())
+    return _precision
+
+
+def default_precision() -> str:
+    """The mode the library starts in: "fp32_split" unless LHG_CONV_PRECISION (fp32 | fp32_split | fp32_split2 | bf16) says otherwise."""
+    return _PRECISION_NAMES[int(native.load().lhg_default_conv_precision())]
 
 
 def set_conv_precision(name: str) -> None:
-    """"fp32" (default, exact fp32 MFMA) or "bf16" (bf16 operands, fp32 accumulation, fp32 tensors): see lhg_set_conv_precision."""
+    """Arithmetic of the conv GEMMs (tensors are fp32 in every mode), see lhg_set_conv_precision:
+    "fp32_split"  fp32-faithful on the bf16 matrix pipe: operands as exact sums of three bf16 terms, six MFMA products, fp32 accumulate;
+    "fp32"        exact fp32 MFMA (v_mfma_f32_32x32x2_f32);
+    "fp32_split2" two bf16 terms, three products (~2^-16 per product), measurements only;
+    "bf16"        operands rounded to bf16, fp32 accumulation (BASELINE configs[2] / [4]);
+    "default"     back to default_precision()."""
     global _precision
+    if name == "default":
+        name = default_precision()
     if name not in _PRECISIONS:
-        raise ValueError(f"unknown precision {name!r} (fp32 | bf16)")
+        raise ValueError(f"unknown precision {name!r} ({' | '.join(_PRECISIONS)} | default)")
     call("lhg_set_conv_precision", _PRECISIONS[name])
     _precision = _PRECISIONS[name]
 
 
 def conv_precision() -> str:
-    return "bf16" if _precision else "fp32"
+    return _PRECISION_NAMES[_mode()]
 
 
 def apply_env_precision() -> None:
-    """LHG_CONV_PRECISION=bf16 selects the bf16 operand mode for programs whose flags must stay the reference's (trainingModel.py,
-    generatePOH.py).  Called by the trainer / generator constructors."""
-    want = os.environ.get("LHG_CONV_PRECISION")
-    if want and _PRECISIONS.get(want, _precision) != _precision:
-        set_conv_precision(want)
+    """Kept for the entry points (trainingModel.py, generatePOH.py): LHG_CONV_PRECISION is read by the library itself at load time."""
+    _mode()
 
 
 # --------------------------------------------------------------------------- weight packing
@@ -325,15 +342,16 @@ def pack_weight(w: torch.Tensor, rows_from_d0: bool, k_pad_to: int = 32) -> torc
         cache = w.__dict__.setdefault("_lhg_packed", {})
     except AttributeError:  # pragma: no cover
         cache = {}
-    hit = cache.get((rows_from_d0, k_pad, _precision))
+    hit = cache.get((rows_from_d0, k_pad, _mode()))
     if hit is not None and hit[0] == stamp:
         return hit[1]
     wd = w.detach()
     if not wd.is_contiguous():
         wd = wd.contiguous()
-    out = torch.empty((KH * KW, rows_pad, k_pad), dtype=torch.float32, device=w.device)
+    floats = int(native.load().lhg_packed_weight_floats(KH * KW, rows_pad, k_pad))
+    out = torch.empty((KH * KW, rows_pad, floats // (KH * KW * rows_pad)), dtype=torch.float32, device=w.device)
     call("lhg_pack_weight", ptr(wd), D0, D1, KH, KW, int(rows_from_d0), ptr(out), rows_pad, k_pad, stream_ptr())
-    cache[(rows_from_d0, k_pad, _precision)] = (stamp, out)
+    cache[(rows_from_d0, k_pad, _mode())] = (stamp, out)
     return out
 
 
@@ -508,8 +526,8 @@ class Conv2dInputGradFn(TrackedFunction):
         pg, N, Ho, Wo, Cg, ldg = nhwc(gyp)
         Co, Ci, KH, KW = w.shape
         wp = pack_weight(w, False, 32)
-        if wp.shape[2] != Cg:
-            raise ValueError(f"conv2d input-grad: gy has {Cg} channels, packed K is {wp.shape[2]}")
+        if pad_to(Co, 32) != Cg:
+            raise ValueError(f"conv2d input-grad: gy has {Cg} channels, packed K is {pad_to(Co, 32)}")
         gx = new_nhwc(N, H, W, Cx, gy.device)
         if Cx > Ci:
             gx[..., Ci:].zero_()

@@ -40,6 +40,8 @@ _SIGNATURES = {
     "lhg_nhwc_to_nchw": [_p, _i, _p, _i, _i, _i, _i, _p],
     "lhg_set_conv_precision": [_i],
     "lhg_get_conv_precision": [],
+    "lhg_default_conv_precision": [],
+    "lhg_packed_weight_floats": [C.c_int, C.c_int, C.c_int],
     "lhg_pack_weight": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _p],
     "lhg_conv2d_forward": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _i, _i, _f, _i, _p],
     "lhg_conv2d_backward_input": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p],
@@ -79,7 +81,7 @@ _SIGNATURES = {
     "lhg_psnr_ssim": [_p, _p, _i, _i, _i, _p, _p, _sz, _p],
     "lhg_adam_step": [_p, _p, _p, _p, _ll, _f, _f, _f, _f, _i, _p],
 }
-_RESTYPE = {"lhg_last_error": C.c_char_p, "lhg_conv2d_thin_wgrad_workspace": C.c_size_t, "lhg_psnr_ssim_workspace": C.c_size_t}
+_RESTYPE = {"lhg_last_error": C.c_char_p, "lhg_packed_weight_floats": C.c_longlong, "lhg_conv2d_thin_wgrad_workspace": C.c_size_t, "lhg_psnr_ssim_workspace": C.c_size_t}
 
 _lib = None
 

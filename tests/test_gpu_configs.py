@@ -80,7 +80,7 @@ def test_config2_per_rank_bf16_train_step_384_bs4(oracle_full_step):
         got = dict(zip(("focal_phase_gradient_loss", "perceptual_loss", "pixel_loss", "TV_loss", "gan_loss", "G_loss", "D_loss"),
                        W.train_losses_tensor.tolist()))
     finally:
-        hip_ops.set_conv_precision("fp32")
+        hip_ops.set_conv_precision("default")
     assert out["hat_amps"].shape == (B, 3, cfg["rows"], cfg["cols"])
     p_amp = _psnr(out["hat_amps"].cpu(), ref["hat_amps"])
     p_poh = _psnr(torch.cos(out["POH"].cpu()), torch.cos(ref["POH"]))
@@ -89,7 +89,7 @@ def test_config2_per_rank_bf16_train_step_384_bs4(oracle_full_step):
     for k in ("focal_phase_gradient_loss", "pixel_loss", "TV_loss"):
         assert abs(got[k] - ref[k]) <= 5e-2 * abs(ref[k]) + 1e-6, (k, got[k], ref[k])
     assert abs(got["D_loss"] - ref["D_loss"]) <= 1e-1 * abs(ref["D_loss"]) + 1e-6
-    assert hip_ops.conv_precision() == "fp32"
+    assert hip_ops.conv_precision() == hip_ops.default_precision()
 
 
 # ----------------------------------------------------------------------------- configs[4]: batch 1 per rank, 3-plane reconstruction loss
@@ -135,7 +135,7 @@ def test_config4_per_rank_bs1_three_plane_reconstruction_loss_384(precision):
         (focal + mse + 1e-3 * tv).backward()
         torch.cuda.synchronize()
     finally:
-        hip_ops.set_conv_precision("fp32")
+        hip_ops.set_conv_precision("default")
     named = dict(G.named_parameters())
     probe = ("part1.part1.decoder4.0.convolution_layer_2.weight", "part1.part1.bottleneck.1.0.convolution_layer_1.weight",
              "part1.part1.encoder1.0.0.convolution_layer_1.weight", "part2.part1.conv_g.params")

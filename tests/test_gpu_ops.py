@@ -90,6 +90,57 @@ def test_conv2d_forward_and_gradients(ops, case):
     assert rel_err(bg.grad.cpu(), br.grad) < 5e-5
 
 
+@pytest.mark.parametrize("case", [(2, 64, 64, 48, 48, 3, 1), (2, 128, 256, 24, 24, 3, 1), (2, 512, 512, 12, 12, 3, 1), (2, 64, 128, 24, 24, 1, 1),
+                                  (2, 64, 128, 32, 32, 3, 2), (4, 1024, 1024, 8, 8, 3, 1), (1, 96, 160, 17, 23, 3, 1)], ids=lambda c: "x".join(map(str, c)))
+def test_split_bf16_gemm_is_fp32_faithful(ops, case):
+    """The default GEMM mode ("fp32_split": every operand an exact sum of three bf16 terms, six MFMA products, fp32 accumulation) against a
+    FLOAT64 convolution, next to the exact fp32 MFMA kernels ("fp32") on the same data: forward, input gradient and weight gradient must
+    be as close to the truth as the exact kernels are (same order of rounding error: the sum is accumulated in fp32 either way) and far
+    inside the 2e-5 the per-op parity tests use."""
+    N, Ci, Co, H, W, k, stride = case
+    x = rnd(N, Ci, H, W, seed=11)
+    w = rnd(Co, Ci, k, k, seed=12, scale=(Ci * k * k) ** -0.5)
+    Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+    gy = rnd(N, Co, Ho, Wo, seed=13)
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yd = F.conv2d(xd, wd, None, stride=stride, padding=k // 2)
+    gxd, gwd = torch.autograd.grad(yd, (xd, wd), gy.double())
+    truth = (yd.detach(), gxd, gwd)
+    Cip = ops.pad_to(Ci, 32)
+    xh, gh, wg = to_nhwc(x, Cip), to_nhwc(gy, ops.pad_to(Co, 4)), w.to(DEV)
+
+    def errors(mode):
+        ops.set_conv_precision(mode)
+        try:
+            with torch.no_grad():
+                y = to_nchw(ops.conv2d_forward_raw(xh, wg, None, stride))
+                gx = to_nchw(ops.Conv2dInputGradFn.apply(gh, wg, stride, H, W, Cip))[:, :Ci]
+                gw = ops.Conv2dWeightGradFn.apply(xh, gh, w.shape, stride).cpu()
+        finally:
+            ops.set_conv_precision("default")
+        return [rel_err(a.double(), b) for a, b in zip((y, gx, gw), truth)]
+
+    e_split, e_exact = errors("fp32_split"), errors("fp32")
+    for es, ee in zip(e_split, e_exact):
+        assert es < 1e-5 and es <= 3.0 * ee + 5e-7, (e_split, e_exact)
+
+
+def test_default_gemm_mode_and_env_override():
+    """The library starts in the fp32-faithful split mode unless LHG_CONV_PRECISION names another one (read at load time)."""
+    import os
+    import subprocess
+    import sys
+
+    from learned_hologram_gan_amd import hip_ops
+
+    want = os.environ.get("LHG_CONV_PRECISION", "fp32_split")
+    assert hip_ops.default_precision() == want and hip_ops.conv_precision() == want
+    code = "from learned_hologram_gan_amd import hip_ops; print(hip_ops.conv_precision())"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    out = subprocess.run([sys.executable, "-c", code], cwd=root, env=dict(os.environ, LHG_CONV_PRECISION="fp32"), capture_output=True, text=True)
+    assert out.returncode == 0 and out.stdout.strip().splitlines()[-1] == "fp32", out.stderr[-500:]
+
+
 @pytest.mark.parametrize("case", [(2, 64, 64, 24, 20, 3, 1), (1, 32, 128, 40, 40, 3, 1), (2, 128, 256, 16, 16, 3, 1), (2, 32, 64, 18, 22, 3, 2),
                                   (3, 256, 128, 8, 8, 1, 1), (2, 128, 128, 64, 64, 3, 1)], ids=lambda c: "x".join(map(str, c)))
 def test_conv2d_bf16_operand_mode(ops, case):
@@ -117,7 +168,7 @@ def test_conv2d_bf16_operand_mode(ops, case):
         wgrad_ref = torch.autograd.grad((F.conv2d(rb(x), wr := w.clone().requires_grad_(True), b, stride=stride, padding=k // 2) * rb(proj)).sum(), wr)[0]
         assert rel_err(wg.grad.cpu(), wgrad_ref) < 5e-5  # weight gradient: x and gy rounded to bf16, fp32 accumulation
     finally:
-        ops.set_conv_precision("fp32")
+        ops.set_conv_precision("default")
     # back in fp32 mode the packed panels are fp32 again
     y32 = ops.Conv2dFn.apply(to_nhwc(x), w.to(DEV), b.to(DEV), stride, None)
     assert rel_err(to_nchw(y32), y_exact) < TOL

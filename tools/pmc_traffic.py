@@ -13,7 +13,8 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def kernel_source_sha16():
     h = hashlib.sha256()
-    for name in ("conv_engine.hip", "gg2_kernel.inc", "gg2b_kernel.inc", "wg2_kernel.inc", "wg2b_kernel.inc", "wg3_kernel.inc"):  # = bench.KERNEL_SOURCES
+    for name in ("conv_engine.hip", "gg2_kernel.inc", "gg2b_kernel.inc", "gg3s_kernel.inc", "wg2_kernel.inc", "wg2b_kernel.inc", "wg2s_kernel.inc",
+                 "wg3_kernel.inc"):  # = bench.KERNEL_SOURCES
         with open(os.path.join(REPO, "learned_hologram_gan_amd", "csrc", name), "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
@@ -23,9 +24,9 @@ def family(name):
     head = name.split("(")[0]
     if "wgrad_reduce" in head or "pack_weight" in head:
         return None
-    if "gg2_kernel" in head or "gg_kernel" in head:
+    if "gg2_kernel" in head or "gg_kernel" in head or "gg3s_kernel" in head or "gg2b_kernel" in head:
         return "gg"
-    if "wg3_kernel" in head or "wg2_kernel" in head or "wg_kernel" in head:
+    if "wg3_kernel" in head or "wg2_kernel" in head or "wg_kernel" in head or "wg2s_kernel" in head or "wg2b_kernel" in head:
         return "wg"
     return None
 
