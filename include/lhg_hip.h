@@ -29,7 +29,7 @@
 extern "C" {
 #endif
 
-#define LHG_ABI_VERSION 1
+#define LHG_ABI_VERSION 2
 
 enum {
   LHG_OK = 0,
@@ -152,13 +152,15 @@ int lhg_conv_transpose2x2_backward_weight(const float* x, int N, int H, int W, i
                                           const float* gy, int Co, int ldgy,
                                           float* slabs, int S, int ci_pad, int co_pad, lhg_stream_t s);
 
-/* grad[D0][D1][KH][KW] = sum_s slabs[s][t][m][n]  (m = conv-input channel, n = conv-output
- * channel).  m_is_d1 = 1 for Conv2d (OIHW: D0 = n, D1 = m), 0 for ConvTranspose2d (IOHW). */
+/* grad[D0][D1][KH][KW] (+)= sum_s slabs[s][t][m][n]  (m = conv-input channel, n = conv-output
+ * channel).  m_is_d1 = 1 for Conv2d (OIHW: D0 = n, D1 = m), 0 for ConvTranspose2d (IOHW).
+ * accumulate != 0 adds to `grad` (a parameter's slot of the flat gradient buffer: what autograd's AccumulateGrad would do
+ * with one more launch; ref: loss.backward() call sites watermelon.py:256, 275). */
 int lhg_wgrad_reduce(const float* slabs, int S, int T, int m_pad, int n_pad,
-                     float* grad, int D0, int D1, int m_is_d1, lhg_stream_t s);
+                     float* grad, int D0, int D1, int m_is_d1, int accumulate, lhg_stream_t s);
 
-/* out[c] = sum over pixels of x[pixel][c]  (bias gradients).  ws: >= 2048*C floats. */
-int lhg_channel_sum(const float* x, long long pixels, int C, int ld, float* out, float* ws, lhg_stream_t s);
+/* out[c] (+)= sum over pixels of x[pixel][c]  (bias gradients).  ws: >= 2048*C floats. */
+int lhg_channel_sum(const float* x, long long pixels, int C, int ld, float* out, int accumulate, float* ws, lhg_stream_t s);
 
 /* ------------------------------------------------------------------ batch norm (train / eval)
  * ref: nn.LazyBatchNorm2d neural_network_components.py:23-24, nn.BatchNorm2d discriminator.py:39.
@@ -173,12 +175,12 @@ int lhg_bn_apply(const float* x, int ldx, long long pixels, int C, const float* 
                  const float* gamma, const float* beta, const float* res, int ldres,
                  int act, float slope, float* y, int ldy, lhg_stream_t s);
 /* Backward of y = act(bn(x) + res) given gy:  g = gy * act'(y);  gres = g (if non-NULL);
- * gx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); ggamma = sum g*xhat; gbeta = sum g.
+ * gx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); ggamma (+)= sum g*xhat; gbeta (+)= sum g  (accumulate != 0 adds).
  * `y` is the forward OUTPUT (sign gives the activation mask).  ws: >= 8192*C floats. */
 int lhg_bn_backward(const float* gy, int ldgy, const float* x, int ldx, const float* y, int ldy,
                     long long pixels, int C, const float* stats, const float* gamma,
                     int act, float slope, float* gx, int ldgx, float* gres, int ldgres,
-                    float* ggamma, float* gbeta, float* ws, lhg_stream_t s);
+                    float* ggamma, float* gbeta, int accumulate, float* ws, lhg_stream_t s);
 /* Double backward of the gx output above (WGAN-GP, ref: watermelon.py:466-473):
  * given ggx (cotangent of gx) returns ggy (cotangent of gy), gx2 (cotangent of x) and
  * ggamma2 (cotangent of gamma).  ws: >= 5*4096*C floats. */

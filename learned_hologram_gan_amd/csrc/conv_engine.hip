@@ -395,7 +395,7 @@ __global__ void pack_weight_split_kernel(const float* __restrict__ w, int D0, in
 // slices; each thread sums every 4th slab, then the slices are combined through LDS.
 template <int LANES>  // outputs per block; 256 / LANES slab slices
 __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restrict__ slabs, int S, int T, int m_pad, int n_pad,
-                                                           float* __restrict__ grad, int D0, int D1, int m_is_d1) {
+                                                           float* __restrict__ grad, int D0, int D1, int m_is_d1, int accumulate) {
   constexpr int SLICES = 256 / LANES;
   __shared__ float red[SLICES][LANES];
   const int M = m_is_d1 ? D1 : D0, Nn = m_is_d1 ? D0 : D1;
@@ -421,7 +421,7 @@ __global__ __launch_bounds__(256) void wgrad_reduce_kernel(const float* __restri
       float v = 0.f;
 #pragma unroll
       for (int k = 0; k < SLICES; ++k) v += red[k][lane_o];
-      grad[dst] = v;
+      grad[dst] = accumulate ? grad[dst] + v : v;  // one writer per element: accumulating into a gradient slot is ordered by the stream
     }
     __syncthreads();
   }
@@ -1002,14 +1002,15 @@ int lhg_conv_transpose2x2_backward_weight(const float* x, int N, int H, int W, i
   return LHG_OK;
 }
 
-int lhg_wgrad_reduce(const float* slabs, int S, int T, int m_pad, int n_pad, float* grad, int D0, int D1, int m_is_d1, lhg_stream_t s) {
+int lhg_wgrad_reduce(const float* slabs, int S, int T, int m_pad, int n_pad, float* grad, int D0, int D1, int m_is_d1, int accumulate,
+                     lhg_stream_t s) {
   const size_t total = (size_t)T * D0 * D1;
   if (total * 4 < (size_t)S * 64 || total < 65536) {  // few outputs, many slabs: spend the threads on the slab axis
     const int blocks = (int)std::min<size_t>((total + 15) / 16, 16384);
-    hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(blocks), dim3(256), 0, as_stream(s), slabs, S, T, m_pad, n_pad, grad, D0, D1, m_is_d1);
+    hipLaunchKernelGGL(wgrad_reduce_kernel<16>, dim3(blocks), dim3(256), 0, as_stream(s), slabs, S, T, m_pad, n_pad, grad, D0, D1, m_is_d1, accumulate);
   } else {
     const int blocks = (int)std::min<size_t>((total + 63) / 64, 16384);
-    hipLaunchKernelGGL(wgrad_reduce_kernel<64>, dim3(blocks), dim3(256), 0, as_stream(s), slabs, S, T, m_pad, n_pad, grad, D0, D1, m_is_d1);
+    hipLaunchKernelGGL(wgrad_reduce_kernel<64>, dim3(blocks), dim3(256), 0, as_stream(s), slabs, S, T, m_pad, n_pad, grad, D0, D1, m_is_d1, accumulate);
   }
   return check_launch("wgrad_reduce");
 }

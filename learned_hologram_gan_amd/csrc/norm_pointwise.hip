@@ -128,7 +128,8 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ 
 // accumulators per thread keep several loads in flight (the kernel is latency-bound: 2048 partial rows, few workgroups).
 constexpr int RP_SLICES = 32;
 template <int NSUM>
-__global__ __launch_bounds__(1024) void reduce_partials(const float* __restrict__ partial, int nblk, int C, float* __restrict__ sums) {
+__global__ __launch_bounds__(1024) void reduce_partials(const float* __restrict__ partial, int nblk, int C, float* __restrict__ sums,
+                                                        int accumulate = 0) {
   __shared__ double red[RP_SLICES][32];
   const int lane_c = threadIdx.x & 31, slice = threadIdx.x >> 5, k = blockIdx.y;
   const int c = blockIdx.x * 32 + lane_c;
@@ -151,7 +152,8 @@ __global__ __launch_bounds__(1024) void reduce_partials(const float* __restrict_
     double s = 0;
 #pragma unroll
     for (int i = 0; i < RP_SLICES; ++i) s += red[i][lane_c];
-    sums[(size_t)k * C + c] = (float)s;
+    float* dst = sums + (size_t)k * C + c;
+    *dst = accumulate ? *dst + (float)s : (float)s;
   }
 }
 
@@ -160,15 +162,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ gy
                                                     const float* __restrict__ stats, const float* __restrict__ gamma,
                                                     const float* __restrict__ sums, int act, float slope,
                                                     float* __restrict__ gx, int ldgx, float* __restrict__ gres, int ldgres,
-                                                    float* __restrict__ ggamma, float* __restrict__ gbeta, int lanes_c, int rows) {
+                                                    float* __restrict__ ggamma, float* __restrict__ gbeta, int accumulate, int lanes_c,
+                                                    int rows) {
   const int tx = threadIdx.x % lanes_c, ty = threadIdx.x / lanes_c;
   const float invn = 1.f / (float)pixels;
   for (int cb = tx * 4; cb < C; cb += lanes_c * 4) {
     const f32x4 mean = ld4(stats + cb), inv = ld4(stats + C + cb), gam = ld4(gamma + cb);
     const f32x4 sg = ld4(sums + cb), sgx = ld4(sums + C + cb);
-    if (blockIdx.x == 0 && ty == 0) {
-      if (ggamma) st4(ggamma + cb, sgx);
-      if (gbeta) st4(gbeta + cb, sg);
+    if (blockIdx.x == 0 && ty == 0) {  // one writer per channel: accumulation into a gradient slot is race free and ordered by the stream
+      if (ggamma) st4(ggamma + cb, accumulate ? ld4(ggamma + cb) + sgx : sgx);
+      if (gbeta) st4(gbeta + cb, accumulate ? ld4(gbeta + cb) + sg : sg);
     }
     const f32x4 k = gam * inv, mg = sg * invn, mgx = sgx * invn;
     for (long long q = (long long)blockIdx.x * rows + ty; q < pixels; q += (long long)gridDim.x * rows) {
@@ -398,12 +401,12 @@ int lhg_nhwc_to_nchw(const float* src, int ld, float* dst, int N, int C, int H, 
   return check_launch("nhwc_to_nchw");
 }
 
-int lhg_channel_sum(const float* x, long long pixels, int C, int ld, float* out, float* ws, lhg_stream_t s) {
+int lhg_channel_sum(const float* x, long long pixels, int C, int ld, float* out, int accumulate, float* ws, lhg_stream_t s) {
   LHG_NHWC_OK(x, C, ld, "channel_sum");
   const ColMap cm = col_map(C);
   const int nblk = partial_blocks(pixels);
   hipLaunchKernelGGL(channel_sum_partial, dim3(nblk), dim3(256), 0, as_stream(s), x, pixels, C, ld, cm.lanes_c, cm.rows, ws);
-  hipLaunchKernelGGL(reduce_partials<1>, dim3((C + 31) / 32, 1), dim3(1024), 0, as_stream(s), ws, nblk, C, out);
+  hipLaunchKernelGGL(reduce_partials<1>, dim3((C + 31) / 32, 1), dim3(1024), 0, as_stream(s), ws, nblk, C, out, accumulate);
   return check_launch("channel_sum");
 }
 
@@ -435,7 +438,7 @@ int lhg_bn_apply(const float* x, int ldx, long long pixels, int C, const float* 
 
 int lhg_bn_backward(const float* gy, int ldgy, const float* x, int ldx, const float* y, int ldy, long long pixels, int C,
                     const float* stats, const float* gamma, int act, float slope, float* gx, int ldgx, float* gres, int ldgres,
-                    float* ggamma, float* gbeta, float* ws, lhg_stream_t s) {
+                    float* ggamma, float* gbeta, int accumulate, float* ws, lhg_stream_t s) {
   LHG_NHWC_OK(gy, C, ldgy, "bn_backward(gy)");
   LHG_NHWC_OK(x, C, ldx, "bn_backward(x)");
   LHG_NHWC_OK(gx, C, ldgx, "bn_backward(gx)");
@@ -449,7 +452,7 @@ int lhg_bn_backward(const float* gy, int ldgy, const float* x, int ldx, const fl
   hipLaunchKernelGGL(reduce_partials<2>, dim3((C + 31) / 32, 2), dim3(1024), 0, as_stream(s), ws, nblk, C, sums);
   const int nb2 = grid_for((size_t)pixels, cm.rows * 4, 4096);
   hipLaunchKernelGGL(bn_bwd_apply, dim3(nb2), dim3(256), 0, as_stream(s), gy, ldgy, x, ldx, y, ldy, pixels, C, stats, gamma, sums, act,
-                     slope, gx, ldgx, gres, ldgres, ggamma, gbeta, cm.lanes_c, cm.rows);
+                     slope, gx, ldgx, gres, ldgres, ggamma, gbeta, accumulate, cm.lanes_c, cm.rows);
   return check_launch("bn_backward");
 }
 

@@ -256,12 +256,13 @@ def join_side_stream(device=None) -> None:
 
 
 def _weight_grad(w, inputs, fn):
-    """fn() -> weight gradient from `inputs`.  Plain backward into a registered slot: run on the side stream, accumulate, return None."""
+    """fn(slot) -> weight gradient from `inputs`: with ``slot`` None it returns a new tensor, otherwise it ACCUMULATES into ``slot``.
+    Plain backward into a registered slot: run on the side stream, accumulate, return None (autograd's zero)."""
     slot = _grad_slot(w) if (SLOT_ACCUMULATE and not torch.is_grad_enabled()) else None
     if slot is None:
-        return fn()
+        return fn(None)
     if not (SIDE_WGRAD and w.is_cuda):  # same accumulate-into-the-slot contract on the caller's stream
-        slot.add_(fn())
+        fn(slot)
         note_contribution(w)
         return None
     main, side = torch.cuda.current_stream(w.device), _side_stream(w.device)
@@ -279,9 +280,16 @@ def _weight_grad(w, inputs, fn):
     for t in inputs:
         t.record_stream(side)  # keep their memory out of main-stream reuse until the side stream is done with it
     with torch.cuda.stream(side):
-        slot.add_(fn())
+        fn(slot)
     note_contribution(w)
     return None
+
+
+def _small_grad_slot(p):
+    """Slot of a bias / BatchNorm affine parameter for direct accumulation from the main stream, or None (autograd path)."""
+    if p is None or torch.is_grad_enabled() or not SLOT_ACCUMULATE:
+        return None
+    return _grad_slot(p)
 
 
 # --------------------------------------------------------------------------- operand precision of the conv GEMMs
@@ -481,8 +489,8 @@ class Conv2dFn(TrackedFunction):
         ctx.save_for_backward(x, w)
         ctx.stride, ctx.has_bias = stride, bias is not None
         note_use(w, ctx.needs_input_grad[1])
-        ctx.zero_bias = bias if (ctx.bias_grad_is_zero and bias is not None and ctx.needs_input_grad[2]) else None
-        note_use(ctx.zero_bias)
+        ctx.bias = bias if (bias is not None and ctx.needs_input_grad[2]) else None  # its gradient never passes through autograd
+        note_use(ctx.bias)
         return conv2d_forward_raw(x, w, bias, stride, out=out)
 
     @staticmethod
@@ -495,13 +503,9 @@ class Conv2dFn(TrackedFunction):
         if not param_grads_wanted():  # inside only_input_gradients(): the caller differentiates with respect to activations only
             return gx, None, None, None, None
         if ctx.needs_input_grad[1]:
-            gw = _weight_grad(w, (x, gy), lambda: Conv2dWeightGradFn.apply(x, gy, w.shape, ctx.stride))
+            gw = _weight_grad(w, (x, gy), lambda slot: conv2d_weight_grad(x, gy, w.shape, ctx.stride, slot))
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            # exactly-zero gradient: None (autograd's zero) instead of a zero tensor saves a fill and an accumulate launch per layer
-            if ctx.bias_grad_is_zero and not torch.is_grad_enabled():
-                note_contribution(ctx.zero_bias)
-            else:
-                gb = torch.zeros(w.shape[0], dtype=torch.float32, device=w.device) if ctx.bias_grad_is_zero else channel_sum(gy)
+            gb = _bias_grad(ctx.bias, gy, ctx.bias_grad_is_zero, w.shape[0])
         return gx, gw, gb, None, None
 
 
@@ -543,8 +547,67 @@ class Conv2dInputGradFn(TrackedFunction):
         if ctx.needs_input_grad[0]:
             g_gy = Conv2dFn.apply(ggx, w, None, ctx.stride, None)
         if ctx.needs_input_grad[1] and param_grads_wanted():
-            g_w = _weight_grad(w, (ggx, gy), lambda: Conv2dWeightGradFn.apply(ggx, gy, w.shape, ctx.stride))
+            g_w = _weight_grad(w, (ggx, gy), lambda slot: conv2d_weight_grad(ggx, gy, w.shape, ctx.stride, slot))
         return g_gy, g_w, None, None, None, None
+
+
+def conv2d_weight_grad_raw(x, gy, wshape, stride, slot=None):
+    """gw (OIHW) = sum over pixels of x (gathered) outer gy; no autograd.  With ``slot`` the slab reduction accumulates straight into
+    it (the parameter's view of the flat gradient buffer) and nothing is returned."""
+    Co, Ci, KH, KW = wshape
+    if KH == KW and gy.shape[-1] >= Co and x.shape[-1] >= Ci and thin_mode(Ci, Co, KH, stride):
+        px, N, H, W, _, ldx = nhwc(x)
+        gyv = _as_nhwc_view(gy)
+        pg, _, _, _, _, ldg = nhwc(gyv)
+        nbytes = int(native.load().lhg_conv2d_thin_wgrad_workspace(N, H, W, Ci, Co, KH))
+        ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=x.device)
+        gw = torch.empty(tuple(wshape), dtype=torch.float32, device=x.device)
+        call("lhg_conv2d_thin_backward_weight", px, N, H, W, Ci, ldx, pg, Co, ldg, KH, ptr(gw), ptr(ws), nbytes, stream_ptr())
+        if slot is None:
+            return gw
+        slot.add_(gw)
+        return None
+    gyp = _padded_gy(gy, 4)
+    px, N, H, W, Cx, ldx = nhwc(x)
+    pg, _, _, _, Cg, ldg = nhwc(gyp)
+    lib = native.load()
+    S = lib.lhg_conv2d_wgrad_splits(N, H, W, Cx, Cg, KH, KW, stride)
+    ci_pad, co_pad = pad_to(Cx, 64), pad_to(Cg, 64)
+    slabs = torch.empty((S, KH * KW, ci_pad, co_pad), dtype=torch.float32, device=x.device)
+    native.count_flops(1, 2.0 * N * gy.shape[1] * gy.shape[2] * Co * Ci * KH * KW)
+    call("lhg_conv2d_backward_weight", px, N, H, W, Cx, ldx, pg, Cg, ldg, KH, KW, stride, ptr(slabs), S, ci_pad, co_pad, stream_ptr())
+    gw = slot if slot is not None else torch.empty(tuple(wshape), dtype=torch.float32, device=x.device)
+    if not gw.is_contiguous():
+        raise ValueError("weight-gradient slot must be contiguous")
+    call("lhg_wgrad_reduce", ptr(slabs), S, KH * KW, ci_pad, co_pad, ptr(gw), Co, Ci, 1, int(slot is not None), stream_ptr())
+    return None if slot is not None else gw
+
+
+def conv2d_weight_grad(x, gy, wshape, stride, slot):
+    """Differentiable op without a slot, raw accumulation with one."""
+    if slot is None:
+        return Conv2dWeightGradFn.apply(x, gy, wshape, stride)
+    return conv2d_weight_grad_raw(x, gy, wshape, stride, slot)
+
+
+def _bias_grad(bias, gy, is_zero, Co):
+    """d loss / d bias = sum of gy over pixels.  In a plain backward pass into a registered slot the sum is accumulated straight into
+    the slot (None goes back to autograd: no AccumulateGrad add launch); an analytically-zero gradient (conv in front of a train-mode
+    BatchNorm) costs nothing at all."""
+    if is_zero:
+        if not torch.is_grad_enabled():
+            note_contribution(bias)
+            return None
+        return torch.zeros(Co, dtype=torch.float32, device=gy.device)
+    slot = _small_grad_slot(bias)
+    if slot is None:
+        return channel_sum(gy)  # autograd accumulates it (and its post-accumulate hook reports the arrival)
+    if gy.shape[-1] % 4 == 0:
+        channel_sum_into(gy, slot)
+    else:  # narrow heads (6 / 1 channels): a few hundred KB
+        slot.add_(gy.sum(dim=(0, 1, 2)))
+    note_contribution(bias)
+    return None
 
 
 class Conv2dWeightGradFn(Function):
@@ -554,28 +617,7 @@ class Conv2dWeightGradFn(Function):
     def forward(ctx, x, gy, wshape, stride):
         ctx.save_for_backward(x, gy)
         ctx.stride, ctx.wshape = stride, tuple(wshape)
-        Co, Ci, KH, KW = wshape
-        if KH == KW and gy.shape[-1] >= Co and x.shape[-1] >= Ci and thin_mode(Ci, Co, KH, stride):
-            px, N, H, W, _, ldx = nhwc(x)
-            gyv = _as_nhwc_view(gy)
-            pg, _, _, _, _, ldg = nhwc(gyv)
-            nbytes = int(native.load().lhg_conv2d_thin_wgrad_workspace(N, H, W, Ci, Co, KH))
-            ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=x.device)
-            gw = torch.empty(ctx.wshape, dtype=torch.float32, device=x.device)
-            call("lhg_conv2d_thin_backward_weight", px, N, H, W, Ci, ldx, pg, Co, ldg, KH, ptr(gw), ptr(ws), nbytes, stream_ptr())
-            return gw
-        gyp = _padded_gy(gy, 4)
-        px, N, H, W, Cx, ldx = nhwc(x)
-        pg, _, _, _, Cg, ldg = nhwc(gyp)
-        lib = native.load()
-        S = lib.lhg_conv2d_wgrad_splits(N, H, W, Cx, Cg, KH, KW, stride)
-        ci_pad, co_pad = pad_to(Cx, 64), pad_to(Cg, 64)
-        slabs = torch.empty((S, KH * KW, ci_pad, co_pad), dtype=torch.float32, device=x.device)
-        native.count_flops(1, 2.0 * N * gy.shape[1] * gy.shape[2] * Co * Ci * KH * KW)
-        call("lhg_conv2d_backward_weight", px, N, H, W, Cx, ldx, pg, Cg, ldg, KH, KW, stride, ptr(slabs), S, ci_pad, co_pad, stream_ptr())
-        gw = torch.empty(ctx.wshape, dtype=torch.float32, device=x.device)
-        call("lhg_wgrad_reduce", ptr(slabs), S, KH * KW, ci_pad, co_pad, ptr(gw), Co, Ci, 1, stream_ptr())
-        return gw
+        return conv2d_weight_grad_raw(x, gy, ctx.wshape, stride)
 
     @staticmethod
     def backward(ctx, ggw):
@@ -596,6 +638,8 @@ class ConvTranspose2x2Fn(TrackedFunction):
         ctx.save_for_backward(x, w)
         ctx.has_bias = bias is not None
         note_use(w, ctx.needs_input_grad[1])
+        ctx.bias = bias if (bias is not None and ctx.needs_input_grad[2]) else None
+        note_use(ctx.bias)
         px, N, H, W, Ci, ldx = nhwc(x)
         Ciw, Co, KH, KW = w.shape
         assert (KH, KW) == (2, 2) and Ciw == Ci, "conv_transpose2x2: weight/input mismatch"
@@ -622,7 +666,7 @@ class ConvTranspose2x2Fn(TrackedFunction):
         if not param_grads_wanted():
             return gx, None, None, None
         if ctx.needs_input_grad[1]:
-            def wgrad():
+            def wgrad(slot):
                 px, N, H, W, Cx, ldx = nhwc(x)
                 pg, _, _, _, Cg, ldg = nhwc(gy)
                 S = native.load().lhg_conv_transpose2x2_wgrad_splits(N, H, W, Cx, Cg)
@@ -630,13 +674,13 @@ class ConvTranspose2x2Fn(TrackedFunction):
                 slabs = torch.empty((S, 4, ci_pad, co_pad), dtype=torch.float32, device=x.device)
                 native.count_flops(1, 2.0 * N * H * W * 4 * Ci * Co)
                 call("lhg_conv_transpose2x2_backward_weight", px, N, H, W, Cx, ldx, pg, Cg, ldg, ptr(slabs), S, ci_pad, co_pad, stream_ptr())
-                out = torch.empty(w.shape, dtype=torch.float32, device=x.device)
-                call("lhg_wgrad_reduce", ptr(slabs), S, 4, ci_pad, co_pad, ptr(out), Ci, Co, 0, stream_ptr())
-                return out
+                out = slot if slot is not None else torch.empty(w.shape, dtype=torch.float32, device=x.device)
+                call("lhg_wgrad_reduce", ptr(slabs), S, 4, ci_pad, co_pad, ptr(out), Ci, Co, 0, int(slot is not None), stream_ptr())
+                return None if slot is not None else out
 
             gw = _weight_grad(w, (x, gy), wgrad)
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = channel_sum(gy)
+            gb = _bias_grad(ctx.bias, gy, False, Co)
         return gx, gw, gb, None
 
 
@@ -647,6 +691,13 @@ def channel_sum(t):
     return ChannelSumFn.apply(t)
 
 
+def channel_sum_into(t, slot):
+    """slot += sum over (N,H,W) of t (C % 4 == 0): the bias gradient accumulated by the reduction kernel itself."""
+    p, N, H, W, Cc, ld = nhwc(t)
+    ws = torch.empty((2048 * Cc,), dtype=torch.float32, device=t.device)
+    call("lhg_channel_sum", p, N * H * W, Cc, ld, ptr(slot), 1, ptr(ws), stream_ptr())
+
+
 class ChannelSumFn(Function):
     @staticmethod
     def forward(ctx, t):
@@ -654,7 +705,7 @@ class ChannelSumFn(Function):
         ctx.shape = t.shape
         out = torch.empty((Cc,), dtype=torch.float32, device=t.device)
         ws = torch.empty((2048 * Cc,), dtype=torch.float32, device=t.device)
-        call("lhg_channel_sum", p, N * H * W, Cc, ld, ptr(out), ptr(ws), stream_ptr())
+        call("lhg_channel_sum", p, N * H * W, Cc, ld, ptr(out), 0, ptr(ws), stream_ptr())
         return out
 
     @staticmethod
@@ -692,6 +743,8 @@ class ConvBiasActFn(TrackedFunction):
         ctx.save_for_backward(x, w, y)
         ctx.stride, ctx.act, ctx.slope, ctx.has_bias = stride, act, slope, bias is not None
         note_use(w, ctx.needs_input_grad[1])
+        ctx.bias = bias if (bias is not None and ctx.needs_input_grad[2]) else None
+        note_use(ctx.bias)
         return y
 
     @staticmethod
@@ -704,9 +757,9 @@ class ConvBiasActFn(TrackedFunction):
         if not param_grads_wanted():
             return gx, None, None, None, None, None
         if ctx.needs_input_grad[1]:
-            gw = _weight_grad(w, (x, g), lambda: Conv2dWeightGradFn.apply(x, g, w.shape, ctx.stride))
+            gw = _weight_grad(w, (x, g), lambda slot: conv2d_weight_grad(x, g, w.shape, ctx.stride, slot))
         if ctx.has_bias and ctx.needs_input_grad[2]:
-            gb = channel_sum(g)
+            gb = _bias_grad(ctx.bias, g, False, w.shape[0])
         return gx, gw, gb, None, None, None
 
 
@@ -715,7 +768,7 @@ def _bn_ws(Cc, device, mult=8192):
     return torch.empty((mult * Cc,), dtype=torch.float32, device=device)
 
 
-class BatchNormTrainFn(Function):
+class BatchNormTrainFn(TrackedFunction):
     """y = act(BN_batchstats(x) * gamma + beta [+ res]); updates running stats in place.
     ref: F.batch_norm(training=True) via nn.LazyBatchNorm2d, neural_network_components.py:27-31;
     nn.BatchNorm2d discriminator.py:39."""
@@ -735,13 +788,37 @@ class BatchNormTrainFn(Function):
         call("lhg_bn_apply", px, ldx, pixels, Cc, ptr(stats), ptr(gamma), ptr(beta), pres, ldres, act, float(slope), py, ldy, stream_ptr())
         ctx.save_for_backward(x, y, gamma, stats)
         ctx.act, ctx.slope, ctx.has_res = act, slope, res is not None
+        ctx.beta = beta if ctx.needs_input_grad[2] else None
+        note_use(gamma, ctx.needs_input_grad[1])
+        note_use(ctx.beta)
         return y
 
     @staticmethod
     def backward(ctx, gy):
         x, y, gamma, stats = ctx.saved_tensors
-        gx, gres, ggamma, gbeta = BatchNormGradFn.apply(_as_nhwc_view(gy), x, y, gamma, stats, ctx.act, ctx.slope, ctx.has_res)
+        gy = _as_nhwc_view(gy)
+        s_gamma = _small_grad_slot(gamma) if ctx.needs_input_grad[1] else None
+        s_beta = _small_grad_slot(ctx.beta)
+        if s_gamma is not None and s_beta is not None and param_grads_wanted():
+            # plain backward into the flat gradient buffer: the kernel adds d gamma / d beta to their slots itself
+            gx, gres = bn_backward_raw(gy, x, y, gamma, stats, ctx.act, ctx.slope, ctx.has_res, s_gamma, s_beta, True)
+            note_contribution(gamma)
+            note_contribution(ctx.beta)
+            return gx, None, None, None, None, (gres if ctx.has_res else None), None, None, None
+        gx, gres, ggamma, gbeta = BatchNormGradFn.apply(gy, x, y, gamma, stats, ctx.act, ctx.slope, ctx.has_res)
         return gx, ggamma, gbeta, None, None, (gres if ctx.has_res else None), None, None, None
+
+
+def bn_backward_raw(gy, x, y, gamma, stats, act, slope, want_res, ggamma, gbeta, accumulate):
+    """lhg_bn_backward; ggamma / gbeta are written (or, with ``accumulate``, added to).  Returns (gx, gres)."""
+    pg, N, H, W, Cc, ldg = nhwc(gy)
+    px, _, _, _, _, ldx = nhwc(x)
+    py, _, _, _, _, ldy = nhwc(y)
+    gx = new_nhwc(N, H, W, Cc, gy.device)
+    gres = new_nhwc(N, H, W, Cc, gy.device) if want_res else None
+    call("lhg_bn_backward", pg, ldg, px, ldx, py, ldy, N * H * W, Cc, ptr(stats), ptr(gamma), act, float(slope),
+         ptr(gx), Cc, ptr(gres), Cc, ptr(ggamma), ptr(gbeta), int(accumulate), ptr(_bn_ws(Cc, gy.device)), stream_ptr())
+    return gx, gres
 
 
 class BatchNormGradFn(Function):
@@ -749,16 +826,10 @@ class BatchNormGradFn(Function):
 
     @staticmethod
     def forward(ctx, gy, x, y, gamma, stats, act, slope, want_res):
-        pg, N, H, W, Cc, ldg = nhwc(gy)
-        px, _, _, _, _, ldx = nhwc(x)
-        py, _, _, _, _, ldy = nhwc(y)
-        pixels = N * H * W
-        gx = new_nhwc(N, H, W, Cc, gy.device)
-        gres = new_nhwc(N, H, W, Cc, gy.device) if want_res else None
+        Cc = gy.shape[-1]
         ggamma = torch.empty((Cc,), dtype=torch.float32, device=gy.device)
         gbeta = torch.empty((Cc,), dtype=torch.float32, device=gy.device)
-        call("lhg_bn_backward", pg, ldg, px, ldx, py, ldy, pixels, Cc, ptr(stats), ptr(gamma), act, float(slope),
-             ptr(gx), Cc, ptr(gres), Cc, ptr(ggamma), ptr(gbeta), ptr(_bn_ws(Cc, gy.device)), stream_ptr())
+        gx, gres = bn_backward_raw(gy, x, y, gamma, stats, act, slope, want_res, ggamma, gbeta, False)
         ctx.save_for_backward(gy, x, y, gamma, stats)
         ctx.act, ctx.slope, ctx.want_res = act, slope, want_res
         ctx.set_materialize_grads(False)
@@ -833,7 +904,7 @@ class SigmoidHeadFn(TrackedFunction):
         if ctx.needs_input_grad[0]:
             gx = Conv2dInputGradFn.apply(g_nhwc, w, 1, x.shape[1], x.shape[2], x.shape[3])
         if ctx.needs_input_grad[1]:
-            gw = _weight_grad(w, (x, g_nhwc), lambda: Conv2dWeightGradFn.apply(x, g_nhwc, w.shape, 1))
+            gw = _weight_grad(w, (x, g_nhwc), lambda slot: conv2d_weight_grad(x, g_nhwc, w.shape, 1, slot))
         if ctx.needs_input_grad[2]:
             gb = g_pre.sum(dim=(0, 2, 3))
         return gx, gw, gb

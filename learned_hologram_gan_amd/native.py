@@ -56,11 +56,11 @@ _SIGNATURES = {
     "lhg_conv_transpose2x2_backward_input": [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _i, _p],
     "lhg_conv_transpose2x2_wgrad_splits": [_i, _i, _i, _i, _i],
     "lhg_conv_transpose2x2_backward_weight": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _i, _i, _i, _p],
-    "lhg_wgrad_reduce": [_p, _i, _i, _i, _i, _p, _i, _i, _i, _p],
-    "lhg_channel_sum": [_p, _ll, _i, _i, _p, _p, _p],
+    "lhg_wgrad_reduce": [_p, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p],
+    "lhg_channel_sum": [_p, _ll, _i, _i, _p, _i, _p, _p],
     "lhg_bn_stats": [_p, _ll, _i, _i, _p, _p, _p, _f, _f, _p, _p],
     "lhg_bn_apply": [_p, _i, _ll, _i, _p, _p, _p, _p, _i, _i, _f, _p, _i, _p],
-    "lhg_bn_backward": [_p, _i, _p, _i, _p, _i, _ll, _i, _p, _p, _i, _f, _p, _i, _p, _i, _p, _p, _p, _p],
+    "lhg_bn_backward": [_p, _i, _p, _i, _p, _i, _ll, _i, _p, _p, _i, _f, _p, _i, _p, _i, _p, _p, _i, _p, _p],
     "lhg_bn_backward_backward": [_p, _p, _p, _p, _ll, _i, _p, _p, _i, _f, _p, _p, _p, _p, _p],
     "lhg_maxpool2x2_forward": [_p, _i, _i, _i, _i, _i, _p, _i, _p],
     "lhg_maxpool2x2_backward": [_p, _i, _p, _i, _i, _i, _i, _i, _p, _i, _p],
@@ -120,8 +120,8 @@ def load():
         fn.argtypes = argtypes
         fn.restype = _RESTYPE.get(name, C.c_int)
     got = lib.lhg_abi_version()
-    if got != 1:
-        raise NativeLibraryError(f"ABI version mismatch: library {got}, binding 1")
+    if got != 2:
+        raise NativeLibraryError(f"ABI version mismatch: library {got}, binding 2")
     _lib = lib
     return lib
 

@@ -34,8 +34,9 @@ class FlatParams:
                 self.data[o:o + p.numel()].copy_(p.detach().reshape(-1))
                 p.data = self.data[o:o + p.numel()].view_as(p)
                 p.grad = self.grad[o:o + p.numel()].view_as(p)
-                if p.dim() == 4:  # conv / conv-transpose weights: gradient GEMMs accumulate here (from a side stream on the GPU)
-                    hip_ops.register_grad_slot(p, p.grad)
+                # the ops' backward kernels accumulate straight into these slots (conv / conv-transpose weights from the weight-gradient
+                # stream; BatchNorm affine parameters and biases from the main stream) and hand autograd None
+                hip_ops.register_grad_slot(p, p.grad)
 
     def zero_grad(self):
         """Keep .grad bound to the flat buffer (set_to_none would drop the views)."""

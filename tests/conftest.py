@@ -56,6 +56,24 @@ def oracle_full_step():
     return cfg, ref
 
 
+@pytest.fixture(scope="session")
+def oracle_full_step_fp64(oracle_full_step):
+    """The same full-size step evaluated in FLOAT64 (the fp32-defined constants w / H / mask are cast, not rebuilt): the truth against
+    which both fp32 evaluations — the CPU oracle's (= the reference's arithmetic) and the GPU's — are measured."""
+    from oracle import optics, seeded, step
+
+    cfg, _ = oracle_full_step
+    torch.set_num_threads(min(16, os.cpu_count() or 1))
+    st32 = step.make_state(cfg["rows"], cfg["cols"], cfg["pad"], cfg["coef"], cfg["stack"], seeded.generator_state_dict(), seeded.critic_state_dict())
+    dbl = lambda sd: {k: (v.double() if v.is_floating_point() else v) for k, v in sd.items()}  # noqa: E731
+    o = st32.o
+    o64 = optics.Optics(o.rows0, o.cols0, o.pad_r, o.pad_c, o.rows, o.cols, o.w.double(), o.mask.double())
+    st = step.TrainState(o64, st32.H_fixed.to(torch.complex128), st32.H_stack.to(torch.complex128),
+                         step.nets.as_parameters(dbl(seeded.generator_state_dict())), step.nets.as_parameters(dbl(seeded.critic_state_dict())))
+    return step.train_step(st, cfg["rgbd"].double(), cfg["tamp"].double(), cfg["tphs"].double(), step.LossWeights(d_ratio=1), cfg["idx"],
+                           [a.double() for a in cfg["alphas"]])
+
+
 def rel_err(a, b):
     """max|a-b| / max|b| — the fp32 parity measure used throughout (north_star: 1e-4)."""
     a, b = torch.as_tensor(a), torch.as_tensor(b)

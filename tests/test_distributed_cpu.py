@@ -102,7 +102,14 @@ class _SlotScaleFn(_tracked_base()):
         from learned_hologram_gan_amd import hip_ops
 
         x, w = ctx.saved_tensors
-        gw = hip_ops._weight_grad(w, (x, g), lambda: (g * x).sum() * torch.ones_like(w))
+        def wgrad(slot):  # the ops' contract: a new tensor without a slot, accumulation into it with one
+            val = (g * x).sum() * torch.ones_like(w)
+            if slot is None:
+                return val
+            slot.add_(val)
+            return None
+
+        gw = hip_ops._weight_grad(w, (x, g), wgrad)
         hip_ops.note_contribution(ctx.bias)
         return g * w.sum(), gw, None
 
