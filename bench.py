@@ -206,7 +206,7 @@ def main():
         hip_ops.set_conv_precision(args.precision)
         args.dtype = "bf16" if args.precision == "bf16" else "f32"
     elif args.dtype == "bf16":
-        hip_ops.set_conv_precision("bf16")
+        hip_ops.set_activation_storage("bf16")  # bf16 NHWC activations + bf16 conv-GEMM operands; fp32 accumulation / BN / FFT / Adam
     bf16 = args.dtype == "bf16"
     mfma_peak = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
     stack = torch.linspace(-4e-4, 0.0, 21)[:-1]  # trainingModel.py:62
@@ -336,7 +336,8 @@ def main():
             "config": {"workload": f"{args.rows}x{args.cols}x3 bs={B}/GPU generator+critic train step (d_ratio={args.d_ratio}, "
                                    f"lambda_gp=10, pad {args.pad} -> {args.rows + 2 * args.pad}^2 FFTs, 20-plane stack, "
                                    + (f"VGG19 perceptual term x{args.perceptual} with random weights" if args.perceptual > 0 else "no VGG term") + "), "
-                                   + ("bf16 conv-GEMM operands, fp32 accumulation / BatchNorm / FFT / Adam (informational)" if bf16 else "fp32"),
+                                   + ((f"bf16 conv-GEMM operands, {hip_ops.activation_storage()} activation storage, fp32 accumulation / BatchNorm / FFT / Adam "
+                                      "(informational)") if bf16 else f"fp32 tensors, conv GEMMs in the '{hip_ops.conv_precision()}' mode"),
                        "global_batch": B * world, "parallelism": f"dp{world}"},
             "roofline": r,
         }

@@ -41,6 +41,8 @@ enum {
 enum { LHG_ACT_NONE = 0, LHG_ACT_RELU = 1, LHG_ACT_LEAKY = 2, LHG_ACT_SIGMOID = 3 };
 enum { LHG_PRECISION_F32 = 0, LHG_PRECISION_BF16 = 1, LHG_PRECISION_F32_SPLIT = 2, LHG_PRECISION_F32_SPLIT2 = 3 };
 
+enum { LHG_DTYPE_F32 = 0, LHG_DTYPE_BF16 = 1 };
+
 typedef void* lhg_stream_t; /* hipStream_t */
 
 int lhg_abi_version(void);
@@ -56,6 +58,14 @@ const char* lhg_last_error(void);
 int lhg_autotune(int on);
 int lhg_profile_enable(int kernel, int on);
 int lhg_profile_read(int kernel, double* total_ms, long long* launches, double* executed_flops);
+
+/* Element type of the NHWC ACTIVATION tensors (process-wide, default LHG_DTYPE_F32).  With LHG_DTYPE_BF16 (BASELINE configs[2], [4]:
+ * "bf16", "bf16 + fp32 FFT") every `float*` argument that names an NHWC activation or activation-gradient tensor addresses bf16
+ * elements instead (`ld` / `C` stay element counts); parameters, statistics, workspaces, weight gradients, NCHW tensors, planar
+ * outputs and everything of the angular-spectrum / loss / optimiser kernels stay fp32, and all arithmetic is fp32.  Requires
+ * LHG_PRECISION_BF16 for the conv GEMMs (their operands are read from HBM as bf16 without conversion). */
+int lhg_set_activation_dtype(int dtype);
+int lhg_get_activation_dtype(void);
 
 /* ------------------------------------------------------------------ layout */
 /* NCHW (planar) -> NHWC with `ld` floats per pixel; channels C..ld-1 are zero-filled.

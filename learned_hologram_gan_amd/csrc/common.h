@@ -29,6 +29,13 @@ inline int check_launch(const char* what) {
 
 inline hipStream_t as_stream(lhg_stream_t s) { return reinterpret_cast<hipStream_t>(s); }
 
+// element type of every NHWC activation tensor the kernels see (lhg_set_activation_dtype): one instance per shared object
+inline int& act_dtype() {
+  static int d = LHG_DTYPE_F32;
+  return d;
+}
+inline bool act_is_bf16() { return act_dtype() == LHG_DTYPE_BF16; }
+
 constexpr int kWave = 64;  // CDNA wavefront
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));

@@ -530,6 +530,7 @@ static int launch_gg(GGParams& p, hipStream_t st) {
   if (g.M <= 0) return LHG_OK;
   p.xcd = xcd_order();
   if (g_precision == LHG_PRECISION_BF16) return launch_gg_bf16(p, st);
+  LHG_REQUIRE(!act_is_bf16(), "bf16 activation storage needs the bf16 conv precision (lhg_set_conv_precision(LHG_PRECISION_BF16))");
   if (split_mode()) return launch_gg_split(p, st);
   LHG_REQUIRE(g.Ci % BK == 0 && g.Ci > 0, "gather-GEMM: K channels (%d) must be a positive multiple of 32", g.Ci);
   LHG_REQUIRE(g.ldi % 4 == 0 && (reinterpret_cast<uintptr_t>(p.in) & 15) == 0, "gather-GEMM: input must be 16-byte aligned (ld %d)", g.ldi);
@@ -580,15 +581,18 @@ static int launch_gg(GGParams& p, hipStream_t st) {
 }
 
 // bf16 operands: `p.wp` holds bf16 panels (lhg_pack_weight in the same mode).  Tilings 128x128 / 128x64 / 64x64, autotuned.
-static int launch_gg_bf16(GGParams& p, hipStream_t st) {
+// In the bf16 storage mode (lhg_set_activation_dtype) the gathered tensor, the residual and the NHWC output are bf16 in HBM.
+template <class TA>
+static int launch_gg_bf16_t(GGParams& p, hipStream_t st) {
   const Geom& g = p.g;
+  constexpr int ES = (int)sizeof(TA);
   LHG_REQUIRE(g.Ci % BK == 0 && g.Ci > 0, "gather-GEMM: K channels (%d) must be a positive multiple of 32", g.Ci);
-  LHG_REQUIRE(g.ldi % 4 == 0 && (reinterpret_cast<uintptr_t>(p.in) & 15) == 0, "gather-GEMM: input must be 16-byte aligned (ld %d)", g.ldi);
+  LHG_REQUIRE((g.ldi * ES) % 16 == 0 && (reinterpret_cast<uintptr_t>(p.in) & 15) == 0, "gather-GEMM: input must be 16-byte aligned (ld %d)", g.ldi);
   LHG_REQUIRE((reinterpret_cast<uintptr_t>(p.wp) & 15) == 0, "gather-GEMM: packed weights must be 16-byte aligned");
   LHG_REQUIRE(p.rows_pad % 64 == 0 && p.rows_pad >= g.Co, "gather-GEMM: rows_pad %d must be a multiple of 64 covering Co=%d", p.rows_pad, g.Co);
   int max_ws = 0;
   for (int t = 0; t < g.T; ++t) max_ws = std::max(max_ws, g.ws[t]);
-  const unsigned long long in_bytes = (((unsigned long long)g.N * g.Hi * g.Wi - 1) * g.ldi + g.Ci) * 4ull;
+  const unsigned long long in_bytes = (((unsigned long long)g.N * g.Hi * g.Wi - 1) * g.ldi + g.Ci) * (unsigned long long)ES;
   const unsigned long long wp_bytes = (unsigned long long)(max_ws + 1) * p.rows_pad * g.Ci * 2ull;
   LHG_REQUIRE(wp_bytes < (1ull << 32) - 64, "gather-GEMM (bf16 mode): weight panels of 4 GiB and more are not supported");
   const unsigned long long ib = in_bytes;
@@ -600,24 +604,28 @@ static int launch_gg_bf16(GGParams& p, hipStream_t st) {
   auto valid = [&](int v) { return (v % 3 == 0 ? n128 : true) && (v < 3 || k64); };
   auto run = [&](int v) {
     switch (v) {
-      case 0: hipLaunchKernelGGL((gg2b_kernel<128, 128, 2, 2>), dim3(blocks(128, 128)), dim3(256), 0, st, p, ib, wb); break;
-      case 1: hipLaunchKernelGGL((gg2b_kernel<128, 64, 2, 2>), dim3(blocks(128, 64)), dim3(256), 0, st, p, ib, wb); break;
-      case 2: hipLaunchKernelGGL((gg2b_kernel<64, 64, 2, 2>), dim3(blocks(64, 64)), dim3(256), 0, st, p, ib, wb); break;
-      case 3: hipLaunchKernelGGL((gg2b_kernel<128, 128, 2, 2, 64>), dim3(blocks(128, 128)), dim3(256), 0, st, p, ib, wb); break;
-      case 4: hipLaunchKernelGGL((gg2b_kernel<128, 64, 2, 2, 64>), dim3(blocks(128, 64)), dim3(256), 0, st, p, ib, wb); break;
-      default: hipLaunchKernelGGL((gg2b_kernel<64, 64, 2, 2, 64>), dim3(blocks(64, 64)), dim3(256), 0, st, p, ib, wb); break;
+      case 0: hipLaunchKernelGGL((gg2b_kernel<128, 128, 2, 2, 32, TA>), dim3(blocks(128, 128)), dim3(256), 0, st, p, ib, wb); break;
+      case 1: hipLaunchKernelGGL((gg2b_kernel<128, 64, 2, 2, 32, TA>), dim3(blocks(128, 64)), dim3(256), 0, st, p, ib, wb); break;
+      case 2: hipLaunchKernelGGL((gg2b_kernel<64, 64, 2, 2, 32, TA>), dim3(blocks(64, 64)), dim3(256), 0, st, p, ib, wb); break;
+      case 3: hipLaunchKernelGGL((gg2b_kernel<128, 128, 2, 2, 64, TA>), dim3(blocks(128, 128)), dim3(256), 0, st, p, ib, wb); break;
+      case 4: hipLaunchKernelGGL((gg2b_kernel<128, 64, 2, 2, 64, TA>), dim3(blocks(128, 64)), dim3(256), 0, st, p, ib, wb); break;
+      default: hipLaunchKernelGGL((gg2b_kernel<64, 64, 2, 2, 64, TA>), dim3(blocks(64, 64)), dim3(256), 0, st, p, ib, wb); break;
     }
   };
   static const int forced = [] { const char* e = getenv("LHG_GGB_VARIANT"); return e ? atoi(e) : -1; }();
   int choice = (forced >= 0 && forced < NV && valid(forced)) ? forced : -1;
   if (choice < 0 && g_autotune_enabled) {
-    const std::array<int, 12> key = {g.M, p.rows_pad, g.Ci, g.Co, g.T, g.istep, g.ostep, g.Hi, g.Wi, g.ldi, g.ldo, p.planar_out + 2};
+    const std::array<int, 12> key = {g.M, p.rows_pad, g.Ci, g.Co, g.T, g.istep, g.ostep, g.Hi, g.Wi, g.ldi, g.ldo, p.planar_out + 2 + 16 * ES};
     choice = autotuned_variant(g_gg_choice, key, NV, valid, run, st);
   }
   if (choice < 0) choice = n128 && blocks(128, 128) >= 256 ? 0 : (blocks(128, 64) >= 256 ? 1 : 2);
   ScopedKernelTime timed(0, st, 2.0 * g.M * (double)p.rows_pad * g.Ci * g.T);
   run(choice);
   return check_launch("gg2b_kernel");
+}
+
+static int launch_gg_bf16(GGParams& p, hipStream_t st) {
+  return act_is_bf16() ? launch_gg_bf16_t<__bf16>(p, st) : launch_gg_bf16_t<float>(p, st);
 }
 
 // fp32 operands as exact sums of bf16 terms (gg3s_kernel): `p.wp` holds split panels (lhg_pack_weight in the same mode).
@@ -675,8 +683,11 @@ static int launch_wg(WGParams& p, int S, hipStream_t st, const WG3Params* p3 = n
   LHG_REQUIRE(S >= 1 && S <= 65535, "wgrad: bad split count %d", S);
   const int steps = (g.M + BK - 1) / BK;
   p.kchunk = ((steps + S - 1) / S) * BK;
-  const unsigned long long in_bytes = (((unsigned long long)g.N * g.Hi * g.Wi - 1) * g.ldi + g.Ci) * 4ull;
-  const unsigned long long go_bytes = (((unsigned long long)g.N * g.Ho * g.Wo - 1) * g.ldo + g.Co) * 4ull;
+  const bool act16 = act_is_bf16();
+  LHG_REQUIRE(!act16 || g_precision == LHG_PRECISION_BF16, "bf16 activation storage needs the bf16 conv precision");
+  const unsigned long long es = act16 ? 2ull : 4ull;
+  const unsigned long long in_bytes = (((unsigned long long)g.N * g.Hi * g.Wi - 1) * g.ldi + g.Ci) * es;
+  const unsigned long long go_bytes = (((unsigned long long)g.N * g.Ho * g.Wo - 1) * g.ldo + g.Co) * es;
   const bool small = in_bytes < (1ull << 32) - 64 && go_bytes < (1ull << 32) - 64;
   const unsigned ib = (unsigned)in_bytes, gb = (unsigned)go_bytes;
   const bool m128 = p.m_pad % 128 == 0, n128 = p.n_pad % 128 == 0;
@@ -706,10 +717,22 @@ static int launch_wg(WGParams& p, int S, hipStream_t st, const WG3Params* p3 = n
         hipLaunchKernelGGL(wg3_kernel, dim3((p.m_pad / 64) * (p.n_pad / 64), 1, S), dim3(256), 0, st, q3, ib, gb);
         break;
       }
-      case 6: hipLaunchKernelGGL((wg2b_kernel<128, 128>), grid(128, 128), dim3(256), 0, st, p, ib, gb); break;
-      case 7: hipLaunchKernelGGL((wg2b_kernel<128, 64>), grid(128, 64), dim3(256), 0, st, p, ib, gb); break;
-      case 8: hipLaunchKernelGGL((wg2b_kernel<64, 128>), grid(64, 128), dim3(256), 0, st, p, ib, gb); break;
-      case 9: hipLaunchKernelGGL((wg2b_kernel<64, 64>), grid(64, 64), dim3(256), 0, st, p, ib, gb); break;
+      case 6:
+        if (act16) hipLaunchKernelGGL((wg2b_kernel<128, 128, __bf16>), grid(128, 128), dim3(256), 0, st, p, ib, gb);
+        else hipLaunchKernelGGL((wg2b_kernel<128, 128, float>), grid(128, 128), dim3(256), 0, st, p, ib, gb);
+        break;
+      case 7:
+        if (act16) hipLaunchKernelGGL((wg2b_kernel<128, 64, __bf16>), grid(128, 64), dim3(256), 0, st, p, ib, gb);
+        else hipLaunchKernelGGL((wg2b_kernel<128, 64, float>), grid(128, 64), dim3(256), 0, st, p, ib, gb);
+        break;
+      case 8:
+        if (act16) hipLaunchKernelGGL((wg2b_kernel<64, 128, __bf16>), grid(64, 128), dim3(256), 0, st, p, ib, gb);
+        else hipLaunchKernelGGL((wg2b_kernel<64, 128, float>), grid(64, 128), dim3(256), 0, st, p, ib, gb);
+        break;
+      case 9:
+        if (act16) hipLaunchKernelGGL((wg2b_kernel<64, 64, __bf16>), grid(64, 64), dim3(256), 0, st, p, ib, gb);
+        else hipLaunchKernelGGL((wg2b_kernel<64, 64, float>), grid(64, 64), dim3(256), 0, st, p, ib, gb);
+        break;
       case 10:
         if (NP == 3) hipLaunchKernelGGL((wg2s_kernel<128, 128, 3, 1>), grid(128, 128), dim3(256), 0, st, p, ib, gb);
         else hipLaunchKernelGGL((wg2s_kernel<128, 128, 2, 2>), grid(128, 128), dim3(256), 0, st, p, ib, gb);
@@ -734,7 +757,7 @@ static int launch_wg(WGParams& p, int S, hipStream_t st, const WG3Params* p3 = n
   int choice = -1;
   if (forced >= 0 && forced < NV && valid(forced)) choice = forced;
   if (choice < 0 && tune && g_autotune_enabled) {
-    const std::array<int, 12> key = {g.M, p.m_pad, p.n_pad, g.T, S, g.istep, g.ostep, g.Hi, g.Wi, g.ldi, g.ldo, g.ws[0] + 100 * g_precision};
+    const std::array<int, 12> key = {g.M, p.m_pad, p.n_pad, g.T, S, g.istep, g.ostep, g.Hi, g.Wi, g.ldi, g.ldo, g.ws[0] + 100 * g_precision + (act16 ? 1000 : 0)};
     choice = autotuned_variant(g_wg_choice, key, NV, valid, run, st);
   }
   if (choice < 0 && split) choice = m128 && n128 && (p.m_pad / 128) * (p.n_pad / 128) * g.T * S >= 200 ? 10 : 13;

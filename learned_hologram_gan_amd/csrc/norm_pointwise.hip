@@ -53,11 +53,21 @@ __device__ __forceinline__ void column_reduce(long long pixels, int C, int lanes
   }
 }
 
+// Activation tensors are fp32 or — in the bf16 storage mode (lhg_set_activation_dtype) — bf16; every kernel computes in fp32.
+// Four channels per lane either way: 16-byte or 8-byte accesses.
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ f32x4 ld4(const __bf16* p) { return __builtin_convertvector(*reinterpret_cast<const bf16x4_t*>(p), f32x4); }
+__device__ __forceinline__ void st4(__bf16* p, f32x4 v) { *reinterpret_cast<bf16x4_t*>(p) = __builtin_convertvector(v, bf16x4_t); }
+__device__ __forceinline__ float ld1(const float* p) { return *p; }
+__device__ __forceinline__ float ld1(const __bf16* p) { return (float)*p; }
+__device__ __forceinline__ void st1(float* p, float v) { *p = v; }
+__device__ __forceinline__ void st1(__bf16* p, float v) { *p = (__bf16)v; }
 
 // ------------------------------------------------------------------ BN statistics
-__global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict__ x, long long pixels, int C, int ld,
+template <class T>
+__global__ __launch_bounds__(256) void bn_stats_partial(const T* __restrict__ x, long long pixels, int C, int ld,
                                                         int lanes_c, int rows, float* __restrict__ partial) {
   // shifted sums around the first pixel of each channel (stable one-pass variance)
   column_reduce<2>(pixels, C, lanes_c, rows, partial, [&](long long q, int cb, f32x4* acc) {
@@ -68,13 +78,14 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const float* __restrict_
   });
 }
 
-__global__ void bn_stats_final(const float* __restrict__ sums /* [2][C] shifted sums */, const float* __restrict__ x, long long pixels, int C,
+template <class T>
+__global__ void bn_stats_final(const float* __restrict__ sums /* [2][C] shifted sums */, const T* __restrict__ x, long long pixels, int C,
                                float* __restrict__ stats, float* running_mean, float* running_var, float momentum, float eps) {
   const int c = blockIdx.x * blockDim.x + threadIdx.x;
   if (c >= C) return;
   const double n = (double)pixels;
   const double dm = (double)sums[c] / n;
-  const double mean = (double)x[c] + dm;
+  const double mean = (double)ld1(x + c) + dm;
   double var = (double)sums[C + c] / n - dm * dm;
   if (var < 0) var = 0;
   stats[c] = (float)mean;
@@ -87,10 +98,11 @@ __global__ void bn_stats_final(const float* __restrict__ sums /* [2][C] shifted 
 }
 
 // ------------------------------------------------------------------ BN apply (+residual, +activation)
-__global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__ x, int ldx, long long pixels, int C,
+template <class T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, int ldx, long long pixels, int C,
                                                        const float* __restrict__ stats, const float* __restrict__ gamma,
-                                                       const float* __restrict__ beta, const float* __restrict__ res, int ldres,
-                                                       int act, float slope, float* __restrict__ y, int ldy, int lanes_c, int rows) {
+                                                       const float* __restrict__ beta, const T* __restrict__ res, int ldres,
+                                                       int act, float slope, T* __restrict__ y, int ldy, int lanes_c, int rows) {
   const int tx = threadIdx.x % lanes_c, ty = threadIdx.x / lanes_c;
   for (int cb = tx * 4; cb < C; cb += lanes_c * 4) {
     const f32x4 mean = ld4(stats + cb), inv = ld4(stats + C + cb);
@@ -107,8 +119,9 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const float* __restrict__
 }
 
 // ------------------------------------------------------------------ BN backward
-__global__ __launch_bounds__(256) void bn_bwd_partial(const float* __restrict__ gy, int ldgy, const float* __restrict__ x, int ldx,
-                                                      const float* __restrict__ y, int ldy, long long pixels, int C,
+template <class T>
+__global__ __launch_bounds__(256) void bn_bwd_partial(const T* __restrict__ gy, int ldgy, const T* __restrict__ x, int ldx,
+                                                      const T* __restrict__ y, int ldy, long long pixels, int C,
                                                       const float* __restrict__ stats, int act, float slope, int lanes_c, int rows,
                                                       float* __restrict__ partial) {
   column_reduce<2>(pixels, C, lanes_c, rows, partial, [&](long long q, int cb, f32x4* acc) {
@@ -157,11 +170,12 @@ __global__ __launch_bounds__(1024) void reduce_partials(const float* __restrict_
   }
 }
 
-__global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ gy, int ldgy, const float* __restrict__ x, int ldx,
-                                                    const float* __restrict__ y, int ldy, long long pixels, int C,
+template <class T>
+__global__ __launch_bounds__(256) void bn_bwd_apply(const T* __restrict__ gy, int ldgy, const T* __restrict__ x, int ldx,
+                                                    const T* __restrict__ y, int ldy, long long pixels, int C,
                                                     const float* __restrict__ stats, const float* __restrict__ gamma,
                                                     const float* __restrict__ sums, int act, float slope,
-                                                    float* __restrict__ gx, int ldgx, float* __restrict__ gres, int ldgres,
+                                                    T* __restrict__ gx, int ldgx, T* __restrict__ gres, int ldgres,
                                                     float* __restrict__ ggamma, float* __restrict__ gbeta, int accumulate, int lanes_c,
                                                     int rows) {
   const int tx = threadIdx.x % lanes_c, ty = threadIdx.x / lanes_c;
@@ -193,8 +207,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const float* __restrict__ gy
 //   ggy = act'(y) * gamma*r * (q - mean(q) - xc r^2 mean(q xc))
 //   gx2 = gamma * r^3/M * [ xc*(S_q S_g / M - S_gq + 3 r^2 S_gx S_qx / M) + S_qx (S_g/M - g) + S_gx (S_q/M - q) ]
 //   ggamma2 = r * (S_gq - S_q S_g / M - r^2 S_gx S_qx / M)
-__global__ __launch_bounds__(256) void bn_bwd2_partial(const float* __restrict__ ggx, const float* __restrict__ gy,
-                                                       const float* __restrict__ x, const float* __restrict__ y, long long pixels, int C,
+template <class T>
+__global__ __launch_bounds__(256) void bn_bwd2_partial(const T* __restrict__ ggx, const T* __restrict__ gy,
+                                                       const T* __restrict__ x, const T* __restrict__ y, long long pixels, int C,
                                                        const float* __restrict__ stats, int act, float slope, int lanes_c, int rows,
                                                        float* __restrict__ partial) {
   column_reduce<5>(pixels, C, lanes_c, rows, partial, [&](long long qi, int cb, f32x4* acc) {
@@ -215,11 +230,12 @@ __global__ __launch_bounds__(256) void bn_bwd2_partial(const float* __restrict__
   });
 }
 
-__global__ __launch_bounds__(256) void bn_bwd2_apply(const float* __restrict__ ggx, const float* __restrict__ gy,
-                                                     const float* __restrict__ x, const float* __restrict__ y, long long pixels, int C,
+template <class T>
+__global__ __launch_bounds__(256) void bn_bwd2_apply(const T* __restrict__ ggx, const T* __restrict__ gy,
+                                                     const T* __restrict__ x, const T* __restrict__ y, long long pixels, int C,
                                                      const float* __restrict__ stats, const float* __restrict__ gamma,
                                                      const float* __restrict__ sums, int act, float slope,
-                                                     float* __restrict__ ggy, float* __restrict__ gx2, float* __restrict__ ggamma2,
+                                                     T* __restrict__ ggy, T* __restrict__ gx2, float* __restrict__ ggamma2,
                                                      int lanes_c, int rows) {
   const int tx = threadIdx.x % lanes_c, ty = threadIdx.x / lanes_c;
   const float invM = 1.f / (float)pixels;
@@ -249,13 +265,15 @@ __global__ __launch_bounds__(256) void bn_bwd2_apply(const float* __restrict__ g
 }
 
 // ------------------------------------------------------------------ channel sums (bias gradients)
-__global__ __launch_bounds__(256) void channel_sum_partial(const float* __restrict__ x, long long pixels, int C, int ld, int lanes_c, int rows,
+template <class T>
+__global__ __launch_bounds__(256) void channel_sum_partial(const T* __restrict__ x, long long pixels, int C, int ld, int lanes_c, int rows,
                                                            float* __restrict__ partial) {
   column_reduce<1>(pixels, C, lanes_c, rows, partial, [&](long long q, int cb, f32x4* acc) { acc[0] += ld4(x + (size_t)q * ld + cb); });
 }
 
 // ------------------------------------------------------------------ layout
-__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int C, int HW, int ld) {
+template <class T>
+__global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict__ dst, int N, int C, int HW, int ld) {
   // one thread per (pixel, channel of ld); reads are strided by HW across channels but each
   // channel plane is swept contiguously by consecutive pixels of consecutive blocks.
   const size_t total = (size_t)N * HW * ld;
@@ -263,23 +281,25 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, float* __rest
     const int c = (int)(i % ld);
     const size_t pix = i / ld;
     const size_t n = pix / HW, hw = pix - n * HW;
-    dst[i] = c < C ? src[(n * C + c) * HW + hw] : 0.f;
+    st1(dst + i, c < C ? src[(n * C + c) * HW + hw] : 0.f);
   }
 }
 
-__global__ void nhwc_to_nchw_kernel(const float* __restrict__ src, int ld, float* __restrict__ dst, int N, int C, int HW) {
+template <class T>
+__global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, int ld, float* __restrict__ dst, int N, int C, int HW) {
   const size_t total = (size_t)N * C * HW;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const size_t hw = i % HW;
     const size_t nc = i / HW;
     const size_t n = nc / C, c = nc - n * C;
-    dst[i] = src[(n * HW + hw) * ld + c];
+    dst[i] = ld1(src + (n * HW + hw) * ld + c);
   }
 }
 
 // ------------------------------------------------------------------ max pool 2x2
-__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restrict__ x, int N, int H, int W, int C, int ldx,
-                                                          float* __restrict__ y, int ldy) {
+template <class T>
+__global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ x, int N, int H, int W, int C, int ldx,
+                                                          T* __restrict__ y, int ldy) {
   const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
   const size_t total = (size_t)N * Ho * Wo * C4;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -288,7 +308,7 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
     const int ox = (int)(op % Wo);
     const int oy = (int)((op / Wo) % Ho);
     const size_t n = op / ((size_t)Wo * Ho);
-    const float* b = x + ((n * H + 2 * oy) * W + 2 * ox) * (size_t)ldx + c;
+    const T* b = x + ((n * H + 2 * oy) * W + 2 * ox) * (size_t)ldx + c;
     f32x4 v = ld4(b);
     const f32x4 v1 = ld4(b + ldx), v2 = ld4(b + (size_t)W * ldx), v3 = ld4(b + (size_t)(W + 1) * ldx);
 #pragma unroll
@@ -297,8 +317,9 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const float* __restric
   }
 }
 
-__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restrict__ x, int ldx, const float* __restrict__ gy, int ldgy,
-                                                          int N, int H, int W, int C, float* __restrict__ gx, int ldgx) {
+template <class T>
+__global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ gy, int ldgy,
+                                                          int N, int H, int W, int C, T* __restrict__ gx, int ldgx) {
   const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
   const size_t total = (size_t)N * Ho * Wo * C4;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -329,8 +350,9 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const float* __restric
   }
 }
 
-__global__ __launch_bounds__(256) void act_bwd_kernel(const float* __restrict__ g, int ldg, const float* __restrict__ y, int ldy,
-                                                      long long pixels, int C, int act, float slope, float* __restrict__ out, int ldo) {
+template <class T>
+__global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ g, int ldg, const T* __restrict__ y, int ldy,
+                                                      long long pixels, int C, int act, float slope, T* __restrict__ out, int ldo) {
   const int C4 = C / 4;
   const size_t total = (size_t)pixels * C4;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -387,58 +409,72 @@ extern "C" {
 int lhg_abi_version(void) { return LHG_ABI_VERSION; }
 const char* lhg_last_error(void) { return err_buf(); }
 
-int lhg_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, int ld, lhg_stream_t s) {
+}  // extern "C"
+
+// ---- host side, generic over the activation element type T (float, or __bf16 in the bf16 storage mode).  The C entry points take
+// `float*` for every tensor (the ABI of the fp32 path); in the bf16 mode the same pointers address bf16 NHWC tensors.
+#define LHG_ACT_CALL(fn, ...) (lhg::act_is_bf16() ? fn<__bf16>(__VA_ARGS__) : fn<float>(__VA_ARGS__))
+template <class T> static inline const T* as_act(const float* p) { return reinterpret_cast<const T*>(p); }
+template <class T> static inline T* as_act(float* p) { return reinterpret_cast<T*>(p); }
+
+template <class T>
+static int nchw_to_nhwc_impl(const float* src, float* dst, int N, int C, int H, int W, int ld, lhg_stream_t s) {
   LHG_REQUIRE(ld >= C, "nchw_to_nhwc: ld %d < C %d", ld, C);
   const size_t total = (size_t)N * H * W * ld;
-  hipLaunchKernelGGL(nchw_to_nhwc_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, as_stream(s), src, dst, N, C, H * W, ld);
+  hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3(grid_for(total, 256, 16384)), dim3(256), 0, as_stream(s), src, as_act<T>(dst), N, C, H * W, ld);
   return check_launch("nchw_to_nhwc");
 }
 
-int lhg_nhwc_to_nchw(const float* src, int ld, float* dst, int N, int C, int H, int W, lhg_stream_t s) {
+template <class T>
+static int nhwc_to_nchw_impl(const float* src, int ld, float* dst, int N, int C, int H, int W, lhg_stream_t s) {
   LHG_REQUIRE(ld >= C, "nhwc_to_nchw: ld %d < C %d", ld, C);
   const size_t total = (size_t)N * C * H * W;
-  hipLaunchKernelGGL(nhwc_to_nchw_kernel, dim3(grid_for(total, 256, 16384)), dim3(256), 0, as_stream(s), src, ld, dst, N, C, H * W);
+  hipLaunchKernelGGL((nhwc_to_nchw_kernel<T>), dim3(grid_for(total, 256, 16384)), dim3(256), 0, as_stream(s), as_act<T>(src), ld, dst, N, C, H * W);
   return check_launch("nhwc_to_nchw");
 }
 
-int lhg_channel_sum(const float* x, long long pixels, int C, int ld, float* out, int accumulate, float* ws, lhg_stream_t s) {
+template <class T>
+static int channel_sum_impl(const float* x, long long pixels, int C, int ld, float* out, int accumulate, float* ws, lhg_stream_t s) {
   LHG_NHWC_OK(x, C, ld, "channel_sum");
   const ColMap cm = col_map(C);
   const int nblk = partial_blocks(pixels);
-  hipLaunchKernelGGL(channel_sum_partial, dim3(nblk), dim3(256), 0, as_stream(s), x, pixels, C, ld, cm.lanes_c, cm.rows, ws);
+  hipLaunchKernelGGL((channel_sum_partial<T>), dim3(nblk), dim3(256), 0, as_stream(s), as_act<T>(x), pixels, C, ld, cm.lanes_c, cm.rows, ws);
   hipLaunchKernelGGL(reduce_partials<1>, dim3((C + 31) / 32, 1), dim3(1024), 0, as_stream(s), ws, nblk, C, out, accumulate);
   return check_launch("channel_sum");
 }
 
-int lhg_bn_stats(const float* x, long long pixels, int C, int ld, float* stats, float* running_mean, float* running_var,
-                 float momentum, float eps, float* ws, lhg_stream_t s) {
+template <class T>
+static int bn_stats_impl(const float* x, long long pixels, int C, int ld, float* stats, float* running_mean, float* running_var,
+                         float momentum, float eps, float* ws, lhg_stream_t s) {
   LHG_NHWC_OK(x, C, ld, "bn_stats");
   LHG_REQUIRE(pixels > 0, "bn_stats: empty tensor");
   const ColMap cm = col_map(C);
   const int nblk = partial_blocks(pixels);
-  hipLaunchKernelGGL(bn_stats_partial, dim3(nblk), dim3(256), 0, as_stream(s), x, pixels, C, ld, cm.lanes_c, cm.rows, ws);
+  hipLaunchKernelGGL((bn_stats_partial<T>), dim3(nblk), dim3(256), 0, as_stream(s), as_act<T>(x), pixels, C, ld, cm.lanes_c, cm.rows, ws);
   float* sums = ws + (size_t)nblk * 2 * C;
-  hipLaunchKernelGGL(reduce_partials<2>, dim3((C + 31) / 32, 2), dim3(1024), 0, as_stream(s), ws, nblk, C, sums);
-  hipLaunchKernelGGL(bn_stats_final, dim3((C + 255) / 256), dim3(256), 0, as_stream(s), sums, x, pixels, C, stats, running_mean,
+  hipLaunchKernelGGL(reduce_partials<2>, dim3((C + 31) / 32, 2), dim3(1024), 0, as_stream(s), ws, nblk, C, sums, 0);
+  hipLaunchKernelGGL((bn_stats_final<T>), dim3((C + 255) / 256), dim3(256), 0, as_stream(s), sums, as_act<T>(x), pixels, C, stats, running_mean,
                      running_var, momentum, eps);
   return check_launch("bn_stats");
 }
 
-int lhg_bn_apply(const float* x, int ldx, long long pixels, int C, const float* stats, const float* gamma, const float* beta,
-                 const float* res, int ldres, int act, float slope, float* y, int ldy, lhg_stream_t s) {
+template <class T>
+static int bn_apply_impl(const float* x, int ldx, long long pixels, int C, const float* stats, const float* gamma, const float* beta,
+                         const float* res, int ldres, int act, float slope, float* y, int ldy, lhg_stream_t s) {
   LHG_NHWC_OK(x, C, ldx, "bn_apply(x)");
   LHG_NHWC_OK(y, C, ldy, "bn_apply(y)");
   if (res) LHG_NHWC_OK(res, C, ldres, "bn_apply(res)");
   const ColMap cm = col_map(C);
   const int nblk = grid_for((size_t)pixels, cm.rows * 4, 4096);
-  hipLaunchKernelGGL(bn_apply_kernel, dim3(nblk), dim3(256), 0, as_stream(s), x, ldx, pixels, C, stats, gamma, beta, res, ldres, act,
-                     slope, y, ldy, cm.lanes_c, cm.rows);
+  hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(nblk), dim3(256), 0, as_stream(s), as_act<T>(x), ldx, pixels, C, stats, gamma, beta, as_act<T>(res),
+                     ldres, act, slope, as_act<T>(y), ldy, cm.lanes_c, cm.rows);
   return check_launch("bn_apply");
 }
 
-int lhg_bn_backward(const float* gy, int ldgy, const float* x, int ldx, const float* y, int ldy, long long pixels, int C,
-                    const float* stats, const float* gamma, int act, float slope, float* gx, int ldgx, float* gres, int ldgres,
-                    float* ggamma, float* gbeta, int accumulate, float* ws, lhg_stream_t s) {
+template <class T>
+static int bn_backward_impl(const float* gy, int ldgy, const float* x, int ldx, const float* y, int ldy, long long pixels, int C,
+                            const float* stats, const float* gamma, int act, float slope, float* gx, int ldgx, float* gres, int ldgres,
+                            float* ggamma, float* gbeta, int accumulate, float* ws, lhg_stream_t s) {
   LHG_NHWC_OK(gy, C, ldgy, "bn_backward(gy)");
   LHG_NHWC_OK(x, C, ldx, "bn_backward(x)");
   LHG_NHWC_OK(gx, C, ldgx, "bn_backward(gx)");
@@ -447,61 +483,113 @@ int lhg_bn_backward(const float* gy, int ldgy, const float* x, int ldx, const fl
   const ColMap cm = col_map(C);
   const int nblk = partial_blocks(pixels);
   float* sums = ws + (size_t)nblk * 2 * C;
-  hipLaunchKernelGGL(bn_bwd_partial, dim3(nblk), dim3(256), 0, as_stream(s), gy, ldgy, x, ldx, y, ldy, pixels, C, stats, act, slope,
-                     cm.lanes_c, cm.rows, ws);
-  hipLaunchKernelGGL(reduce_partials<2>, dim3((C + 31) / 32, 2), dim3(1024), 0, as_stream(s), ws, nblk, C, sums);
+  hipLaunchKernelGGL((bn_bwd_partial<T>), dim3(nblk), dim3(256), 0, as_stream(s), as_act<T>(gy), ldgy, as_act<T>(x), ldx, as_act<T>(y), ldy, pixels, C,
+                     stats, act, slope, cm.lanes_c, cm.rows, ws);
+  hipLaunchKernelGGL(reduce_partials<2>, dim3((C + 31) / 32, 2), dim3(1024), 0, as_stream(s), ws, nblk, C, sums, 0);
   const int nb2 = grid_for((size_t)pixels, cm.rows * 4, 4096);
-  hipLaunchKernelGGL(bn_bwd_apply, dim3(nb2), dim3(256), 0, as_stream(s), gy, ldgy, x, ldx, y, ldy, pixels, C, stats, gamma, sums, act,
-                     slope, gx, ldgx, gres, ldgres, ggamma, gbeta, accumulate, cm.lanes_c, cm.rows);
+  hipLaunchKernelGGL((bn_bwd_apply<T>), dim3(nb2), dim3(256), 0, as_stream(s), as_act<T>(gy), ldgy, as_act<T>(x), ldx, as_act<T>(y), ldy, pixels, C, stats,
+                     gamma, sums, act, slope, as_act<T>(gx), ldgx, as_act<T>(gres), ldgres, ggamma, gbeta, accumulate, cm.lanes_c, cm.rows);
   return check_launch("bn_backward");
 }
 
-int lhg_bn_backward_backward(const float* ggx, const float* gy, const float* x, const float* y, long long pixels, int C,
-                             const float* stats, const float* gamma, int act, float slope, float* ggy, float* gx2, float* ggamma2,
-                             float* ws, lhg_stream_t s) {
+template <class T>
+static int bn_backward_backward_impl(const float* ggx, const float* gy, const float* x, const float* y, long long pixels, int C,
+                                     const float* stats, const float* gamma, int act, float slope, float* ggy, float* gx2, float* ggamma2,
+                                     float* ws, lhg_stream_t s) {
   LHG_NHWC_OK(ggx, C, C, "bn_backward_backward(ggx)");
   LHG_REQUIRE(aligned16(gy) && aligned16(x) && aligned16(ggy) && aligned16(gx2), "bn_backward_backward: unaligned tensor");
   const ColMap cm = col_map(C);
   const int nblk = partial_blocks(pixels);
   float* sums = ws + (size_t)nblk * 5 * C;
-  hipLaunchKernelGGL(bn_bwd2_partial, dim3(nblk), dim3(256), 0, as_stream(s), ggx, gy, x, y, pixels, C, stats, act, slope, cm.lanes_c,
-                     cm.rows, ws);
-  hipLaunchKernelGGL(reduce_partials<5>, dim3((C + 31) / 32, 5), dim3(1024), 0, as_stream(s), ws, nblk, C, sums);
+  hipLaunchKernelGGL((bn_bwd2_partial<T>), dim3(nblk), dim3(256), 0, as_stream(s), as_act<T>(ggx), as_act<T>(gy), as_act<T>(x), as_act<T>(y), pixels, C,
+                     stats, act, slope, cm.lanes_c, cm.rows, ws);
+  hipLaunchKernelGGL(reduce_partials<5>, dim3((C + 31) / 32, 5), dim3(1024), 0, as_stream(s), ws, nblk, C, sums, 0);
   const int nb2 = grid_for((size_t)pixels, cm.rows * 4, 4096);
-  hipLaunchKernelGGL(bn_bwd2_apply, dim3(nb2), dim3(256), 0, as_stream(s), ggx, gy, x, y, pixels, C, stats, gamma, sums, act, slope, ggy,
-                     gx2, ggamma2, cm.lanes_c, cm.rows);
+  hipLaunchKernelGGL((bn_bwd2_apply<T>), dim3(nb2), dim3(256), 0, as_stream(s), as_act<T>(ggx), as_act<T>(gy), as_act<T>(x), as_act<T>(y), pixels, C, stats,
+                     gamma, sums, act, slope, as_act<T>(ggy), as_act<T>(gx2), ggamma2, cm.lanes_c, cm.rows);
   return check_launch("bn_backward_backward");
 }
 
-int lhg_maxpool2x2_forward(const float* x, int N, int H, int W, int C, int ldx, float* y, int ldy, lhg_stream_t s) {
+template <class T>
+static int maxpool_fwd_impl(const float* x, int N, int H, int W, int C, int ldx, float* y, int ldy, lhg_stream_t s) {
   LHG_NHWC_OK(x, C, ldx, "maxpool(x)");
   LHG_NHWC_OK(y, C, ldy, "maxpool(y)");
   LHG_REQUIRE(H % 2 == 0 && W % 2 == 0, "maxpool2x2: odd extent %dx%d", H, W);
   const size_t total = (size_t)N * (H / 2) * (W / 2) * (C / 4);
-  hipLaunchKernelGGL(maxpool_fwd_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, as_stream(s), x, N, H, W, C, ldx, y, ldy);
+  hipLaunchKernelGGL((maxpool_fwd_kernel<T>), dim3(grid_for(total, 256, 8192)), dim3(256), 0, as_stream(s), as_act<T>(x), N, H, W, C, ldx, as_act<T>(y), ldy);
   return check_launch("maxpool_fwd");
 }
 
-int lhg_maxpool2x2_backward(const float* x, int ldx, const float* gy, int ldgy, int N, int H, int W, int C, float* gx, int ldgx,
-                            lhg_stream_t s) {
+template <class T>
+static int maxpool_bwd_impl(const float* x, int ldx, const float* gy, int ldgy, int N, int H, int W, int C, float* gx, int ldgx, lhg_stream_t s) {
   LHG_NHWC_OK(x, C, ldx, "maxpool_bwd(x)");
   LHG_NHWC_OK(gy, C, ldgy, "maxpool_bwd(gy)");
   LHG_NHWC_OK(gx, C, ldgx, "maxpool_bwd(gx)");
   const size_t total = (size_t)N * (H / 2) * (W / 2) * (C / 4);
-  hipLaunchKernelGGL(maxpool_bwd_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, as_stream(s), x, ldx, gy, ldgy, N, H, W, C, gx,
-                     ldgx);
+  hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(grid_for(total, 256, 8192)), dim3(256), 0, as_stream(s), as_act<T>(x), ldx, as_act<T>(gy), ldgy, N, H, W,
+                     C, as_act<T>(gx), ldgx);
   return check_launch("maxpool_bwd");
 }
 
-int lhg_act_backward(const float* g, int ldg, const float* y, int ldy, long long pixels, int C, int act, float slope, float* out,
-                     int ldo, lhg_stream_t s) {
+template <class T>
+static int act_backward_impl(const float* g, int ldg, const float* y, int ldy, long long pixels, int C, int act, float slope, float* out,
+                             int ldo, lhg_stream_t s) {
   LHG_NHWC_OK(g, C, ldg, "act_backward(g)");
   LHG_NHWC_OK(y, C, ldy, "act_backward(y)");
   LHG_NHWC_OK(out, C, ldo, "act_backward(out)");
   const size_t total = (size_t)pixels * (C / 4);
-  hipLaunchKernelGGL(act_bwd_kernel, dim3(grid_for(total, 256, 8192)), dim3(256), 0, as_stream(s), g, ldg, y, ldy, pixels, C, act, slope,
-                     out, ldo);
+  hipLaunchKernelGGL((act_bwd_kernel<T>), dim3(grid_for(total, 256, 8192)), dim3(256), 0, as_stream(s), as_act<T>(g), ldg, as_act<T>(y), ldy, pixels, C, act,
+                     slope, as_act<T>(out), ldo);
   return check_launch("act_backward");
+}
+
+extern "C" {
+
+int lhg_set_activation_dtype(int dtype) {
+  LHG_REQUIRE(dtype == LHG_DTYPE_F32 || dtype == LHG_DTYPE_BF16, "set_activation_dtype: unknown dtype %d", dtype);
+  lhg::act_dtype() = dtype;
+  return LHG_OK;
+}
+int lhg_get_activation_dtype(void) { return lhg::act_dtype(); }
+
+int lhg_nchw_to_nhwc(const float* src, float* dst, int N, int C, int H, int W, int ld, lhg_stream_t s) {
+  return LHG_ACT_CALL(nchw_to_nhwc_impl, src, dst, N, C, H, W, ld, s);
+}
+int lhg_nhwc_to_nchw(const float* src, int ld, float* dst, int N, int C, int H, int W, lhg_stream_t s) {
+  return LHG_ACT_CALL(nhwc_to_nchw_impl, src, ld, dst, N, C, H, W, s);
+}
+int lhg_channel_sum(const float* x, long long pixels, int C, int ld, float* out, int accumulate, float* ws, lhg_stream_t s) {
+  return LHG_ACT_CALL(channel_sum_impl, x, pixels, C, ld, out, accumulate, ws, s);
+}
+int lhg_bn_stats(const float* x, long long pixels, int C, int ld, float* stats, float* running_mean, float* running_var,
+                 float momentum, float eps, float* ws, lhg_stream_t s) {
+  return LHG_ACT_CALL(bn_stats_impl, x, pixels, C, ld, stats, running_mean, running_var, momentum, eps, ws, s);
+}
+int lhg_bn_apply(const float* x, int ldx, long long pixels, int C, const float* stats, const float* gamma, const float* beta,
+                 const float* res, int ldres, int act, float slope, float* y, int ldy, lhg_stream_t s) {
+  return LHG_ACT_CALL(bn_apply_impl, x, ldx, pixels, C, stats, gamma, beta, res, ldres, act, slope, y, ldy, s);
+}
+int lhg_bn_backward(const float* gy, int ldgy, const float* x, int ldx, const float* y, int ldy, long long pixels, int C,
+                    const float* stats, const float* gamma, int act, float slope, float* gx, int ldgx, float* gres, int ldgres,
+                    float* ggamma, float* gbeta, int accumulate, float* ws, lhg_stream_t s) {
+  return LHG_ACT_CALL(bn_backward_impl, gy, ldgy, x, ldx, y, ldy, pixels, C, stats, gamma, act, slope, gx, ldgx, gres, ldgres, ggamma, gbeta,
+                      accumulate, ws, s);
+}
+int lhg_bn_backward_backward(const float* ggx, const float* gy, const float* x, const float* y, long long pixels, int C,
+                             const float* stats, const float* gamma, int act, float slope, float* ggy, float* gx2, float* ggamma2,
+                             float* ws, lhg_stream_t s) {
+  return LHG_ACT_CALL(bn_backward_backward_impl, ggx, gy, x, y, pixels, C, stats, gamma, act, slope, ggy, gx2, ggamma2, ws, s);
+}
+int lhg_maxpool2x2_forward(const float* x, int N, int H, int W, int C, int ldx, float* y, int ldy, lhg_stream_t s) {
+  return LHG_ACT_CALL(maxpool_fwd_impl, x, N, H, W, C, ldx, y, ldy, s);
+}
+int lhg_maxpool2x2_backward(const float* x, int ldx, const float* gy, int ldgy, int N, int H, int W, int C, float* gx, int ldgx,
+                            lhg_stream_t s) {
+  return LHG_ACT_CALL(maxpool_bwd_impl, x, ldx, gy, ldgy, N, H, W, C, gx, ldgx, s);
+}
+int lhg_act_backward(const float* g, int ldg, const float* y, int ldy, long long pixels, int C, int act, float slope, float* out,
+                     int ldo, lhg_stream_t s) {
+  return LHG_ACT_CALL(act_backward_impl, g, ldg, y, ldy, pixels, C, act, slope, out, ldo, s);
 }
 
 int lhg_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps, int step,

@@ -439,6 +439,7 @@ int lhg_conv2d_thin_forward(const float* x, int N, int H, int W, int Ci, int ldx
                             const float* bias, const float* scale, const float* shift, int act, float slope, int planar_out,
                             lhg_stream_t s) {
   const int mode = lhg_conv2d_thin_supported(Ci, Co, k, 1);
+  LHG_REQUIRE(!act_is_bf16(), "conv2d_thin_forward: thin convolutions take fp32 tensors (bf16 storage routes every layer to the MFMA path)");
   LHG_REQUIRE(mode != 0, "conv2d_thin_forward: %d -> %d channels, %dx%d is not a thin convolution", Ci, Co, k, k);
   LHG_REQUIRE(N > 0 && H > 0 && W > 0 && ldx >= Ci && (planar_out || ldy >= Co), "conv2d_thin_forward: bad extents");
   LHG_REQUIRE(!(planar_out && mode == 1), "conv2d_thin_forward: planar output only for thin outputs");
@@ -461,6 +462,7 @@ int lhg_conv2d_thin_forward(const float* x, int N, int H, int W, int Ci, int ldx
 int lhg_conv2d_thin_backward_input(const float* gy, int N, int H, int W, int Co, int ldg, const float* w, int Ci, int k, float* gx,
                                    int ldgx, lhg_stream_t s) {
   const int mode = lhg_conv2d_thin_supported(Ci, Co, k, 1);
+  LHG_REQUIRE(!act_is_bf16(), "conv2d_thin_backward_input: thin convolutions take fp32 tensors (bf16 storage routes every layer to the MFMA path)");
   LHG_REQUIRE(mode != 0, "conv2d_thin_backward_input: %d -> %d channels, %dx%d is not a thin convolution", Ci, Co, k, k);
   LHG_REQUIRE(N > 0 && H > 0 && W > 0 && ldg >= Co && ldgx >= Ci, "conv2d_thin_backward_input: bad extents");
   ThinParams p{};
@@ -490,6 +492,7 @@ size_t lhg_conv2d_thin_wgrad_workspace(int N, int H, int W, int Ci, int Co, int 
 int lhg_conv2d_thin_backward_weight(const float* x, int N, int H, int W, int Ci, int ldx, const float* gy, int Co, int ldg, int k,
                                     float* gw, float* ws, size_t ws_bytes, lhg_stream_t s) {
   const int mode = lhg_conv2d_thin_supported(Ci, Co, k, 1);
+  LHG_REQUIRE(!act_is_bf16(), "conv2d_thin_backward_weight: thin convolutions take fp32 tensors (bf16 storage routes every layer to the MFMA path)");
   LHG_REQUIRE(mode != 0, "conv2d_thin_backward_weight: %d -> %d channels, %dx%d is not a thin convolution", Ci, Co, k, k);
   LHG_REQUIRE(N > 0 && H > 0 && W > 0 && ldx >= Ci && ldg >= Co, "conv2d_thin_backward_weight: bad extents");
   const size_t need = lhg_conv2d_thin_wgrad_workspace(N, H, W, Ci, Co, k);

@@ -27,6 +27,36 @@ from .native import ACT_LEAKY, ACT_NONE, ACT_RELU, ACT_SIGMOID, call, ptr, strea
 BN_EPS = 1e-5
 BN_MOMENTUM = 0.1
 
+# Element type of every NHWC activation (and activation-gradient) tensor between the ops: fp32, or bf16 in the bf16 storage mode
+# (set_activation_storage; BASELINE configs[2] / [4]).  NCHW tensors at the model boundary, planar outputs, parameters, statistics
+# and gradients of parameters are fp32 in both.
+_ACT_DTYPE = torch.float32
+
+
+def act_dtype() -> torch.dtype:
+    return _ACT_DTYPE
+
+
+def set_activation_storage(name: str) -> None:
+    """"fp32" or "bf16".  bf16 storage reads the conv-GEMM operands from HBM as bf16, so it also selects the "bf16" conv precision;
+    going back to fp32 storage restores the default precision.  Tensors created under one setting must not be used under the other."""
+    global _ACT_DTYPE
+    if name not in ("fp32", "bf16"):
+        raise ValueError(f"unknown activation storage {name!r} (fp32 | bf16)")
+    if name == "bf16":
+        set_conv_precision("bf16")
+        call("lhg_set_activation_dtype", 1)
+        _ACT_DTYPE = torch.bfloat16
+    else:
+        call("lhg_set_activation_dtype", 0)
+        _ACT_DTYPE = torch.float32
+        set_conv_precision("default")
+    _THIN_MODE.clear()
+
+
+def activation_storage() -> str:
+    return "bf16" if _ACT_DTYPE == torch.bfloat16 else "fp32"
+
 
 def pad_to(c: int, m: int) -> int:
     return (c + m - 1) // m * m
@@ -37,8 +67,8 @@ def nhwc(t: torch.Tensor):
     """(ptr, N, H, W, C, ld) of an NHWC view; validates the layout the kernels assume."""
     if t.dim() != 4:
         raise ValueError(f"expected a 4-D NHWC tensor, got shape {tuple(t.shape)}")
-    if t.dtype != torch.float32:
-        raise TypeError("hot-path tensors are fp32")
+    if t.dtype != _ACT_DTYPE:
+        raise TypeError(f"NHWC activation tensors are {_ACT_DTYPE} in the current storage mode, got {t.dtype}")
     N, H, W, Cc = t.shape
     s = t.stride()
     ld = s[2] if W > 1 else (s[1] if H > 1 else max(Cc, s[2]))
@@ -49,7 +79,7 @@ def nhwc(t: torch.Tensor):
 
 
 def new_nhwc(N, H, W, Cc, device):
-    return torch.empty((N, H, W, Cc), dtype=torch.float32, device=device)
+    return torch.empty((N, H, W, Cc), dtype=_ACT_DTYPE, device=device)
 
 
 class OutSlot:
@@ -64,9 +94,9 @@ class OutSlot:
         self.t = t
 
 
-def _resolve_out(out, shape, device):
+def _resolve_out(out, shape, device, dtype=None):
     if out is None:
-        return torch.empty(shape, dtype=torch.float32, device=device)
+        return torch.empty(shape, dtype=dtype or _ACT_DTYPE, device=device)
     t = out.t
     if tuple(t.shape) != tuple(shape):
         raise ValueError(f"output slot has shape {tuple(t.shape)}, op produces {tuple(shape)}")
@@ -419,7 +449,7 @@ def thin_mode(Ci, Co, k, stride):
     """0: MFMA gather-GEMM; 1 / 2: direct kernels of csrc/thin_conv.hip (thin input / thin output).  LHG_THIN=0 disables."""
     key = (Ci, Co, k, stride)
     if key not in _THIN_MODE:
-        on = os.environ.get("LHG_THIN", "1") != "0"
+        on = os.environ.get("LHG_THIN", "1") != "0" and _ACT_DTYPE == torch.float32  # bf16 storage: every layer on the MFMA path
         _THIN_MODE[key] = int(native.load().lhg_conv2d_thin_supported(Ci, Co, k, stride)) if on else 0
     return _THIN_MODE[key]
 
@@ -438,7 +468,7 @@ def conv2d_forward_raw(x, w, bias, stride, act=ACT_NONE, slope=0.0, scale=None, 
     mode = thin_mode(Ciw, Co, KH, stride) if KH == KW and res is None else 0
     if mode and not (mode == 2 and (scale is not None or shift is not None)) and not (mode == 1 and planar):
         if planar:
-            y = _resolve_out(out, (N, Co, H, W), x.device)
+            y = _resolve_out(out, (N, Co, H, W), x.device, torch.float32)
             py, ldy = ptr(y), Co
         else:
             y = _resolve_out(out, (N, H, W, Co), x.device)
@@ -449,7 +479,7 @@ def conv2d_forward_raw(x, w, bias, stride, act=ACT_NONE, slope=0.0, scale=None, 
     wp = pack_weight(w, True)
     Ho, Wo = _conv_out_hw(H, W, KH, stride)
     if planar:
-        y = _resolve_out(out, (N, Co, Ho, Wo), x.device)
+        y = _resolve_out(out, (N, Co, Ho, Wo), x.device, torch.float32)  # NCHW outputs are fp32 in every storage mode
         py, ldy = ptr(y), Co
     else:
         y = _resolve_out(out, (N, Ho, Wo, Co), x.device)
@@ -605,7 +635,7 @@ def _bias_grad(bias, gy, is_zero, Co):
     if gy.shape[-1] % 4 == 0:
         channel_sum_into(gy, slot)
     else:  # narrow heads (6 / 1 channels): a few hundred KB
-        slot.add_(gy.sum(dim=(0, 1, 2)))
+        slot.add_(gy.sum(dim=(0, 1, 2), dtype=torch.float32))
     note_contribution(bias)
     return None
 
@@ -687,7 +717,7 @@ class ConvTranspose2x2Fn(TrackedFunction):
 def channel_sum(t):
     """sum over (N,H,W) of an NHWC tensor -> (C,).  Used for bias gradients (linear in t)."""
     if t.shape[-1] % 4:  # heads with 6 / 1 channels: a few hundred KB
-        return t.sum(dim=(0, 1, 2))
+        return t.sum(dim=(0, 1, 2), dtype=torch.float32)
     return ChannelSumFn.apply(t)
 
 
@@ -710,7 +740,7 @@ class ChannelSumFn(Function):
 
     @staticmethod
     def backward(ctx, g):
-        return g.view(1, 1, 1, -1).expand(ctx.shape)
+        return g.to(_ACT_DTYPE).view(1, 1, 1, -1).expand(ctx.shape)
 
 
 # --------------------------------------------------------------------------- activations
@@ -898,7 +928,7 @@ class SigmoidHeadFn(TrackedFunction):
     @staticmethod
     def backward(ctx, gy):
         x, w, y = ctx.saved_tensors
-        g_pre = gy * y * (1 - y)  # (N, Co, H, W): 6 planes, negligible
+        g_pre = gy.float() * y * (1 - y)  # (N, Co, H, W) fp32: 6 planes, negligible
         g_nhwc = ToNHWC.apply(g_pre, 8 if thin_mode(w.shape[1], w.shape[0], 1, 1) else 32)
         gx = gw = gb = None
         if ctx.needs_input_grad[0]:

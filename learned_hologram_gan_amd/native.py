@@ -40,6 +40,8 @@ _SIGNATURES = {
     "lhg_nhwc_to_nchw": [_p, _i, _p, _i, _i, _i, _i, _p],
     "lhg_set_conv_precision": [_i],
     "lhg_get_conv_precision": [],
+    "lhg_set_activation_dtype": [_i],
+    "lhg_get_activation_dtype": [],
     "lhg_default_conv_precision": [],
     "lhg_packed_weight_floats": [C.c_int, C.c_int, C.c_int],
     "lhg_pack_weight": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _p],

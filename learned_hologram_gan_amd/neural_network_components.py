@@ -178,7 +178,7 @@ class UNet(nn.Module):
         N, _, H, W = X.shape
         dev = X.device
         x = ops.ToNHWC.apply(X, 32)
-        new = lambda h, w, c: torch.empty((N, h, w, c), dtype=torch.float32, device=dev)  # noqa: E731
+        new = lambda h, w, c: ops.new_nhwc(N, h, w, c, dev)  # noqa: E731  (fp32, or bf16 in the bf16 storage mode)
         buf4, buf3, buf2, buf1 = new(H, W, 128), new(H // 2, W // 2, 256), new(H // 4, W // 4, 512), new(H // 8, W // 8, 1024)
         pool = ops.MaxPool2x2Fn.apply
 

@@ -55,7 +55,7 @@ class WGANGPDiscriminator192(nn.Module):
                     sc, sh = ops.batch_norm_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var)
                     h = ops.conv2d_forward_raw(h, conv.weight, conv.bias, conv.stride[0], act=ACT_LEAKY, slope=0.2, scale=sc, shift=sh)
                 s = ops.conv2d_forward_raw(h, self.conv.weight, self.conv.bias, 1)
-        return s.reshape(s.shape[0], -1)  # (N, H/8, W/8, 1) -> (N, H*W/64), same order as Flatten on NCHW
+        return s.reshape(s.shape[0], -1).float()  # (N, H/8, W/8, 1) -> (N, H*W/64), same order as Flatten on NCHW; scores are fp32
 
 
 class fakeDiscriminator(nn.Module):

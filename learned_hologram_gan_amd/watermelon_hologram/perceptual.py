@@ -86,5 +86,5 @@ class perceptualLoss(nn.Module):
         fh = self.features(hat)
         loss = torch.zeros((), device=hat.device)
         for a, b in zip(fh, ft):
-            loss = loss + torch.nn.functional.mse_loss(a, b)
+            loss = loss + torch.nn.functional.mse_loss(a.float(), b.float())  # (feature maps are bf16 in the bf16 storage mode)
         return loss / self.feature_map_layers_num

@@ -4,6 +4,7 @@ artefact (`poh.pt` -> ten PNGs, README.md:123-156) through the HIP path.  Everyt
 tests support; bf16 mode: reconstruction PSNR against the fp32 oracle (BASELINE.json "recon PSNR vs ref").
 """
 
+import contextlib
 import os
 
 import numpy as np
@@ -59,16 +60,35 @@ def test_known_answer_terminal_test_pngs_on_the_hip_path():
 
 
 # ----------------------------------------------------------------------------- configs[1] / configs[2]: 384^2, batch 4 per rank
-def test_config2_per_rank_bf16_train_step_384_bs4(oracle_full_step):
-    """BASELINE configs[2], one rank's share: the 384x384 batch-4 GAN train step in the bf16 mode (bf16 conv-GEMM operands, fp32
-    accumulation, fp32 BatchNorm / losses / FFT / Adam) against the fp32 CPU oracle on identical inputs: reconstruction PSNR."""
+@contextlib.contextmanager
+def _bf16(kind):
+    """"operands": fp32 tensors, conv-GEMM operands rounded to bf16.  "storage": NHWC activations and their gradients bf16 in HBM as well
+    (BatchNorm / loss / FFT / Adam arithmetic and every parameter stay fp32)."""
+    from learned_hologram_gan_amd import hip_ops
+
+    if kind == "storage":
+        hip_ops.set_activation_storage("bf16")
+    else:
+        hip_ops.set_conv_precision(kind if kind == "fp32" else "bf16")
+    try:
+        yield
+    finally:
+        if kind == "storage":
+            hip_ops.set_activation_storage("fp32")
+        hip_ops.set_conv_precision("default")
+
+
+@pytest.mark.parametrize("kind", ["operands", "storage"])
+def test_config2_per_rank_bf16_train_step_384_bs4(oracle_full_step, kind):
+    """BASELINE configs[2], one rank's share: the 384x384 batch-4 GAN train step in the bf16 modes (bf16 conv-GEMM operands, and bf16
+    activation storage; fp32 accumulation, fp32 BatchNorm / losses / FFT / Adam) against the fp32 CPU oracle on identical inputs:
+    reconstruction PSNR."""
     from learned_hologram_gan_amd import hip_ops
     from learned_hologram_gan_amd.watermelon_hologram.watermelon import watermelon
 
     cfg, ref = oracle_full_step
     B = cfg["rgbd"].shape[0]
-    hip_ops.set_conv_precision("bf16")
-    try:
+    with _bf16(kind):
         W = watermelon(filter_radius_coefficient=cfg["coef"], pad_size=cfg["pad"], distance_stack=cfg["stack"],
                        input_shape=(1, 4, cfg["rows"], cfg["cols"]))
         W.generator.load_state_dict(seeded.generator_state_dict())
@@ -79,21 +99,20 @@ def test_config2_per_rank_bf16_train_step_384_bs4(oracle_full_step):
         out = W.train_step(cfg["rgbd"].to(DEV), cfg["tamp"].to(DEV), cfg["tphs"].to(DEV), cfg["idx"], [a.to(DEV) for a in cfg["alphas"]])
         got = dict(zip(("focal_phase_gradient_loss", "perceptual_loss", "pixel_loss", "TV_loss", "gan_loss", "G_loss", "D_loss"),
                        W.train_losses_tensor.tolist()))
-    finally:
-        hip_ops.set_conv_precision("default")
     assert out["hat_amps"].shape == (B, 3, cfg["rows"], cfg["cols"])
     p_amp = _psnr(out["hat_amps"].cpu(), ref["hat_amps"])
     p_poh = _psnr(torch.cos(out["POH"].cpu()), torch.cos(ref["POH"]))
-    assert p_amp > 35.0 and p_poh > 28.0, (p_amp, p_poh)
+    assert (p_amp > 35.0 and p_poh > 28.0) if kind == "operands" else (p_amp > 30.0 and p_poh > 24.0), (p_amp, p_poh)
     assert rel_err(out["target_amps"].cpu(), ref["target_amps"]) < PARITY  # no conv GEMM on the target path
+    tol = 5e-2 if kind == "operands" else 1e-1
     for k in ("focal_phase_gradient_loss", "pixel_loss", "TV_loss"):
-        assert abs(got[k] - ref[k]) <= 5e-2 * abs(ref[k]) + 1e-6, (k, got[k], ref[k])
-    assert abs(got["D_loss"] - ref["D_loss"]) <= 1e-1 * abs(ref["D_loss"]) + 1e-6
-    assert hip_ops.conv_precision() == hip_ops.default_precision()
+        assert abs(got[k] - ref[k]) <= tol * abs(ref[k]) + 1e-6, (k, got[k], ref[k])
+    assert abs(got["D_loss"] - ref["D_loss"]) <= 2 * tol * abs(ref["D_loss"]) + 1e-6
+    assert hip_ops.conv_precision() == hip_ops.default_precision() and hip_ops.activation_storage() == "fp32"
 
 
 # ----------------------------------------------------------------------------- configs[4]: batch 1 per rank, 3-plane reconstruction loss
-@pytest.mark.parametrize("precision", ["fp32", "bf16"])
+@pytest.mark.parametrize("precision", ["fp32", "bf16", "bf16_storage"])
 def test_config4_per_rank_bs1_three_plane_reconstruction_loss_384(precision):
     """BASELINE configs[4], one rank's share: batch 1 at 384x384 (pad 320 -> 1024^2 fp32 FFTs), the hologram and the target propagated
     to ALL planes of a 3-plane stack (``..._all_fixed_multiple_distances_freq2amp``, ref: angular_spectrum_method.py:524-531) and the
@@ -121,8 +140,7 @@ def test_config4_per_rank_bs1_three_plane_reconstruction_loss_384(precision):
                  losses.total_variation_loss(a_ref[:n], a_ref[n:]))
     (terms_ref[0] + terms_ref[1] + 1e-3 * terms_ref[2]).backward()
 
-    hip_ops.set_conv_precision(precision)
-    try:
+    with _bf16({"fp32": "fp32", "bf16": "operands", "bf16_storage": "storage"}[precision]):
         G = Generator(rows, cols, pad, coef, 3, PITCH, WL, torch.tensor([1e-3]))
         G.load_state_dict(seeded.generator_state_dict())
         G.to(DEV).train()
@@ -134,8 +152,6 @@ def test_config4_per_rank_bs1_three_plane_reconstruction_loss_384(precision):
         focal, mse, tv = ReconLossFn.apply(amps[:n].contiguous(), amps[n:].contiguous(), phss[:n].contiguous(), phss[n:].contiguous()).unbind(0)
         (focal + mse + 1e-3 * tv).backward()
         torch.cuda.synchronize()
-    finally:
-        hip_ops.set_conv_precision("default")
     named = dict(G.named_parameters())
     probe = ("part1.part1.decoder4.0.convolution_layer_2.weight", "part1.part1.bottleneck.1.0.convolution_layer_1.weight",
              "part1.part1.encoder1.0.0.convolution_layer_1.weight", "part2.part1.conv_g.params")
@@ -148,12 +164,13 @@ def test_config4_per_rank_bs1_three_plane_reconstruction_loss_384(precision):
             g, r = named[k].grad.cpu().double(), sd[k].grad.double()
             assert ((g - r).norm() / r.norm()).item() < 2e-2, k
     else:
-        assert _psnr(amps[:n].detach().cpu(), a_ref[:n].detach()) > 35.0
+        storage = precision == "bf16_storage"
+        assert _psnr(amps[:n].detach().cpu(), a_ref[:n].detach()) > (30.0 if storage else 35.0)
         for got, ref in zip((focal, mse, tv), terms_ref):
-            assert abs(got.item() - ref.item()) <= 5e-2 * abs(ref.item()) + 1e-6
+            assert abs(got.item() - ref.item()) <= (1e-1 if storage else 5e-2) * abs(ref.item()) + 1e-6
         for k in probe:
             g, r = named[k].grad.cpu().double(), sd[k].grad.double()
-            assert (torch.dot(g.flatten(), r.flatten()) / (g.norm() * r.norm())).item() > 0.9, k  # direction of the update (bf16 operand rounding through up to 27 conv layers and batch-1 BatchNorm)
+            assert (torch.dot(g.flatten(), r.flatten()) / (g.norm() * r.norm())).item() > (0.8 if storage else 0.9), k  # direction of the update (bf16 operand rounding through up to 27 conv layers and batch-1 BatchNorm)
 
 
 # ----------------------------------------------------------------------------- configs[3]: one 4K frame end to end

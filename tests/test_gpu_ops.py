@@ -495,3 +495,69 @@ def test_psnr_ssim_kernels_match_definitions(shape):
     assert abs(got[1].item() - ssim(x, y).item()) < 2e-5 and abs(got[0].item() - psnr(x, y).item()) < 1e-3
     same = psnr_ssim(x.to(DEV), x.to(DEV)).cpu()
     assert abs(same[1].item() - 1.0) < 1e-6 and torch.isinf(same[0])
+
+
+# ----------------------------------------------------------------------------- bf16 activation storage (BASELINE configs[2] / [4])
+@pytest.fixture
+def bf16_storage(ops):
+    ops.set_activation_storage("bf16")
+    try:
+        yield ops
+    finally:
+        ops.set_activation_storage("fp32")
+    assert ops.activation_storage() == "fp32" and ops.conv_precision() == ops.default_precision()
+
+
+def _rb(t):
+    return t.bfloat16().float()
+
+
+@pytest.mark.parametrize("case", [(2, 64, 64, 24, 20, 3, 1), (1, 32, 128, 40, 40, 3, 1), (2, 128, 256, 16, 16, 3, 1), (2, 32, 64, 18, 22, 3, 2),
+                                  (3, 256, 128, 8, 8, 1, 1), (2, 4, 64, 32, 32, 3, 1), (2, 64, 6, 32, 32, 1, 1)], ids=lambda c: "x".join(map(str, c)))
+def test_bf16_storage_conv_family(bf16_storage, case):
+    """bf16 storage mode: NHWC activations and their gradients are bf16 in HBM, the GEMMs read them without conversion, accumulate in
+    fp32 and round once on the way out.  Against fp32 convolutions of the SAME bf16 values: only the output rounding (2^-9) and the
+    summation order differ.  The thin layers (4 -> 64, 64 -> 6) take the MFMA path here."""
+    ops = bf16_storage
+    N, Ci, Co, H, W, k, stride = case
+    x, w, b = _rb(rnd(N, Ci, H, W, seed=1)), rnd(Co, Ci, k, k, seed=2, scale=(Ci * k * k) ** -0.5), rnd(Co, seed=3, scale=0.1)
+    xr, wr = x.clone().requires_grad_(True), _rb(w).requires_grad_(True)
+    y_ref = F.conv2d(xr, wr, b, stride=stride, padding=k // 2)
+    proj = _rb(rnd(*y_ref.shape, seed=4))
+    gx_ref, gw_ref = torch.autograd.grad((y_ref * proj).sum(), (xr, wr))
+    xg = to_nhwc(x, ops.pad_to(Ci, 32)).bfloat16().requires_grad_(True)
+    wg, bg = w.to(DEV).requires_grad_(True), b.to(DEV).requires_grad_(True)
+    yg = ops.Conv2dFn.apply(xg, wg, bg, stride, None)
+    assert yg.dtype == torch.bfloat16
+    assert rel_err(to_nchw(yg.float()), y_ref.detach()) < 6e-3
+    (yg.float() * to_nhwc(proj)).sum().backward()
+    assert xg.grad.dtype == torch.bfloat16 and wg.grad.dtype == torch.float32
+    assert rel_err(to_nchw(xg.grad.float())[:, :Ci], gx_ref) < 6e-3
+    assert rel_err(wg.grad.cpu(), gw_ref) < 2e-3  # fp32 accumulation of bf16 x bf16 products, fp32 result
+    assert rel_err(bg.grad.cpu(), proj.sum(dim=(0, 2, 3))) < 1e-4
+
+
+def test_bf16_storage_batch_norm_pool_and_layout(bf16_storage):
+    ops = bf16_storage
+    N, C, H, W = 2, 64, 12, 20
+    x = _rb(rnd(N, C, H, W, seed=5) * 2 + 0.3)
+    gamma, beta = rnd(C, seed=6) + 1.5, rnd(C, seed=7)
+    xr, gr, br = x.clone().requires_grad_(True), gamma.clone().requires_grad_(True), beta.clone().requires_grad_(True)
+    y_ref = F.relu(F.batch_norm(xr, None, None, gr, br, True, 0.1, 1e-5))
+    proj = _rb(rnd(N, C, H, W, seed=8))
+    gx_ref, gg_ref, gb_ref = torch.autograd.grad((y_ref * proj).sum(), (xr, gr, br))
+    # layout kernels: NCHW fp32 <-> NHWC bf16
+    xg = ops.ToNHWC.apply(x.to(DEV), C)
+    assert xg.dtype == torch.bfloat16 and torch.equal(ops.ToNCHW.apply(xg, C).cpu(), x)
+    xg = xg.detach().requires_grad_(True)
+    gg, bb = gamma.to(DEV).requires_grad_(True), beta.to(DEV).requires_grad_(True)
+    rm, rv = torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+    yg = ops.BatchNormTrainFn.apply(xg, gg, bb, rm, rv, None, ops.ACT_RELU, 0.0, None)
+    assert yg.dtype == torch.bfloat16 and rel_err(to_nchw(yg.float()), y_ref.detach()) < 6e-3
+    (yg.float() * to_nhwc(proj)).sum().backward()
+    assert rel_err(to_nchw(xg.grad.float()), gx_ref) < 2e-2  # the mask comes from the ROUNDED output: a few borderline pixels flip
+    assert rel_err(gg.grad.cpu(), gg_ref) < 2e-2 and rel_err(bb.grad.cpu(), gb_ref) < 2e-2
+    assert rel_err(rm.cpu(), 0.1 * x.mean(dim=(0, 2, 3))) < 1e-4
+    # max pool: exact on bf16 values, gradient routed to the first maximum
+    p = ops.MaxPool2x2Fn.apply(xg.detach())
+    assert torch.equal(to_nchw(p.float()), F.max_pool2d(x, 2))
