@@ -599,17 +599,27 @@ static int launch_gg_bf16_t(GGParams& p, hipStream_t st) {
   const unsigned wb = (unsigned)wp_bytes;
   auto blocks = [&](int bm, int bn) { return (unsigned)(((g.M + bm - 1) / bm) * (p.rows_pad / bn)); };
   const bool n128 = p.rows_pad % 128 == 0;
-  constexpr int NV = 6;  // 0..2: 32-k steps; 3..5: 64-k steps (half the barriers and address arithmetic per flop; Ci % 64 == 0)
+  // 0..2: 32-k steps; 3..5: 64-k steps (half the barriers and address arithmetic per flop; Ci % 64 == 0); 6..9: the 8-wave
+  // producer / consumer kernel (gg3s_kernel with one bf16 plane): 128x128 / 128x64 / 64x64 tiles with 64-k steps, 128x128 with 32-k
+  constexpr int NV = 10;
   const bool k64 = g.Ci % 64 == 0;
-  auto valid = [&](int v) { return (v % 3 == 0 ? n128 : true) && (v < 3 || k64); };
+  auto valid = [&](int v) {
+    if (v >= 6) return (v == 6 || v == 9 ? n128 : true) && (v == 9 || k64);
+    return (v % 3 == 0 ? n128 : true) && (v < 3 || k64);
+  };
   auto run = [&](int v) {
     switch (v) {
+      case 6: hipLaunchKernelGGL((gg3s_kernel<128, 128, 1, 4, 64, TA>), dim3(blocks(128, 128)), dim3(512), 0, st, p, ib, wb); break;
+      case 7: hipLaunchKernelGGL((gg3s_kernel<128, 64, 1, 4, 64, TA>), dim3(blocks(128, 64)), dim3(512), 0, st, p, ib, wb); break;
+      case 8: hipLaunchKernelGGL((gg3s_kernel<64, 64, 1, 4, 64, TA>), dim3(blocks(64, 64)), dim3(512), 0, st, p, ib, wb); break;
+      case 9: hipLaunchKernelGGL((gg3s_kernel<128, 128, 1, 4, 32, TA>), dim3(blocks(128, 128)), dim3(512), 0, st, p, ib, wb); break;
       case 0: hipLaunchKernelGGL((gg2b_kernel<128, 128, 2, 2, 32, TA>), dim3(blocks(128, 128)), dim3(256), 0, st, p, ib, wb); break;
       case 1: hipLaunchKernelGGL((gg2b_kernel<128, 64, 2, 2, 32, TA>), dim3(blocks(128, 64)), dim3(256), 0, st, p, ib, wb); break;
       case 2: hipLaunchKernelGGL((gg2b_kernel<64, 64, 2, 2, 32, TA>), dim3(blocks(64, 64)), dim3(256), 0, st, p, ib, wb); break;
       case 3: hipLaunchKernelGGL((gg2b_kernel<128, 128, 2, 2, 64, TA>), dim3(blocks(128, 128)), dim3(256), 0, st, p, ib, wb); break;
       case 4: hipLaunchKernelGGL((gg2b_kernel<128, 64, 2, 2, 64, TA>), dim3(blocks(128, 64)), dim3(256), 0, st, p, ib, wb); break;
-      default: hipLaunchKernelGGL((gg2b_kernel<64, 64, 2, 2, 64, TA>), dim3(blocks(64, 64)), dim3(256), 0, st, p, ib, wb); break;
+      case 5: hipLaunchKernelGGL((gg2b_kernel<64, 64, 2, 2, 64, TA>), dim3(blocks(64, 64)), dim3(256), 0, st, p, ib, wb); break;
+      default: break;
     }
   };
   static const int forced = [] { const char* e = getenv("LHG_GGB_VARIANT"); return e ? atoi(e) : -1; }();
