@@ -12,10 +12,13 @@
 //                          inverse FFT, keep the rows0 cropped rows      -> T2[plane][rows0][cols]
 //   pass 3  rows_inverse : 1-D inverse FFT, crop to cols0, |z| / angle(z) / complex epilogue.
 // Per plane-pair of 2-D transforms this moves ~11 MB at 384^2/1024^2 instead of the 67 MB of two
-// dense fft2 calls (DESIGN.md has the accounting).  The 1-D transforms are Stockham autosort
-// radix-4 (+ one radix-2 stage for odd log2 n) in LDS with a host-exact twiddle table
-// (computed in double), in place with register staging (read-all / barrier / write-all).
+// dense fft2 calls (DESIGN.md has the accounting).  Transform lengths 256 and 1024 (the 192^2 / 384^2 frames with the
+// reference's pads) run on register-resident two-step transforms (asm_cols_reg.inc: one LDS round trip per 1-D transform);
+// every other length 2^a 3^b uses the Stockham autosort radix-4 / 2 / 3 stages below (in LDS, host-exact twiddle table
+// computed in double, in place with register staging: read-all / barrier / write-all).
 #include <algorithm>
+#include <cstdlib>
+#include <type_traits>
 
 #include "common.h"
 
@@ -352,6 +355,8 @@ __global__ __launch_bounds__(1024) void cols_filter_kernel(const ColsParams p) {
   }
 }
 
+#include "asm_cols_reg.inc"
+
 // ---------------------------------------------------------------------------------------- pass 3
 __global__ __launch_bounds__(256) void rows_inverse_kernel(const float2* __restrict__ t2, int total_rows, int cols0, int pad_c, int n, int nf,
                                                            const float2* __restrict__ twg, float* __restrict__ out_a, float* __restrict__ out_b,
@@ -419,8 +424,37 @@ static int set_dyn_lds(const void* fn, size_t bytes) {
   return LHG_OK;
 }
 
+static bool asm_reg_enabled() {
+  static const bool reg = [] { const char* e = getenv("LHG_ASM_REG"); return e ? atoi(e) != 0 : true; }();
+  return reg;
+}
+
+template <int N1, int NF>
+static int run_rows_forward_reg(const float* in_a, const float* in_b, int in_mode, float phase_scale, int total_rows, int cols0, int pad_c,
+                                const float* tw_cols, float2* t1, hipStream_t st) {
+  const size_t lds = RegFftLds<N1>::bytes(NF);
+  int rc = set_dyn_lds(reinterpret_cast<const void*>(rows_fwd_reg_kernel<N1, NF>), lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL((rows_fwd_reg_kernel<N1, NF>), dim3((total_rows + NF - 1) / NF), dim3(N1 * NF), lds, st, in_a, in_b, in_mode, phase_scale,
+                     total_rows, cols0, pad_c, reinterpret_cast<const float2*>(tw_cols), t1);
+  return check_launch("rows_forward");
+}
+
+template <int N1, int NF>
+static int run_rows_inverse_reg(const float2* t2, int total_rows, int cols0, int pad_c, const float* tw_cols, float* out_a, float* out_b,
+                                float* out_c, int out_mode, hipStream_t st) {
+  const size_t lds = RegFftLds<N1>::bytes(NF);
+  int rc = set_dyn_lds(reinterpret_cast<const void*>(rows_inv_reg_kernel<N1, NF>), lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL((rows_inv_reg_kernel<N1, NF>), dim3((total_rows + NF - 1) / NF), dim3(N1 * NF), lds, st, t2, total_rows, cols0, pad_c,
+                     reinterpret_cast<const float2*>(tw_cols), out_a, out_b, reinterpret_cast<float2*>(out_c), out_mode);
+  return check_launch("rows_inverse");
+}
+
 static int run_rows_forward(const float* in_a, const float* in_b, int in_mode, float phase_scale, int planes, int rows0, int cols0,
                             int pad_c, int cols, const float* tw_cols, float2* t1, hipStream_t st) {
+  if (asm_reg_enabled() && cols == 1024) return run_rows_forward_reg<32, 8>(in_a, in_b, in_mode, phase_scale, planes * rows0, cols0, pad_c, tw_cols, t1, st);
+  if (asm_reg_enabled() && cols == 256) return run_rows_forward_reg<16, 16>(in_a, in_b, in_mode, phase_scale, planes * rows0, cols0, pad_c, tw_cols, t1, st);
   const int nf = rows_nf(cols);
   const size_t lds = (size_t)(cols + nf * cols) * sizeof(float2);
   int rc = set_dyn_lds(reinterpret_cast<const void*>(rows_forward_kernel), lds);
@@ -433,6 +467,8 @@ static int run_rows_forward(const float* in_a, const float* in_b, int in_mode, f
 
 static int run_rows_inverse(const float2* t2, int planes, int rows0, int cols0, int pad_c, int cols, const float* tw_cols, float* out_a,
                             float* out_b, float* out_c, int out_mode, hipStream_t st) {
+  if (asm_reg_enabled() && cols == 1024) return run_rows_inverse_reg<32, 8>(t2, planes * rows0, cols0, pad_c, tw_cols, out_a, out_b, out_c, out_mode, st);
+  if (asm_reg_enabled() && cols == 256) return run_rows_inverse_reg<16, 16>(t2, planes * rows0, cols0, pad_c, tw_cols, out_a, out_b, out_c, out_mode, st);
   const int nf = rows_nf(cols);
   const size_t lds = (size_t)(cols + nf * cols) * sizeof(float2);
   int rc = set_dyn_lds(reinterpret_cast<const void*>(rows_inverse_kernel), lds);
@@ -443,7 +479,22 @@ static int run_rows_inverse(const float2* t2, int planes, int rows0, int cols0, 
   return check_launch("rows_inverse");
 }
 
+template <int N1, int G>
+static int run_cols_reg(ColsParams& p, hipStream_t st) {
+  const size_t lds = RegFftLds<N1>::bytes(G);
+  int rc = set_dyn_lds(reinterpret_cast<const void*>(cols_reg_kernel<N1, G>), lds);
+  if (rc) return rc;
+  p.G = G;
+  hipLaunchKernelGGL((cols_reg_kernel<N1, G>), dim3(p.planes * (p.C / G)), dim3(N1 * G), lds, st, p);
+  return check_launch("cols_reg");
+}
+
 static int run_cols(ColsParams& p, hipStream_t st) {
+  // column lengths 256 and 1024: the register-resident two-step transform (asm_cols_reg.inc); LHG_ASM_REG=0 keeps the Stockham kernel
+  if (asm_reg_enabled() && p.C % 16 == 0) {
+    if (p.R == 1024) return run_cols_reg<32, 8>(p, st);   // 76 KB of LDS: two workgroups per CU overlap each other's memory phases
+    if (p.R == 256) return run_cols_reg<16, 16>(p, st);
+  }
   // G columns per workgroup: 16 (128-byte segments) while G*R <= 16*threads keeps <= MAX_IT butterflies per thread
   int G = 16;
   while (G > 1 && (size_t)G * (p.R + 1) * sizeof(float2) + (size_t)p.R * sizeof(float2) > 150 * 1024) G >>= 1;
