@@ -142,7 +142,7 @@ def roofline_block(res, steps, peak):
                              "algorithmic_gflop_per_step": round(wg["algorithmic_flops"] / steps / 1e9, 2)}}
 
 
-def secondary_4k(native, dev, world, sync, peak, planes=8, warmup=2, steps=5):
+def secondary_4k(native, dev, world, sync, peak, peak_note, planes=8, warmup=2, steps=5):
     """north_star's second target: RGBD -> POH for one 3840x2160 frame (batch 1, pad 72 -> 2304x4096 transforms) + the hologram
     propagated to `planes` planes (generatePOH.py --propagate).  Replicas only across GPUs (one frame per GPU)."""
     from learned_hologram_gan_amd.angular_spectrum_method import bandLimitedAngularSpectrumMethod_for_multiple_distances as Mu
@@ -184,7 +184,8 @@ def secondary_4k(native, dev, world, sync, peak, planes=8, warmup=2, steps=5):
             "config": {"workload": f"{cols}x{rows}x3 bs=1/GPU generator forward (UNet + ASM back-propagation + POH encode, pad {pad} -> "
                                    f"{rows + 2 * pad}x{cols + 2 * int(pad * cols / rows)} transforms) + {planes}-plane propagate; replicas only"},
             "roofline": {"kernel": "gather-GEMM (the frame's 12.89 TFLOP of convolutions)", "bound": "mfma", "achieved": round(a, 3), "peak": peak,
-                         "unit": "TFLOP/s", "frac": round(a / peak, 4), "traffic": None,
+                         "peak_note": peak_note, "unit": "TFLOP/s", "frac": round(a / peak, 4),
+                         "frac_of_fp32_mfma_peak": round(a / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
                          "kernel_ms_per_frame": round(gg["total_ms"] / steps, 3),
                          "algorithmic_gflop_per_frame": round(gg["algorithmic_flops"] / steps / 1e9, 1)}}
 
@@ -208,7 +209,13 @@ def main():
     elif args.dtype == "bf16":
         hip_ops.set_activation_storage("bf16")  # bf16 NHWC activations + bf16 conv-GEMM operands; fp32 accumulation / BN / FFT / Adam
     bf16 = args.dtype == "bf16"
-    mfma_peak = BF16_MFMA_PEAK_TFLOPS if bf16 else FP32_MFMA_PEAK_TFLOPS
+    mode = hip_ops.conv_precision()
+    # the matrix roofline of the GEMM formulation in use: algorithmic (fp32 multiply-add) TFLOP/s it can reach at most
+    products = {"fp32": None, "fp32_split": 6, "fp32_split2": 3, "bf16": 1}[mode]
+    mfma_peak = FP32_MFMA_PEAK_TFLOPS if products is None else round(BF16_MFMA_PEAK_TFLOPS / products, 1)
+    peak_note = ("dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)" if products is None else
+                 f"dense bf16 MFMA peak {BF16_MFMA_PEAK_TFLOPS:.0f} TFLOP/s / {products} bf16 product(s) per multiply-add of the '{mode}' formulation"
+                 + ("" if bf16 else f"; the exact-fp32 MFMA formulation peaks at {FP32_MFMA_PEAK_TFLOPS}"))
     stack = torch.linspace(-4e-4, 0.0, 21)[:-1]  # trainingModel.py:62
     perceptual = None
     if args.perceptual > 0:
@@ -308,16 +315,22 @@ def main():
 
     out = None
     if rank == 0:
-        traffic, traffic_src = (None, None) if bf16 else pmc_traffic()
-        r = {"kernel": "lhg::gg2b_kernel (MFMA bf16 gather-GEMM)" if bf16 else
-                       "lhg::gg2_kernel / gg_kernel (MFMA fp32 gather-GEMM: conv forward / input-gradient / conv-transpose)",
-             "bound": "mfma", "peak": mfma_peak, "unit": "TFLOP/s", "traffic": traffic, "traffic_source": traffic_src}
+        traffic, traffic_src = (None, None) if mode != hip_ops.default_precision() else pmc_traffic()
+        kernel = {"fp32": "lhg::gg2_kernel / gg_kernel (exact fp32 MFMA gather-GEMM)",
+                  "fp32_split": "lhg::gg3s_kernel (gather-GEMM on the bf16 matrix pipe, fp32-faithful: operands as exact sums of three bf16 terms, "
+                                "six MFMA products per multiply, fp32 accumulation)",
+                  "fp32_split2": "lhg::gg3s_kernel (two bf16 terms, three MFMA products per multiply)",
+                  "bf16": "lhg::gg2b_kernel / gg3s_kernel (bf16 MFMA gather-GEMM)"}[mode]
+        r = {"kernel": kernel + ": conv forward / input-gradient / conv-transpose", "bound": "mfma", "peak": mfma_peak, "peak_note": peak_note,
+             "unit": "TFLOP/s", "traffic": traffic, "traffic_source": traffic_src}
         r.update(roofline_block(prof.result, P, mfma_peak))
+        r["frac_of_fp32_mfma_peak"] = round(r["achieved"] / FP32_MFMA_PEAK_TFLOPS, 4)
         r["measured"] = (f"HIP events around every launch over {P} steps of the same workload right after the (un-instrumented) timed region, "
                          "under its conditions: weight-gradient GEMMs run concurrently on a second HIP stream, so launch durations include "
                          "time sharing the GPU")
         if iso is not None:
             r["isolated"] = roofline_block(iso, P, mfma_peak)
+            r["isolated"]["frac_of_fp32_mfma_peak"] = round(r["isolated"]["achieved"] / FP32_MFMA_PEAK_TFLOPS, 4)
             r["isolated"]["measured"] = (f"{P} more steps with the second stream off: the kernel's own duration (what rocprofv3 --kernel-trace "
                                          "reports, since it serialises dispatches)")
         out = {
@@ -347,7 +360,7 @@ def main():
     if args.secondary and not bf16:
         del W
         torch.cuda.empty_cache()
-        sec = secondary_4k(native, dev, world, sync, mfma_peak)
+        sec = secondary_4k(native, dev, world, sync, mfma_peak, peak_note)
     if rank == 0:
         if sec is not None:
             out["secondary"] = sec
