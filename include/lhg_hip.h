@@ -9,10 +9,17 @@
  *
  * Conventions
  *   - plain C: raw DEVICE pointers, ints, floats and a hipStream_t (passed as void*);
- *     no torch types.  The library never allocates, frees or synchronises: every
- *     workspace is passed in, every launch goes to `stream` (graph-capture safe).
- *   - activations are NHWC fp32.  A tensor is (ptr, N, H, W, C, ld) where ld >= C is
- *     the distance in floats between consecutive pixels, so a channel slice of a
+ *     no torch types.  The library never allocates or frees: every workspace is passed
+ *     in, every launch goes to `stream`.  It synchronises in ONE place: the first launch
+ *     of a GEMM geometry it has not seen times its tiling variants with HIP events on
+ *     `stream` (lhg_autotune(0) / LHG_AUTOTUNE=0 turns that off; it is skipped while the
+ *     stream is being captured, so warm the geometries up before capturing a graph).
+ *   - threading: the mode switches, the autotune cache, the profiling timers and the
+ *     last-error text are process-global and not locked.  One host thread per process
+ *     calls the library, as in the reference (single-threaded, DataLoader(num_workers=0)).
+ *   - activations are NHWC fp32 (bf16 after lhg_set_activation_dtype(LHG_DTYPE_BF16)).
+ *     A tensor is (ptr, N, H, W, C, ld) where ld >= C is
+ *     the distance in elements between consecutive pixels, so a channel slice of a
  *     wider buffer (concat-free UNet skips) is addressable.  C must be a multiple of
  *     32 for GEMM inputs (producers zero-pad: lhg_nchw_to_nhwc).
  *   - optical fields are planar (B,3,rows,cols) fp32 / interleaved complex64, exactly

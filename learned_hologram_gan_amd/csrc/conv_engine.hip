@@ -57,6 +57,7 @@ struct GGParams {
   int ldres, rows_pad, act, planar_out;
   float slope;
   int xcd;  // 1: XCD-contiguous tile order (xcd_contiguous)
+  int prio; // gg3s_kernel: 0 no s_setprio, 1 consumers (MFMA waves) raised, 2 producers (load / split waves) raised
 };
 
 struct WGParams {
@@ -529,6 +530,8 @@ static int launch_gg(GGParams& p, hipStream_t st) {
   const Geom& g = p.g;
   if (g.M <= 0) return LHG_OK;
   p.xcd = xcd_order();
+  static const int prio = [] { const char* e = getenv("LHG_GG_PRIO"); return e ? atoi(e) : 1; }();
+  p.prio = prio;
   if (g_precision == LHG_PRECISION_BF16) return launch_gg_bf16(p, st);
   LHG_REQUIRE(!act_is_bf16(), "bf16 activation storage needs the bf16 conv precision (lhg_set_conv_precision(LHG_PRECISION_BF16))");
   if (split_mode()) return launch_gg_split(p, st);
@@ -744,20 +747,20 @@ static int launch_wg(WGParams& p, int S, hipStream_t st, const WG3Params* p3 = n
         else hipLaunchKernelGGL((wg2b_kernel<64, 64, float>), grid(64, 64), dim3(256), 0, st, p, ib, gb);
         break;
       case 10:
-        if (NP == 3) hipLaunchKernelGGL((wg2s_kernel<128, 128, 3, 1>), grid(128, 128), dim3(256), 0, st, p, ib, gb);
-        else hipLaunchKernelGGL((wg2s_kernel<128, 128, 2, 2>), grid(128, 128), dim3(256), 0, st, p, ib, gb);
+        if (NP == 3) hipLaunchKernelGGL((wg2s_kernel<128, 128, 3, 2>), grid(128, 128), dim3(512), 0, st, p, ib, gb);
+        else hipLaunchKernelGGL((wg2s_kernel<128, 128, 2, 2>), grid(128, 128), dim3(512), 0, st, p, ib, gb);
         break;
       case 11:
-        if (NP == 3) hipLaunchKernelGGL((wg2s_kernel<128, 64, 3, 2>), grid(128, 64), dim3(256), 0, st, p, ib, gb);
-        else hipLaunchKernelGGL((wg2s_kernel<128, 64, 2, 2>), grid(128, 64), dim3(256), 0, st, p, ib, gb);
+        if (NP == 3) hipLaunchKernelGGL((wg2s_kernel<128, 64, 3, 2>), grid(128, 64), dim3(512), 0, st, p, ib, gb);
+        else hipLaunchKernelGGL((wg2s_kernel<128, 64, 2, 2>), grid(128, 64), dim3(512), 0, st, p, ib, gb);
         break;
       case 12:
-        if (NP == 3) hipLaunchKernelGGL((wg2s_kernel<64, 128, 3, 2>), grid(64, 128), dim3(256), 0, st, p, ib, gb);
-        else hipLaunchKernelGGL((wg2s_kernel<64, 128, 2, 2>), grid(64, 128), dim3(256), 0, st, p, ib, gb);
+        if (NP == 3) hipLaunchKernelGGL((wg2s_kernel<64, 128, 3, 2>), grid(64, 128), dim3(512), 0, st, p, ib, gb);
+        else hipLaunchKernelGGL((wg2s_kernel<64, 128, 2, 2>), grid(64, 128), dim3(512), 0, st, p, ib, gb);
         break;
       case 13:
-        if (NP == 3) hipLaunchKernelGGL((wg2s_kernel<64, 64, 3, 2>), grid(64, 64), dim3(256), 0, st, p, ib, gb);
-        else hipLaunchKernelGGL((wg2s_kernel<64, 64, 2, 2>), grid(64, 64), dim3(256), 0, st, p, ib, gb);
+        if (NP == 3) hipLaunchKernelGGL((wg2s_kernel<64, 64, 3, 2>), grid(64, 64), dim3(512), 0, st, p, ib, gb);
+        else hipLaunchKernelGGL((wg2s_kernel<64, 64, 2, 2>), grid(64, 64), dim3(512), 0, st, p, ib, gb);
         break;
       default: hipLaunchKernelGGL(wg_kernel, grid(64, 64), dim3(256), 0, st, p); break;
     }
@@ -786,7 +789,8 @@ static int pick_splits(long long pixels, int m_pad, int n_pad, int taps) {
   const int bm = m_pad % 128 == 0 ? 128 : 64, bn = n_pad % 128 == 0 ? 128 : 64;
   const long long tiles = (long long)(m_pad / bm) * (n_pad / bn) * taps;
   const long long steps = (pixels + BK - 1) / BK;
-  long long s = (1536 + tiles - 1) / tiles;
+  static const long long target = [] { const char* e = getenv("LHG_WG_TARGET"); return e ? atoll(e) : 1536ll; }();
+  long long s = (target + tiles - 1) / tiles;
   const long long cap = steps / 8 > 1 ? steps / 8 : 1;
   if (s > cap) s = cap;
   if (s < 1) s = 1;
