@@ -658,14 +658,17 @@ static int launch_gg_split(GGParams& p, hipStream_t st) {
   const unsigned wb = (unsigned)wp_bytes;
   auto blocks = [&](int bm, int bn) { return (unsigned)(((g.M + bm - 1) / bm) * (p.rows_pad / bn)); };
   const bool n128 = p.rows_pad % 128 == 0;
-  constexpr int NV = 3;
-  auto valid = [&](int v) { return v == 0 ? n128 : true; };
+  constexpr int NV = 5;  // 3, 4: eight consumer waves (two per SIMD) on the 128x128 / 128x64 tiles
+  auto valid = [&](int v) { return (v == 0 || v == 3) ? n128 : (NP == 3 || v < 3); };
   auto run = [&](int v) {
     if (NP == 3) {
       switch (v) {
+        case 3: hipLaunchKernelGGL((gg3s_kernel<128, 128, 3, 1, 32, float, 8>), dim3(blocks(128, 128)), dim3(768), 0, st, p, ib, wb); break;
+        case 4: hipLaunchKernelGGL((gg3s_kernel<128, 64, 3, 1, 32, float, 8>), dim3(blocks(128, 64)), dim3(768), 0, st, p, ib, wb); break;
         case 0: hipLaunchKernelGGL((gg3s_kernel<128, 128, 3, 2>), dim3(blocks(128, 128)), dim3(512), 0, st, p, ib, wb); break;
         case 1: hipLaunchKernelGGL((gg3s_kernel<128, 64, 3, 2>), dim3(blocks(128, 64)), dim3(512), 0, st, p, ib, wb); break;
-        default: hipLaunchKernelGGL((gg3s_kernel<64, 64, 3, 2>), dim3(blocks(64, 64)), dim3(512), 0, st, p, ib, wb); break;
+        case 2: hipLaunchKernelGGL((gg3s_kernel<64, 64, 3, 2>), dim3(blocks(64, 64)), dim3(512), 0, st, p, ib, wb); break;
+        default: break;
       }
     } else {
       switch (v) {
