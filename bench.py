@@ -61,6 +61,7 @@ def parse():
     ap.add_argument("--cpu-rows", type=int, default=0, help="frame size of the CPU sample (0 = same as --rows)")
     ap.add_argument("--secondary", type=int, default=1, help="0 skips the 4K inference leg (north_star's second target)")
     ap.add_argument("--profile-steps", type=int, default=5, help="steps of each instrumented pass behind `roofline`")
+    ap.add_argument("--other-modes", type=int, default=1, help="0 skips the informational timing of the other GEMM formulations")
     ap.add_argument("--graph", type=int, default=0, help="infer mode: replay a captured hipGraph instead of eager launches")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
                     help="f32 (the benchmark metric): exact fp32 MFMA.  bf16 (BASELINE configs[2]/[4], informational): bf16 conv-GEMM operands, "
@@ -354,6 +355,26 @@ def main():
                        "global_batch": B * world, "parallelism": f"dp{world}"},
             "roofline": r,
         }
+
+    # ---- the same step with the other fp32-tensor GEMM formulations (informational; a few steps each, every rank: collectives inside)
+    other = {}
+    if args.mode == "train" and not bf16 and args.other_modes:
+        for name in ("fp32", "fp32_split2"):
+            if name == mode:
+                continue
+            hip_ops.set_conv_precision(name)
+            for _ in range(2):
+                W.train_step(rgbd, tamp, tphs)
+            sync()
+            t0 = time.perf_counter()
+            for _ in range(4):
+                W.train_step(rgbd, tamp, tphs)
+            sync()
+            other[name] = round((time.perf_counter() - t0) / 4 * 1e3, 3)
+        hip_ops.set_conv_precision(mode)
+    if rank == 0 and other:
+        out["other_modes_ms_per_step"] = dict(other, note="fp32: exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  fp32_split2: two bf16 terms per operand, "
+                                              "three MFMA products (max-rel error ~5e-6 per op instead of ~1e-6: NOT the headline mode)")
 
     # ---- free the trainer, then north_star's second target (4K bs=1 inference + 8 planes), replicas only
     sec = None

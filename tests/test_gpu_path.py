@@ -755,7 +755,7 @@ def test_two_rank_bench_rehearsal():
     env = dict(os.environ, LHG_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
            "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rows", "64",
-           "--cols", "64", "--pad", "32", "--cpu-baseline", "0", "--secondary", "0"]
+           "--cols", "64", "--pad", "32", "--cpu-baseline", "0", "--secondary", "0", "--other-modes", "0"]
     res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=280)
     assert res.returncode == 0, res.stderr[-2000:]
     line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
