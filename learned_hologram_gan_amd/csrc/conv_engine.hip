@@ -329,6 +329,7 @@ __global__ __launch_bounds__(256, 2) void wg_kernel(const WGParams p) {
 #include "wg2_kernel.inc"
 #include "wg2b_kernel.inc"
 #include "wg2s_kernel.inc"
+#include "wg3b_kernel.inc"
 #include "wg3_kernel.inc"
 
 // ------------------------------------------------------------------------------------ small kernels
@@ -707,12 +708,15 @@ static int launch_wg(WGParams& p, int S, hipStream_t st, const WG3Params* p3 = n
   const bool small = in_bytes < (1ull << 32) - 64 && go_bytes < (1ull << 32) - 64;
   const unsigned ib = (unsigned)in_bytes, gb = (unsigned)go_bytes;
   const bool m128 = p.m_pad % 128 == 0, n128 = p.n_pad % 128 == 0;
-  constexpr int NV = 14;  // 5: nine-tap fused kernel for 3x3 stride 1; 6..9: bf16-operand kernels; 10..13: split (fp32-faithful) kernels
+  // 5: nine-tap fused kernel for 3x3 stride 1; 6..9: bf16-operand kernels; 10..13: split (fp32-faithful) kernels;
+  // 14..17: bf16 STORAGE kernels with transposed LDS reads (wg3b_kernel)
+  constexpr int NV = 18;
   const bool bf16 = g_precision == LHG_PRECISION_BF16;
   const bool split = split_mode();
   const int NP = split_planes();
   if (bf16 || split) LHG_REQUIRE(small, "wgrad (bf16 / split mode): tensors of 4 GiB and more are not supported");
   auto valid = [&](int v) {
+    if (v >= 14) return bf16 && act16 && (v == 14 ? m128 && n128 : v == 15 ? m128 : v == 16 ? n128 : true);
     if (split) return v >= 10 && (v == 10 ? m128 && n128 : v == 11 ? m128 : v == 12 ? n128 : true);
     if (v >= 10) return false;
     if (bf16) return v >= 6 && (v == 6 ? m128 && n128 : v == 7 ? m128 : v == 8 ? n128 : true);
@@ -749,6 +753,10 @@ static int launch_wg(WGParams& p, int S, hipStream_t st, const WG3Params* p3 = n
         if (act16) hipLaunchKernelGGL((wg2b_kernel<64, 64, __bf16>), grid(64, 64), dim3(256), 0, st, p, ib, gb);
         else hipLaunchKernelGGL((wg2b_kernel<64, 64, float>), grid(64, 64), dim3(256), 0, st, p, ib, gb);
         break;
+      case 14: hipLaunchKernelGGL((wg3b_kernel<128, 128>), grid(128, 128), dim3(256), 0, st, p, ib, gb); break;
+      case 15: hipLaunchKernelGGL((wg3b_kernel<128, 64>), grid(128, 64), dim3(256), 0, st, p, ib, gb); break;
+      case 16: hipLaunchKernelGGL((wg3b_kernel<64, 128>), grid(64, 128), dim3(256), 0, st, p, ib, gb); break;
+      case 17: hipLaunchKernelGGL((wg3b_kernel<64, 64>), grid(64, 64), dim3(256), 0, st, p, ib, gb); break;
       case 10:
         if (NP == 3) hipLaunchKernelGGL((wg2s_kernel<128, 128, 3, 2>), grid(128, 128), dim3(512), 0, st, p, ib, gb);
         else hipLaunchKernelGGL((wg2s_kernel<128, 128, 2, 2>), grid(128, 128), dim3(512), 0, st, p, ib, gb);
@@ -777,6 +785,7 @@ static int launch_wg(WGParams& p, int S, hipStream_t st, const WG3Params* p3 = n
     choice = autotuned_variant(g_wg_choice, key, NV, valid, run, st);
   }
   if (choice < 0 && split) choice = m128 && n128 && (p.m_pad / 128) * (p.n_pad / 128) * g.T * S >= 200 ? 10 : 13;
+  if (choice < 0 && bf16 && act16) choice = m128 && n128 && (p.m_pad / 128) * (p.n_pad / 128) * g.T * S >= 400 ? 14 : 17;
   if (choice < 0 && bf16) choice = m128 && n128 && (p.m_pad / 128) * (p.n_pad / 128) * g.T * S >= 400 ? 6 : 9;
   if (choice < 0) choice = small ? (p3 ? 5 : (m128 && n128 && (p.m_pad / 128) * (p.n_pad / 128) * g.T * S >= 400 ? 0 : 3)) : 4;
   ScopedKernelTime timed(1, st, 2.0 * g.M * (double)p.m_pad * p.n_pad * g.T);
