@@ -7,33 +7,57 @@
 
 namespace lhg {
 
-// thread (tx, ty): tx indexes a float4 column group, ty a pixel row inside the pass
+// thread (tx, ty): tx indexes a float4 column group, ty a pixel row inside the pass.  At most 16 lanes (64 channels) along the
+// channel axis per workgroup; wider tensors spread their channel groups over blockIdx.y, so that the deep layers (24 x 24 x 1024:
+// 2304 pixels) still launch hundreds of workgroups instead of a few dozen that walk all channels serially.
 struct ColMap {
   int lanes_c, rows;  // lanes_c * rows == 256
+  int gy;             // workgroups along the channel axis
 };
 static inline ColMap col_map(int C) {
   int c4 = C / 4;
   int lanes = 1;
-  while (lanes < c4 && lanes < 256) lanes <<= 1;
-  return {lanes, 256 / lanes};
+  while (lanes < c4 && lanes < 16) lanes <<= 1;
+  return {lanes, 256 / lanes, (c4 + lanes - 1) / lanes};
 }
 
 // ------------------------------------------------------------------ generic column reductions
-// NSUM partial sums per channel; functor F(pixel, c4 offset) -> array of NSUM float4 contributions
-template <int NSUM, class F>
-__device__ __forceinline__ void column_reduce(long long pixels, int C, int lanes_c, int rows, float* __restrict__ partial, F f) {
+// Streaming loops keep PIXEL_UNROLL pixels of loads in flight per thread: the kernels are bound by memory latency, not by issue
+// (with one pixel per iteration a CU holds ~50-100 KB in flight, below what 8 TB/s x the loaded latency needs, and the bf16 storage
+// mode — half the bytes per load — ran no faster than fp32).  load(q) only loads, use(q, v) only computes/stores.
+constexpr int PIXEL_UNROLL = 4;
+template <class L, class F>
+__device__ __forceinline__ void pixel_loop(long long q0, long long q1, long long step, L load, F use) {
+  long long q = q0;
+  for (; q + (PIXEL_UNROLL - 1) * step < q1; q += PIXEL_UNROLL * step) {
+    decltype(load(q)) v[PIXEL_UNROLL];
+#pragma unroll
+    for (int u = 0; u < PIXEL_UNROLL; ++u) v[u] = load(q + u * step);
+#pragma unroll
+    for (int u = 0; u < PIXEL_UNROLL; ++u) use(q + u * step, v[u]);
+  }
+  for (; q < q1; q += step) use(q, load(q));
+}
+
+// NSUM partial sums per channel.  pre(cb) -> per-column constants, load(q, cb) -> loaded values of one pixel,
+// use(values, constants, acc) adds the NSUM float4 contributions.
+template <int NSUM, class P, class L, class F>
+__device__ __forceinline__ void column_reduce(long long pixels, int C, int lanes_c, int rows, float* __restrict__ partial, P pre, L load,
+                                              F use) {
   __shared__ float red[NSUM][256 * 4];
   const int tx = threadIdx.x % lanes_c, ty = threadIdx.x / lanes_c;
   const long long chunk = (pixels + gridDim.x - 1) / gridDim.x;
   const long long p0 = blockIdx.x * chunk, p1 = min(pixels, p0 + chunk);
-  for (int cb0 = 0; cb0 < C; cb0 += lanes_c * 4) {  // uniform trip count: barriers inside
+  for (int cb0 = blockIdx.y * lanes_c * 4; cb0 < C; cb0 += gridDim.y * lanes_c * 4) {  // uniform trip count: barriers inside
     const int cb = cb0 + tx * 4;
     const bool live = cb < C;
     f32x4 acc[NSUM];
 #pragma unroll
     for (int k = 0; k < NSUM; ++k) acc[k] = (f32x4){0.f, 0.f, 0.f, 0.f};
-    if (live)
-      for (long long q = p0 + ty; q < p1; q += rows) f(q, cb, acc);
+    if (live) {
+      const auto ctx = pre(cb);
+      pixel_loop(p0 + ty, p1, rows, [&](long long q) { return load(q, cb); }, [&](long long, const auto& v) { use(v, ctx, acc); });
+    }
 #pragma unroll
     for (int k = 0; k < NSUM; ++k)
 #pragma unroll
@@ -65,17 +89,30 @@ __device__ __forceinline__ float ld1(const __bf16* p) { return (float)*p; }
 __device__ __forceinline__ void st1(float* p, float v) { *p = v; }
 __device__ __forceinline__ void st1(__bf16* p, float v) { *p = (__bf16)v; }
 
+struct V1 { f32x4 a; };
+struct V2 { f32x4 a, b; };
+struct V3 { f32x4 a, b, c; };
+struct V4 { f32x4 a, b, c, d; };
+__device__ __forceinline__ f32x4 act_grad4(f32x4 yy, int act, float slope) {
+  f32x4 m;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) m[e] = act_grad_from_output(yy[e], act, slope);
+  return m;
+}
+
 // ------------------------------------------------------------------ BN statistics
 template <class T>
 __global__ __launch_bounds__(256) void bn_stats_partial(const T* __restrict__ x, long long pixels, int C, int ld,
                                                         int lanes_c, int rows, float* __restrict__ partial) {
   // shifted sums around the first pixel of each channel (stable one-pass variance)
-  column_reduce<2>(pixels, C, lanes_c, rows, partial, [&](long long q, int cb, f32x4* acc) {
-    const f32x4 k = ld4(x + cb);
-    const f32x4 d = ld4(x + (size_t)q * ld + cb) - k;
-    acc[0] += d;
-    acc[1] += d * d;
-  });
+  column_reduce<2>(
+      pixels, C, lanes_c, rows, partial, [&](int cb) { return ld4(x + cb); },
+      [&](long long q, int cb) { return V1{ld4(x + (size_t)q * ld + cb)}; },
+      [&](const V1& v, const f32x4& k, f32x4* acc) {
+        const f32x4 d = v.a - k;
+        acc[0] += d;
+        acc[1] += d * d;
+      });
 }
 
 template <class T>
@@ -104,17 +141,25 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
                                                        const float* __restrict__ beta, const T* __restrict__ res, int ldres,
                                                        int act, float slope, T* __restrict__ y, int ldy, int lanes_c, int rows) {
   const int tx = threadIdx.x % lanes_c, ty = threadIdx.x / lanes_c;
-  for (int cb = tx * 4; cb < C; cb += lanes_c * 4) {
+  for (int cb = (blockIdx.y * lanes_c + tx) * 4; cb < C; cb += gridDim.y * lanes_c * 4) {
     const f32x4 mean = ld4(stats + cb), inv = ld4(stats + C + cb);
     const f32x4 a = inv * ld4(gamma + cb);
     const f32x4 b = ld4(beta + cb) - mean * a;
-    for (long long q = (long long)blockIdx.x * rows + ty; q < pixels; q += (long long)gridDim.x * rows) {
-      f32x4 v = ld4(x + (size_t)q * ldx + cb) * a + b;
-      if (res) v += ld4(res + (size_t)q * ldres + cb);
+    pixel_loop(
+        (long long)blockIdx.x * rows + ty, pixels, (long long)gridDim.x * rows,
+        [&](long long q) {
+          V2 v;
+          v.a = ld4(x + (size_t)q * ldx + cb);
+          if (res) v.b = ld4(res + (size_t)q * ldres + cb);
+          return v;
+        },
+        [&](long long q, const V2& l) {
+          f32x4 v = l.a * a + b;
+          if (res) v += l.b;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act, slope);
-      st4(y + (size_t)q * ldy + cb, v);
-    }
+          for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act, slope);
+          st4(y + (size_t)q * ldy + cb, v);
+        });
   }
 }
 
@@ -124,17 +169,22 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const T* __restrict__ gy, 
                                                       const T* __restrict__ y, int ldy, long long pixels, int C,
                                                       const float* __restrict__ stats, int act, float slope, int lanes_c, int rows,
                                                       float* __restrict__ partial) {
-  column_reduce<2>(pixels, C, lanes_c, rows, partial, [&](long long q, int cb, f32x4* acc) {
-    f32x4 g = ld4(gy + (size_t)q * ldgy + cb);
-    if (act != LHG_ACT_NONE) {
-      const f32x4 yy = ld4(y + (size_t)q * ldy + cb);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) g[e] *= act_grad_from_output(yy[e], act, slope);
-    }
-    const f32x4 xh = (ld4(x + (size_t)q * ldx + cb) - ld4(stats + cb)) * ld4(stats + C + cb);
-    acc[0] += g;
-    acc[1] += g * xh;
-  });
+  column_reduce<2>(
+      pixels, C, lanes_c, rows, partial, [&](int cb) { return V2{ld4(stats + cb), ld4(stats + C + cb)}; },
+      [&](long long q, int cb) {
+        V3 v;
+        v.a = ld4(gy + (size_t)q * ldgy + cb);
+        v.b = ld4(x + (size_t)q * ldx + cb);
+        if (act != LHG_ACT_NONE) v.c = ld4(y + (size_t)q * ldy + cb);
+        return v;
+      },
+      [&](const V3& v, const V2& st, f32x4* acc) {
+        f32x4 g = v.a;
+        if (act != LHG_ACT_NONE) g *= act_grad4(v.c, act, slope);
+        const f32x4 xh = (v.b - st.a) * st.b;
+        acc[0] += g;
+        acc[1] += g * xh;
+      });
 }
 
 // sums[k][c] = sum_b partial[b][k][c] in double.  grid (ceil(C/32), NSUM), block 32 channels x 32 slices; four independent
@@ -180,7 +230,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const T* __restrict__ gy, in
                                                     int rows) {
   const int tx = threadIdx.x % lanes_c, ty = threadIdx.x / lanes_c;
   const float invn = 1.f / (float)pixels;
-  for (int cb = tx * 4; cb < C; cb += lanes_c * 4) {
+  for (int cb = (blockIdx.y * lanes_c + tx) * 4; cb < C; cb += gridDim.y * lanes_c * 4) {
     const f32x4 mean = ld4(stats + cb), inv = ld4(stats + C + cb), gam = ld4(gamma + cb);
     const f32x4 sg = ld4(sums + cb), sgx = ld4(sums + C + cb);
     if (blockIdx.x == 0 && ty == 0) {  // one writer per channel: accumulation into a gradient slot is race free and ordered by the stream
@@ -188,17 +238,22 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const T* __restrict__ gy, in
       if (gbeta) st4(gbeta + cb, accumulate ? ld4(gbeta + cb) + sg : sg);
     }
     const f32x4 k = gam * inv, mg = sg * invn, mgx = sgx * invn;
-    for (long long q = (long long)blockIdx.x * rows + ty; q < pixels; q += (long long)gridDim.x * rows) {
-      f32x4 g = ld4(gy + (size_t)q * ldgy + cb);
-      if (act != LHG_ACT_NONE) {
-        const f32x4 yy = ld4(y + (size_t)q * ldy + cb);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) g[e] *= act_grad_from_output(yy[e], act, slope);
-      }
-      if (gres) st4(gres + (size_t)q * ldgres + cb, g);
-      const f32x4 xh = (ld4(x + (size_t)q * ldx + cb) - mean) * inv;
-      st4(gx + (size_t)q * ldgx + cb, k * (g - mg - xh * mgx));
-    }
+    pixel_loop(
+        (long long)blockIdx.x * rows + ty, pixels, (long long)gridDim.x * rows,
+        [&](long long q) {
+          V3 v;
+          v.a = ld4(gy + (size_t)q * ldgy + cb);
+          v.b = ld4(x + (size_t)q * ldx + cb);
+          if (act != LHG_ACT_NONE) v.c = ld4(y + (size_t)q * ldy + cb);
+          return v;
+        },
+        [&](long long q, const V3& v) {
+          f32x4 g = v.a;
+          if (act != LHG_ACT_NONE) g *= act_grad4(v.c, act, slope);
+          if (gres) st4(gres + (size_t)q * ldgres + cb, g);
+          const f32x4 xh = (v.b - mean) * inv;
+          st4(gx + (size_t)q * ldgx + cb, k * (g - mg - xh * mgx));
+        });
   }
 }
 
@@ -212,22 +267,27 @@ __global__ __launch_bounds__(256) void bn_bwd2_partial(const T* __restrict__ ggx
                                                        const T* __restrict__ x, const T* __restrict__ y, long long pixels, int C,
                                                        const float* __restrict__ stats, int act, float slope, int lanes_c, int rows,
                                                        float* __restrict__ partial) {
-  column_reduce<5>(pixels, C, lanes_c, rows, partial, [&](long long qi, int cb, f32x4* acc) {
-    const size_t o = (size_t)qi * C + cb;
-    f32x4 g = ld4(gy + o);
-    if (act != LHG_ACT_NONE) {
-      const f32x4 yy = ld4(y + o);
-#pragma unroll
-      for (int e = 0; e < 4; ++e) g[e] *= act_grad_from_output(yy[e], act, slope);
-    }
-    const f32x4 q = ld4(ggx + o);
-    const f32x4 xc = ld4(x + o) - ld4(stats + cb);
-    acc[0] += g;
-    acc[1] += g * xc;
-    acc[2] += q;
-    acc[3] += q * xc;
-    acc[4] += g * q;
-  });
+  column_reduce<5>(
+      pixels, C, lanes_c, rows, partial, [&](int cb) { return ld4(stats + cb); },
+      [&](long long qi, int cb) {
+        const size_t o = (size_t)qi * C + cb;
+        V4 v;
+        v.a = ld4(gy + o);
+        v.b = ld4(ggx + o);
+        v.c = ld4(x + o);
+        if (act != LHG_ACT_NONE) v.d = ld4(y + o);
+        return v;
+      },
+      [&](const V4& v, const f32x4& mean, f32x4* acc) {
+        f32x4 g = v.a;
+        if (act != LHG_ACT_NONE) g *= act_grad4(v.d, act, slope);
+        const f32x4 q = v.b, xc = v.c - mean;
+        acc[0] += g;
+        acc[1] += g * xc;
+        acc[2] += q;
+        acc[3] += q * xc;
+        acc[4] += g * q;
+      });
 }
 
 template <class T>
@@ -239,7 +299,7 @@ __global__ __launch_bounds__(256) void bn_bwd2_apply(const T* __restrict__ ggx, 
                                                      int lanes_c, int rows) {
   const int tx = threadIdx.x % lanes_c, ty = threadIdx.x / lanes_c;
   const float invM = 1.f / (float)pixels;
-  for (int cb = tx * 4; cb < C; cb += lanes_c * 4) {
+  for (int cb = (blockIdx.y * lanes_c + tx) * 4; cb < C; cb += gridDim.y * lanes_c * 4) {
     const f32x4 mean = ld4(stats + cb), r = ld4(stats + C + cb), gam = ld4(gamma + cb);
     const f32x4 Sg = ld4(sums + cb), Sgx = ld4(sums + C + cb), Sq = ld4(sums + 2 * C + cb), Sqx = ld4(sums + 3 * C + cb),
                 Sgq = ld4(sums + 4 * C + cb);
@@ -247,20 +307,28 @@ __global__ __launch_bounds__(256) void bn_bwd2_apply(const T* __restrict__ ggx, 
     const f32x4 all_sub = Sq * Sg * invM - Sgq + r2 * Sgx * Sqx * (3.f * invM);
     if (blockIdx.x == 0 && ty == 0 && ggamma2) st4(ggamma2 + cb, r * (Sgq - Sq * Sg * invM - r2 * Sgx * Sqx * invM));
     const f32x4 kI = gam * r3 * invM, kO = gam * r;
-    for (long long qi = (long long)blockIdx.x * rows + ty; qi < pixels; qi += (long long)gridDim.x * rows) {
-      const size_t o = (size_t)qi * C + cb;
-      f32x4 g = ld4(gy + o), m = {1.f, 1.f, 1.f, 1.f};
-      if (act != LHG_ACT_NONE) {
-        const f32x4 yy = ld4(y + o);
-#pragma unroll
-        for (int e = 0; e < 4; ++e) m[e] = act_grad_from_output(yy[e], act, slope);
-        g *= m;
-      }
-      const f32x4 q = ld4(ggx + o);
-      const f32x4 xc = ld4(x + o) - mean;
-      st4(gx2 + o, kI * (xc * all_sub + Sqx * (Sg * invM - g) + Sgx * (Sq * invM - q)));
-      st4(ggy + o, m * kO * (q - Sq * invM - xc * r2 * Sqx * invM));
-    }
+    pixel_loop(
+        (long long)blockIdx.x * rows + ty, pixels, (long long)gridDim.x * rows,
+        [&](long long qi) {
+          const size_t o = (size_t)qi * C + cb;
+          V4 v;
+          v.a = ld4(gy + o);
+          v.b = ld4(ggx + o);
+          v.c = ld4(x + o);
+          if (act != LHG_ACT_NONE) v.d = ld4(y + o);
+          return v;
+        },
+        [&](long long qi, const V4& v) {
+          const size_t o = (size_t)qi * C + cb;
+          f32x4 g = v.a, m = {1.f, 1.f, 1.f, 1.f};
+          if (act != LHG_ACT_NONE) {
+            m = act_grad4(v.d, act, slope);
+            g *= m;
+          }
+          const f32x4 q = v.b, xc = v.c - mean;
+          st4(gx2 + o, kI * (xc * all_sub + Sqx * (Sg * invM - g) + Sgx * (Sq * invM - q)));
+          st4(ggy + o, m * kO * (q - Sq * invM - xc * r2 * Sqx * invM));
+        });
   }
 }
 
@@ -268,7 +336,9 @@ __global__ __launch_bounds__(256) void bn_bwd2_apply(const T* __restrict__ ggx, 
 template <class T>
 __global__ __launch_bounds__(256) void channel_sum_partial(const T* __restrict__ x, long long pixels, int C, int ld, int lanes_c, int rows,
                                                            float* __restrict__ partial) {
-  column_reduce<1>(pixels, C, lanes_c, rows, partial, [&](long long q, int cb, f32x4* acc) { acc[0] += ld4(x + (size_t)q * ld + cb); });
+  column_reduce<1>(
+      pixels, C, lanes_c, rows, partial, [&](int) { return 0; }, [&](long long q, int cb) { return V1{ld4(x + (size_t)q * ld + cb)}; },
+      [&](const V1& v, int, f32x4* acc) { acc[0] += v.a; });
 }
 
 // ------------------------------------------------------------------ layout
@@ -393,7 +463,9 @@ static inline int grid_for(size_t work_items, int per_block = 256, int cap = 409
 
 // Column reductions are latency-bound streaming kernels: ~8 resident workgroups per CU (2048 blocks) keep enough
 // loads in flight to approach the HBM rate; 512 blocks measured only ~1.6 TB/s.
-static inline int partial_blocks(long long pixels) { return (int)std::min<long long>(2048, std::max<long long>(1, pixels / 64)); }
+static inline int partial_blocks(long long pixels, int gy = 1) {
+  return (int)std::min<long long>(std::max(1, 2048 / gy), std::max<long long>(1, pixels / 64));
+}
 
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
@@ -437,8 +509,8 @@ template <class T>
 static int channel_sum_impl(const float* x, long long pixels, int C, int ld, float* out, int accumulate, float* ws, lhg_stream_t s) {
   LHG_NHWC_OK(x, C, ld, "channel_sum");
   const ColMap cm = col_map(C);
-  const int nblk = partial_blocks(pixels);
-  hipLaunchKernelGGL((channel_sum_partial<T>), dim3(nblk), dim3(256), 0, as_stream(s), as_act<T>(x), pixels, C, ld, cm.lanes_c, cm.rows, ws);
+  const int nblk = partial_blocks(pixels, cm.gy);
+  hipLaunchKernelGGL((channel_sum_partial<T>), dim3(nblk, cm.gy), dim3(256), 0, as_stream(s), as_act<T>(x), pixels, C, ld, cm.lanes_c, cm.rows, ws);
   hipLaunchKernelGGL(reduce_partials<1>, dim3((C + 31) / 32, 1), dim3(1024), 0, as_stream(s), ws, nblk, C, out, accumulate);
   return check_launch("channel_sum");
 }
@@ -449,8 +521,8 @@ static int bn_stats_impl(const float* x, long long pixels, int C, int ld, float*
   LHG_NHWC_OK(x, C, ld, "bn_stats");
   LHG_REQUIRE(pixels > 0, "bn_stats: empty tensor");
   const ColMap cm = col_map(C);
-  const int nblk = partial_blocks(pixels);
-  hipLaunchKernelGGL((bn_stats_partial<T>), dim3(nblk), dim3(256), 0, as_stream(s), as_act<T>(x), pixels, C, ld, cm.lanes_c, cm.rows, ws);
+  const int nblk = partial_blocks(pixels, cm.gy);
+  hipLaunchKernelGGL((bn_stats_partial<T>), dim3(nblk, cm.gy), dim3(256), 0, as_stream(s), as_act<T>(x), pixels, C, ld, cm.lanes_c, cm.rows, ws);
   float* sums = ws + (size_t)nblk * 2 * C;
   hipLaunchKernelGGL(reduce_partials<2>, dim3((C + 31) / 32, 2), dim3(1024), 0, as_stream(s), ws, nblk, C, sums, 0);
   hipLaunchKernelGGL((bn_stats_final<T>), dim3((C + 255) / 256), dim3(256), 0, as_stream(s), sums, as_act<T>(x), pixels, C, stats, running_mean,
@@ -465,8 +537,8 @@ static int bn_apply_impl(const float* x, int ldx, long long pixels, int C, const
   LHG_NHWC_OK(y, C, ldy, "bn_apply(y)");
   if (res) LHG_NHWC_OK(res, C, ldres, "bn_apply(res)");
   const ColMap cm = col_map(C);
-  const int nblk = grid_for((size_t)pixels, cm.rows * 4, 4096);
-  hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(nblk), dim3(256), 0, as_stream(s), as_act<T>(x), ldx, pixels, C, stats, gamma, beta, as_act<T>(res),
+  const int nblk = grid_for((size_t)pixels, cm.rows * 4, std::max(1, 4096 / cm.gy));
+  hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(nblk, cm.gy), dim3(256), 0, as_stream(s), as_act<T>(x), ldx, pixels, C, stats, gamma, beta, as_act<T>(res),
                      ldres, act, slope, as_act<T>(y), ldy, cm.lanes_c, cm.rows);
   return check_launch("bn_apply");
 }
@@ -481,13 +553,13 @@ static int bn_backward_impl(const float* gy, int ldgy, const float* x, int ldx, 
   if (act != LHG_ACT_NONE) LHG_NHWC_OK(y, C, ldy, "bn_backward(y)");
   if (gres) LHG_NHWC_OK(gres, C, ldgres, "bn_backward(gres)");
   const ColMap cm = col_map(C);
-  const int nblk = partial_blocks(pixels);
+  const int nblk = partial_blocks(pixels, cm.gy);
   float* sums = ws + (size_t)nblk * 2 * C;
-  hipLaunchKernelGGL((bn_bwd_partial<T>), dim3(nblk), dim3(256), 0, as_stream(s), as_act<T>(gy), ldgy, as_act<T>(x), ldx, as_act<T>(y), ldy, pixels, C,
+  hipLaunchKernelGGL((bn_bwd_partial<T>), dim3(nblk, cm.gy), dim3(256), 0, as_stream(s), as_act<T>(gy), ldgy, as_act<T>(x), ldx, as_act<T>(y), ldy, pixels, C,
                      stats, act, slope, cm.lanes_c, cm.rows, ws);
   hipLaunchKernelGGL(reduce_partials<2>, dim3((C + 31) / 32, 2), dim3(1024), 0, as_stream(s), ws, nblk, C, sums, 0);
-  const int nb2 = grid_for((size_t)pixels, cm.rows * 4, 4096);
-  hipLaunchKernelGGL((bn_bwd_apply<T>), dim3(nb2), dim3(256), 0, as_stream(s), as_act<T>(gy), ldgy, as_act<T>(x), ldx, as_act<T>(y), ldy, pixels, C, stats,
+  const int nb2 = grid_for((size_t)pixels, cm.rows * 4, std::max(1, 4096 / cm.gy));
+  hipLaunchKernelGGL((bn_bwd_apply<T>), dim3(nb2, cm.gy), dim3(256), 0, as_stream(s), as_act<T>(gy), ldgy, as_act<T>(x), ldx, as_act<T>(y), ldy, pixels, C, stats,
                      gamma, sums, act, slope, as_act<T>(gx), ldgx, as_act<T>(gres), ldgres, ggamma, gbeta, accumulate, cm.lanes_c, cm.rows);
   return check_launch("bn_backward");
 }
@@ -499,13 +571,13 @@ static int bn_backward_backward_impl(const float* ggx, const float* gy, const fl
   LHG_NHWC_OK(ggx, C, C, "bn_backward_backward(ggx)");
   LHG_REQUIRE(aligned16(gy) && aligned16(x) && aligned16(ggy) && aligned16(gx2), "bn_backward_backward: unaligned tensor");
   const ColMap cm = col_map(C);
-  const int nblk = partial_blocks(pixels);
+  const int nblk = partial_blocks(pixels, cm.gy);
   float* sums = ws + (size_t)nblk * 5 * C;
-  hipLaunchKernelGGL((bn_bwd2_partial<T>), dim3(nblk), dim3(256), 0, as_stream(s), as_act<T>(ggx), as_act<T>(gy), as_act<T>(x), as_act<T>(y), pixels, C,
+  hipLaunchKernelGGL((bn_bwd2_partial<T>), dim3(nblk, cm.gy), dim3(256), 0, as_stream(s), as_act<T>(ggx), as_act<T>(gy), as_act<T>(x), as_act<T>(y), pixels, C,
                      stats, act, slope, cm.lanes_c, cm.rows, ws);
   hipLaunchKernelGGL(reduce_partials<5>, dim3((C + 31) / 32, 5), dim3(1024), 0, as_stream(s), ws, nblk, C, sums, 0);
-  const int nb2 = grid_for((size_t)pixels, cm.rows * 4, 4096);
-  hipLaunchKernelGGL((bn_bwd2_apply<T>), dim3(nb2), dim3(256), 0, as_stream(s), as_act<T>(ggx), as_act<T>(gy), as_act<T>(x), as_act<T>(y), pixels, C, stats,
+  const int nb2 = grid_for((size_t)pixels, cm.rows * 4, std::max(1, 4096 / cm.gy));
+  hipLaunchKernelGGL((bn_bwd2_apply<T>), dim3(nb2, cm.gy), dim3(256), 0, as_stream(s), as_act<T>(ggx), as_act<T>(gy), as_act<T>(x), as_act<T>(y), pixels, C, stats,
                      gamma, sums, act, slope, as_act<T>(ggy), as_act<T>(gx2), ggamma2, cm.lanes_c, cm.rows);
   return check_launch("bn_backward_backward");
 }
