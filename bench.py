@@ -217,22 +217,26 @@ def main():
     peak_note = ("dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)" if products is None else
                  f"dense bf16 MFMA peak {BF16_MFMA_PEAK_TFLOPS:.0f} TFLOP/s / {products} bf16 product(s) per multiply-add of the '{mode}' formulation"
                  + ("" if bf16 else f"; the exact-fp32 MFMA formulation peaks at {FP32_MFMA_PEAK_TFLOPS}"))
-    stack = torch.linspace(-4e-4, 0.0, 21)[:-1]  # trainingModel.py:62
-    perceptual = None
-    if args.perceptual > 0:
-        import warnings
+    def build_trainer():
+        stack = torch.linspace(-4e-4, 0.0, 21)[:-1]  # trainingModel.py:62
+        perceptual = None
+        if args.perceptual > 0:
+            import warnings
 
-        from learned_hologram_gan_amd.watermelon_hologram.perceptual import perceptualLoss
+            from learned_hologram_gan_amd.watermelon_hologram.perceptual import perceptualLoss
 
-        with warnings.catch_warnings():
-            warnings.simplefilter("ignore")
-            perceptual = perceptualLoss()
-    W = watermelon(filter_radius_coefficient=0.45, pad_size=args.pad, distance_stack=stack, input_shape=(1, 4, args.rows, args.cols),
-                   perceptual_loss=perceptual)
-    W.generator.to(dev).train()
-    W.discriminator.to(dev).train()
-    W.configure(phs_gradient_loss_weight=1, perceptual_loss_weight=args.perceptual, pixel_loss_weight=1, TV_loss_weight=1e-3,
-                discriminator_loss_weight=1e-1, lr_G=1e-3, lr_D=1e-3, discriminator_train_ratio=args.d_ratio, discriminator_lambda=10)
+            with warnings.catch_warnings():
+                warnings.simplefilter("ignore")
+                perceptual = perceptualLoss()
+        T = watermelon(filter_radius_coefficient=0.45, pad_size=args.pad, distance_stack=stack, input_shape=(1, 4, args.rows, args.cols),
+                       perceptual_loss=perceptual)
+        T.generator.to(dev).train()
+        T.discriminator.to(dev).train()
+        T.configure(phs_gradient_loss_weight=1, perceptual_loss_weight=args.perceptual, pixel_loss_weight=1, TV_loss_weight=1e-3,
+                    discriminator_loss_weight=1e-1, lr_G=1e-3, lr_D=1e-3, discriminator_train_ratio=args.d_ratio, discriminator_lambda=10)
+        return T
+
+    W = build_trainer()
     g = torch.Generator().manual_seed(122731 + rank)
     B = args.batch
     rgbd = torch.rand((B, 4, args.rows, args.cols), generator=g).to(dev)
@@ -372,9 +376,27 @@ def main():
             sync()
             other[name] = round((time.perf_counter() - t0) / 4 * 1e3, 3)
         hip_ops.set_conv_precision(mode)
+        # bf16 NHWC activation storage (what `--dtype bf16` measures): a fresh trainer, the mode is process-wide
+        del W
+        torch.cuda.empty_cache()
+        hip_ops.set_conv_precision("default")
+        hip_ops.set_activation_storage("bf16")
+        W = build_trainer()
+        for _ in range(3):
+            W.train_step(rgbd, tamp, tphs)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(6):
+            W.train_step(rgbd, tamp, tphs)
+        sync()
+        other["bf16_storage"] = round((time.perf_counter() - t0) / 6 * 1e3, 3)
+        hip_ops.set_activation_storage("fp32")
+        if args.precision != "default":
+            hip_ops.set_conv_precision(args.precision)
     if rank == 0 and other:
         out["other_modes_ms_per_step"] = dict(other, note="fp32: exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  fp32_split2: two bf16 terms per operand, "
-                                              "three MFMA products (max-rel error ~5e-6 per op instead of ~1e-6: NOT the headline mode)")
+                                              "three MFMA products (max-rel error ~5e-6 per op instead of ~1e-6).  bf16_storage: bf16 NHWC activations "
+                                              "and bf16 GEMM operands, fp32 accumulation/BN statistics/FFT/Adam (`--dtype bf16`).  None is the headline mode")
 
     # ---- free the trainer, then north_star's second target (4K bs=1 inference + 8 planes), replicas only
     sec = None
