@@ -66,7 +66,7 @@ def parse():
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
                     help="f32 (the benchmark metric): exact fp32 MFMA.  bf16 (BASELINE configs[2]/[4], informational): bf16 conv-GEMM operands, "
                          "fp32 accumulation")
-    ap.add_argument("--precision", choices=("default", "fp32", "fp32_split", "fp32_split2", "bf16"), default="default",
+    ap.add_argument("--precision", choices=("default", "fp32", "fp32_split", "fp32_split2", "fp32_split_f16", "bf16"), default="default",
                     help="conv-GEMM arithmetic (hip_ops.set_conv_precision); default: fp32 tensors with the library's default fp32 GEMM mode, "
                          "or bf16 with --dtype bf16")
     ap.add_argument("--perceptual", type=float, default=0.0,
@@ -212,10 +212,10 @@ def main():
     bf16 = args.dtype == "bf16"
     mode = hip_ops.conv_precision()
     # the matrix roofline of the GEMM formulation in use: algorithmic (fp32 multiply-add) TFLOP/s it can reach at most
-    products = {"fp32": None, "fp32_split": 6, "fp32_split2": 3, "bf16": 1}[mode]
+    products = {"fp32": None, "fp32_split": 6, "fp32_split2": 3, "fp32_split_f16": 3, "bf16": 1}[mode]
     mfma_peak = FP32_MFMA_PEAK_TFLOPS if products is None else round(BF16_MFMA_PEAK_TFLOPS / products, 1)
     peak_note = ("dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)" if products is None else
-                 f"dense bf16 MFMA peak {BF16_MFMA_PEAK_TFLOPS:.0f} TFLOP/s / {products} bf16 product(s) per multiply-add of the '{mode}' formulation"
+                 f"dense 16-bit MFMA peak {BF16_MFMA_PEAK_TFLOPS:.0f} TFLOP/s (bf16 and fp16 alike) / {products} product(s) per multiply-add of the '{mode}' formulation"
                  + ("" if bf16 else f"; the exact-fp32 MFMA formulation peaks at {FP32_MFMA_PEAK_TFLOPS}"))
     def build_trainer():
         stack = torch.linspace(-4e-4, 0.0, 21)[:-1]  # trainingModel.py:62
@@ -325,6 +325,8 @@ def main():
                   "fp32_split": "lhg::gg3s_kernel (gather-GEMM on the bf16 matrix pipe, fp32-faithful: operands as exact sums of three bf16 terms, "
                                 "six MFMA products per multiply, fp32 accumulation)",
                   "fp32_split2": "lhg::gg3s_kernel (two bf16 terms, three MFMA products per multiply)",
+                  "fp32_split_f16": "lhg::gg3s_kernel (gather-GEMM on the fp16 matrix pipe, fp32-faithful: tensor-scaled operands as sums of two "
+                                    "fp16 terms, three MFMA products per multiply, fp32 accumulation)",
                   "bf16": "lhg::gg2b_kernel / gg3s_kernel (bf16 MFMA gather-GEMM)"}[mode]
         r = {"kernel": kernel + ": conv forward / input-gradient / conv-transpose", "bound": "mfma", "peak": mfma_peak, "peak_note": peak_note,
              "unit": "TFLOP/s", "traffic": traffic, "traffic_source": traffic_src}
@@ -363,7 +365,7 @@ def main():
     # ---- the same step with the other fp32-tensor GEMM formulations (informational; a few steps each, every rank: collectives inside)
     other = {}
     if args.mode == "train" and not bf16 and args.other_modes:
-        for name in ("fp32", "fp32_split2"):
+        for name in ("fp32", "fp32_split", "fp32_split2"):
             if name == mode:
                 continue
             hip_ops.set_conv_precision(name)
@@ -382,19 +384,20 @@ def main():
         hip_ops.set_conv_precision("default")
         hip_ops.set_activation_storage("bf16")
         W = build_trainer()
-        for _ in range(3):
+        for _ in range(12):  # the first ~10 steps after the switch are slower (allocator pool of the new tensor sizes, autotune)
             W.train_step(rgbd, tamp, tphs)
         sync()
         t0 = time.perf_counter()
-        for _ in range(6):
+        for _ in range(8):
             W.train_step(rgbd, tamp, tphs)
         sync()
-        other["bf16_storage"] = round((time.perf_counter() - t0) / 6 * 1e3, 3)
+        other["bf16_storage"] = round((time.perf_counter() - t0) / 8 * 1e3, 3)
         hip_ops.set_activation_storage("fp32")
         if args.precision != "default":
             hip_ops.set_conv_precision(args.precision)
     if rank == 0 and other:
-        out["other_modes_ms_per_step"] = dict(other, note="fp32: exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  fp32_split2: two bf16 terms per operand, "
+        out["other_modes_ms_per_step"] = dict(other, note="fp32: exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  fp32_split: three bf16 terms per operand, six MFMA products "
+                                              "(round 2's first fp32-faithful formulation).  fp32_split2: two bf16 terms per operand, "
                                               "three MFMA products (max-rel error ~5e-6 per op instead of ~1e-6).  bf16_storage: bf16 NHWC activations "
                                               "and bf16 GEMM operands, fp32 accumulation/BN statistics/FFT/Adam (`--dtype bf16`).  None is the headline mode")
 

@@ -11,9 +11,11 @@
  *   - plain C: raw DEVICE pointers, ints, floats and a hipStream_t (passed as void*);
  *     no torch types.  The library never allocates or frees: every workspace is passed
  *     in, every launch goes to `stream`.  It synchronises in ONE place: the first launch
- *     of a GEMM geometry it has not seen times its tiling variants with HIP events on
- *     `stream` (lhg_autotune(0) / LHG_AUTOTUNE=0 turns that off; it is skipped while the
- *     stream is being captured, so warm the geometries up before capturing a graph).
+ *     of a GEMM geometry it has not seen drains the device (hipDeviceSynchronize) and times
+ *     its tiling variants, five launches each, with HIP events on `stream`
+ *     (lhg_autotune(0) / LHG_AUTOTUNE=0 turns that off; it is skipped while the stream is
+ *     being captured, so warm the geometries up before capturing a graph).  With
+ *     LHG_TUNE_CACHE=<file> the choices are appended to that file and reused by later processes.
  *   - threading: the mode switches, the autotune cache, the profiling timers and the
  *     last-error text are process-global and not locked.  One host thread per process
  *     calls the library, as in the reference (single-threaded, DataLoader(num_workers=0)).
@@ -36,7 +38,7 @@
 extern "C" {
 #endif
 
-#define LHG_ABI_VERSION 2
+#define LHG_ABI_VERSION 3
 
 enum {
   LHG_OK = 0,
@@ -46,7 +48,7 @@ enum {
 };
 
 enum { LHG_ACT_NONE = 0, LHG_ACT_RELU = 1, LHG_ACT_LEAKY = 2, LHG_ACT_SIGMOID = 3 };
-enum { LHG_PRECISION_F32 = 0, LHG_PRECISION_BF16 = 1, LHG_PRECISION_F32_SPLIT = 2, LHG_PRECISION_F32_SPLIT2 = 3 };
+enum { LHG_PRECISION_F32 = 0, LHG_PRECISION_BF16 = 1, LHG_PRECISION_F32_SPLIT = 2, LHG_PRECISION_F32_SPLIT2 = 3, LHG_PRECISION_F32_SPLIT_F16 = 4 };
 
 enum { LHG_DTYPE_F32 = 0, LHG_DTYPE_BF16 = 1 };
 
@@ -59,8 +61,10 @@ const char* lhg_last_error(void);
  * events recorded on the launch stream; used by bench.py for the roofline figures.  lhg_profile_read
  * synchronises the recorded events and returns the summed duration, the launch count and the executed
  * (padded-tile) flops since the last enable. */
-/* The GEMM launcher times its tiling variants once per new geometry (HIP events on the caller's stream, skipped
- * while the stream is being captured) and caches the fastest; every variant gives identical values.
+/* The GEMM launcher times its tiling variants once per new geometry (idle device, five launches per variant between
+ * HIP events on the caller's stream, skipped while the stream is being captured) and caches the fastest — in the
+ * process, and in the file LHG_TUNE_CACHE names if set; every variant gives identical values.
+ * With LHG_PROFILE_LOG=<file>, lhg_profile_read also appends one CSV line per timed launch (geometry, variant, flops, ms).
  * lhg_autotune(0) turns this off (a fixed heuristic is used instead); env LHG_AUTOTUNE=0 does the same. */
 int lhg_autotune(int on);
 int lhg_profile_enable(int kernel, int on);
@@ -92,14 +96,28 @@ int lhg_nhwc_to_nchw(const float* src, int ld, float* dst, int N, int C, int H, 
  * dropped ones are below 2^-24 |a b|), accumulated in fp32: 6/16 of the exact kernel's matrix time, results within a few fp32 ulps
  * of the accumulated sum of the exact kernel.  Applies to the gather-GEMM and to the weight-gradient GEMMs; lhg_pack_weight writes
  * split panels of lhg_packed_weight_floats() floats.  LHG_PRECISION_F32_SPLIT2 keeps two terms (three products, ~2^-16 relative):
- * for measurements only. */
+ * for measurements only.
+ *
+ * LHG_PRECISION_F32_SPLIT_F16: fp32 tensors, fp32-faithful results from TWO fp16 terms per operand and THREE products.  fp16 holds
+ * 11 significand bits: x*s = h0 + h1 + e with |e| <= 2^-23 |x*s|, and a0*b0 + a0*b1 + a1*b0 misses a*b by ~2^-23 |a b| — inside
+ * the rounding of the fp32 accumulation it is summed into (measured against float64: the same error as the exact fp32 kernels) —
+ * at half the matrix work of LHG_PRECISION_F32_SPLIT.  fp16's 5-bit exponent needs a power-of-two scale s per tensor,
+ * s = 2^(14 - floor(log2 max|x|)): the caller measures max|x| of each activation operand with lhg_absmax and passes the device
+ * pointer (`*_absmax` arguments below, ignored in every other mode); lhg_pack_weight measures max|w| itself and keeps it behind
+ * the panels.  Elements down to 2^-18 max|x| keep the full relative accuracy, smaller ones an absolute error below 2^-39 max|x|.
+ * A non-finite maximum leaves the tensor unscaled (non-finite values then propagate as they do in fp32). */
 int lhg_set_conv_precision(int precision);
 int lhg_get_conv_precision(void);
-/* the mode the library starts in: LHG_PRECISION_F32_SPLIT unless the environment variable LHG_CONV_PRECISION
- * (fp32 | fp32_split | fp32_split2 | bf16) names another one */
+/* the mode the library starts in: LHG_PRECISION_F32_SPLIT_F16 unless the environment variable LHG_CONV_PRECISION
+ * (fp32 | fp32_split | fp32_split2 | fp32_split_f16 | bf16) names another one */
 int lhg_default_conv_precision(void);
 /* floats the caller must allocate for lhg_pack_weight's `dst` in the current precision mode */
 long long lhg_packed_weight_floats(int taps, int rows_pad, int k_pad);
+/* *out = max(*out, max |x|) over the first C of ld channels of `pixels` pixels (fp32 tensors; stream-ordered, no host
+ * synchronisation).  The caller zero-fills `out` first (one fill can prepare many slots); several calls on one slot give the
+ * maximum over several tensors.  The tensor-scale input of LHG_PRECISION_F32_SPLIT_F16: measure each GEMM operand once and pass
+ * `out` as its `*_absmax`; any upper bound of max|x| is valid, a loose one only narrows the window of full relative accuracy. */
+int lhg_absmax(const float* x, long long pixels, int C, int ld, float* out, lhg_stream_t s);
 
 /* Pack a PyTorch 4-D weight w[D0][D1][KH][KW] into GEMM panels dst[KH*KW][rows_pad][k_pad],
  * K contiguous, zero padded.  rows_from_d0 = 1: rows = D0, K = D1 (Conv2d forward,
@@ -113,7 +131,9 @@ int lhg_pack_weight(const float* w, int D0, int D1, int KH, int KW, int rows_fro
  * One implicit-GEMM engine (MFMA v_mfma_f32_32x32x2_f32, LDS-tiled, no im2col buffer).
  * `wp` is a packed panel set from lhg_pack_weight.  Epilogue, in this order:
  *   v = acc + bias[c];  v = v*scale[c] + shift[c];  v += res[pixel][c];  v = act(v)
- * (each pointer may be NULL).  planar_out != 0 stores NCHW instead of NHWC.            */
+ * (each pointer may be NULL).  planar_out != 0 stores NCHW instead of NHWC.
+ * `x_absmax` / `gy_absmax`: device pointer to max|.| of that operand (lhg_absmax), required in the
+ * LHG_PRECISION_F32_SPLIT_F16 mode, ignored (may be NULL) in every other.                          */
 
 /* y = conv2d(x, W, stride, padding=KH/2).  ref: neural_network_components.py:27-30
  * (3x3 s1, 1x1), discriminator.py:34-38 (3x3 s1/s2), :25 (1024->1 head). */
@@ -122,21 +142,22 @@ int lhg_conv2d_forward(const float* x, int N, int H, int W, int Ci, int ldx,
                        float* y, int Co, int ldy,
                        const float* bias, const float* scale, const float* shift,
                        const float* res, int ldres, int act, float slope, int planar_out,
-                       lhg_stream_t s);
+                       const float* x_absmax, lhg_stream_t s);
 
 /* gx = conv2d_backward_input(gy, W).  (H, W) are the INPUT extents of the forward conv.
  * `wp` packed with rows_from_d0 = 0.  Replaces the autograd node of the call sites above;
  * also the "double backward w.r.t. gy" of lhg_conv2d_forward.  ref: watermelon.py:466-473. */
 int lhg_conv2d_backward_input(const float* gy, int N, int H, int W, int Co, int ldgy,
                               const float* wp, int rows_pad, int KH, int KW, int stride,
-                              float* gx, int Ci, int ldgx, lhg_stream_t s);
+                              float* gx, int Ci, int ldgx, const float* gy_absmax, lhg_stream_t s);
 
 /* Partial weight gradients: slabs[S][KH*KW][ci_pad][co_pad] (S = split count chosen by
  * lhg_conv2d_wgrad_splits), to be summed by lhg_wgrad_reduce. */
 int lhg_conv2d_wgrad_splits(int N, int H, int W, int Ci, int Co, int KH, int KW, int stride);
 int lhg_conv2d_backward_weight(const float* x, int N, int H, int W, int Ci, int ldx,
                                const float* gy, int Co, int ldgy, int KH, int KW, int stride,
-                               float* slabs, int S, int ci_pad, int co_pad, lhg_stream_t s);
+                               float* slabs, int S, int ci_pad, int co_pad,
+                               const float* x_absmax, const float* gy_absmax, lhg_stream_t s);
 
 /* ---- thin convolutions: 3x3 (pad 1) or 1x1, stride 1, where one side has very few channels — the RGBD / RGB inputs
  * (4 -> 64 neural_network_components.py:244-249, 3 -> 32 discriminator.py:16-19), the 64 -> 6 head (:288-291) and the
@@ -160,14 +181,15 @@ int lhg_conv2d_thin_backward_weight(const float* x, int N, int H, int W, int Ci,
 /* y = conv_transpose2d(x, W, kernel 2, stride 2).  ref: neural_network_components.py:270-286. */
 int lhg_conv_transpose2x2_forward(const float* x, int N, int H, int W, int Ci, int ldx,
                                   const float* wp, int rows_pad, float* y, int Co, int ldy,
-                                  const float* bias, lhg_stream_t s);
+                                  const float* bias, const float* x_absmax, lhg_stream_t s);
 int lhg_conv_transpose2x2_backward_input(const float* gy, int N, int H, int W, int Co, int ldgy,
                                          const float* wp, int rows_pad, float* gx, int Ci, int ldgx,
-                                         lhg_stream_t s);
+                                         const float* gy_absmax, lhg_stream_t s);
 int lhg_conv_transpose2x2_wgrad_splits(int N, int H, int W, int Ci, int Co);
 int lhg_conv_transpose2x2_backward_weight(const float* x, int N, int H, int W, int Ci, int ldx,
                                           const float* gy, int Co, int ldgy,
-                                          float* slabs, int S, int ci_pad, int co_pad, lhg_stream_t s);
+                                          float* slabs, int S, int ci_pad, int co_pad,
+                               const float* x_absmax, const float* gy_absmax, lhg_stream_t s);
 
 /* grad[D0][D1][KH][KW] (+)= sum_s slabs[s][t][m][n]  (m = conv-input channel, n = conv-output
  * channel).  m_is_d1 = 1 for Conv2d (OIHW: D0 = n, D1 = m), 0 for ConvTranspose2d (IOHW).

@@ -27,6 +27,7 @@
 #include <cstdlib>
 #include <map>
 #include <string>
+#include <type_traits>
 #include <utility>
 #include <vector>
 
@@ -57,6 +58,8 @@ struct GGParams {
   int ldres, rows_pad, act, planar_out;
   float slope;
   int xcd;  // 1: XCD-contiguous tile order (xcd_contiguous)
+  const float* a_amax;  // fp16-split mode: max|in| over the gathered tensor (device, lhg_absmax) and max|w| (behind the weight panels)
+  const float* w_amax;
   int prio; // gg3s_kernel: 0 no s_setprio, 1 consumers (MFMA waves) raised, 2 producers (load / split waves) raised
 };
 
@@ -67,6 +70,8 @@ struct WGParams {
   float* slabs;       // [S][Tslabs][m_pad][n_pad]
   int m_pad, n_pad, Tslabs, kchunk;  // kchunk: pixels per split (multiple of 32)
   int xcd;
+  const float* in_amax;    // fp16-split mode: max|in|, max|gout| (device, lhg_absmax)
+  const float* gout_amax;
 };
 
 // Workgroups are dealt round-robin over the 8 XCDs (linear id % 8 labels the XCD group), each XCD with a private 4 MiB L2.
@@ -367,12 +372,14 @@ __global__ void pack_weight_bf16_kernel(const float* __restrict__ w, int D0, int
   }
 }
 
-// Split panels for gg3s_kernel: dst[t][row][k chunk][plane][32 k] bf16, plane q of w = q-th term of the exact bf16 expansion.
-template <int NP>
+// Split panels for gg3s_kernel: dst[t][row][k chunk][plane][32 k], plane q of w = q-th term of the exact bf16 expansion, or (TE =
+// _Float16) of the fp16 expansion of w * 2^k with k from *amax = max|w| (split_scale, gg3s_kernel.inc).
+template <int NP, class TE>
 __global__ void pack_weight_split_kernel(const float* __restrict__ w, int D0, int D1, int T, int rows_from_d0,
-                                         __bf16* __restrict__ dst, int rows_pad, int k_pad) {
+                                         TE* __restrict__ dst, int rows_pad, int k_pad, const float* __restrict__ amax) {
   const size_t total = (size_t)T * rows_pad * k_pad;
   const int kch = k_pad / 32;
+  const float sc = std::is_same<TE, _Float16>::value ? split_scale(*amax) : 1.f;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
     const int k = (int)(i % k_pad);
     const int row = (int)((i / k_pad) % rows_pad);
@@ -381,16 +388,66 @@ __global__ void pack_weight_split_kernel(const float* __restrict__ w, int D0, in
     float v = 0.f;
     if (row < rows && k < K) {
       const int d0 = rows_from_d0 ? row : k, d1 = rows_from_d0 ? k : row;
-      v = w[((size_t)d0 * D1 + d1) * T + t];
+      v = w[((size_t)d0 * D1 + d1) * T + t] * sc;
     }
-    __bf16* out = dst + ((((size_t)t * rows_pad + row) * kch + k / 32) * NP) * 32 + (k & 31);
+    TE* out = dst + ((((size_t)t * rows_pad + row) * kch + k / 32) * NP) * 32 + (k & 31);
 #pragma unroll
     for (int q = 0; q < NP; ++q) {
-      const __bf16 h = (__bf16)v;  // round to nearest even
+      const TE h = (TE)v;  // round to nearest even
       out[q * 32] = h;
-      v -= (float)h;               // exact
+      v -= (float)h;       // exact
     }
   }
+}
+
+// max |x| over an NHWC slice (pixels x C, row stride ld) as an unsigned compare of the magnitude bits (NaN > inf > finite, so a
+// non-finite tensor yields a non-finite maximum); *out must be zero before the launch.
+__global__ __launch_bounds__(256) void absmax_kernel(const float* __restrict__ x, long long pixels, int C, int ld, unsigned* __restrict__ out) {
+  unsigned m = 0;
+  const bool vec = (C % 4 == 0) && (ld % 4 == 0) && ((reinterpret_cast<uintptr_t>(x) & 15) == 0);
+  const long long stride = (long long)gridDim.x * blockDim.x, first = blockIdx.x * (long long)blockDim.x + threadIdx.x;
+  if (vec) {
+    const int C4 = C / 4;
+    const long long total = pixels * C4;
+    auto at = [&](long long i) {
+      const long long q = i / C4;
+      return *reinterpret_cast<const u32x4*>(x + q * ld + (int)(i - q * C4) * 4);
+    };
+    auto fold = [&](u32x4 v) { m = max(max(m, v[0] & 0x7fffffffu), max(v[1] & 0x7fffffffu, max(v[2] & 0x7fffffffu, v[3] & 0x7fffffffu))); };
+    long long i = first;
+    for (; i + 3 * stride < total; i += 4 * stride) {  // four loads in flight per thread: the pass is bound by memory latency otherwise
+      const u32x4 a = at(i), b = at(i + stride), c = at(i + 2 * stride), d = at(i + 3 * stride);
+      fold(a); fold(b); fold(c); fold(d);
+    }
+    for (; i < total; i += stride) fold(at(i));
+  } else {
+    const long long total = pixels * C;
+    for (long long i = first; i < total; i += stride) {
+      const long long q = i / C;
+      m = max(m, __float_as_uint(x[q * ld + (i - q * C)]) & 0x7fffffffu);
+    }
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+  __shared__ unsigned red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = max(max(red[0], red[1]), max(red[2], red[3]));
+    // one atomic per workgroup, and only when it can raise the running maximum (the unsynchronised read is a filter, not the result)
+    if (m > *reinterpret_cast<volatile unsigned*>(out)) atomicMax(out, m);
+  }
+}
+
+__global__ void zero_word_kernel(unsigned* p) { *p = 0u; }
+
+// *out = max(*out, max|x|): `zero_first` for a fresh measurement into memory of unknown content
+static int launch_absmax(const float* x, long long pixels, int C, int ld, float* out, hipStream_t st, bool zero_first) {
+  if (zero_first) hipLaunchKernelGGL(zero_word_kernel, dim3(1), dim3(1), 0, st, reinterpret_cast<unsigned*>(out));
+  const long long items = pixels * (C % 4 == 0 ? C / 4 : C);
+  const int blocks = (int)std::max<long long>(1, std::min<long long>((items + 255) / 256 / 4, 1024));
+  hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, st, x, pixels, C, ld, reinterpret_cast<unsigned*>(out));
+  return check_launch("absmax");
 }
 
 // grad[d0][d1][t] = sum_s slabs[s][t][m][n].  Block = 64 consecutive outputs (n fastest: coalesced slab reads) x 4 slab
@@ -437,6 +494,7 @@ struct KernelTimer {
   std::vector<std::pair<hipEvent_t, hipEvent_t>> pool;
   size_t used = 0;
   double executed_flops = 0;
+  std::vector<std::string> tags;  // per launch "geometry;variant;flops" (only filled while LHG_PROFILE_LOG names a file)
   std::pair<hipEvent_t, hipEvent_t>& next() {
     if (used == pool.size()) {
       hipEvent_t a, b;
@@ -451,15 +509,59 @@ static KernelTimer g_timer[2];  // 0: gg_kernel, 1: wg_kernel
 static bool g_autotune_enabled = true;
 static std::map<std::array<int, 12>, int> g_gg_choice, g_wg_choice;
 
-// One-time timing of the valid kernel variants for a geometry not seen before (HIP events on `st`: the only place the library
-// synchronises; skipped while the stream is being captured).  Returns the cached / measured winner or -1.
+// One-time timing of the valid kernel variants for a geometry not seen before: the device is drained first (the weight-gradient
+// stream may be busy), then every variant runs once untimed and TUNE_RUNS times between two HIP events on `st`.  The only place the
+// library synchronises; skipped while the stream is being captured.  Returns the cached / measured winner or -1.
+// LHG_TUNE_CACHE=<file>: choices are appended to that file and read back by later processes (one line per geometry, tagged with
+// TUNE_SCHEMA so that a build with a different variant numbering ignores stale lines).
+constexpr int TUNE_RUNS = 5;
+constexpr const char* TUNE_SCHEMA = "lhg-tune-4";
+static void tune_cache_load() {
+  static bool done = false;
+  if (done) return;
+  done = true;
+  const char* path = getenv("LHG_TUNE_CACHE");
+  if (!path) return;
+  FILE* f = fopen(path, "r");
+  if (!f) return;
+  char tag[32], which[8];
+  while (fscanf(f, "%31s %7s", tag, which) == 2) {
+    std::array<int, 12> key;
+    int choice = -1;
+    bool ok = true;
+    for (int i = 0; i < 12; ++i) ok = ok && fscanf(f, "%d", &key[i]) == 1;
+    ok = ok && fscanf(f, "%d", &choice) == 1;
+    if (!ok) break;
+    if (std::string(tag) != TUNE_SCHEMA) continue;
+    (which[0] == 'g' ? g_gg_choice : g_wg_choice)[key] = choice;
+  }
+  fclose(f);
+}
+static void tune_cache_append(bool gg, const std::array<int, 12>& key, int choice) {
+  const char* path = getenv("LHG_TUNE_CACHE");
+  if (!path) return;
+  if (FILE* f = fopen(path, "a")) {
+    fprintf(f, "%s %s", TUNE_SCHEMA, gg ? "gg" : "wg");
+    for (int v : key) fprintf(f, " %d", v);
+    fprintf(f, " %d\n", choice);
+    fclose(f);
+  }
+}
+
 template <class Valid, class Run>
 static int autotuned_variant(std::map<std::array<int, 12>, int>& cache, const std::array<int, 12>& key, int variants, Valid valid, Run run,
                              hipStream_t st) {
+  tune_cache_load();
   auto it = cache.find(key);
-  if (it != cache.end()) return it->second;
+  if (it != cache.end()) {
+    if (it->second >= 0 && it->second < variants && valid(it->second)) return it->second;
+    cache.erase(it);  // a persisted choice this build cannot run
+  }
   hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
   if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return -1;
+  static const bool idle = [] { const char* e = getenv("LHG_TUNE_IDLE"); return e ? atoi(e) != 0 : true; }();
+  static const int runs = [] { const char* e = getenv("LHG_TUNE_RUNS"); return e ? std::max(1, atoi(e)) : TUNE_RUNS; }();
+  if (idle && hipDeviceSynchronize() != hipSuccess) return -1;  // idle device: no other stream shares the CUs with the timed launches
   hipEvent_t e0, e1;
   (void)hipEventCreate(&e0);
   (void)hipEventCreate(&e1);
@@ -469,8 +571,7 @@ static int autotuned_variant(std::map<std::array<int, 12>, int>& cache, const st
     if (!valid(v)) continue;
     run(v);  // warm-up (code object load, caches)
     (void)hipEventRecord(e0, st);
-    run(v);
-    run(v);
+    for (int r = 0; r < runs; ++r) run(v);
     (void)hipEventRecord(e1, st);
     if (hipEventSynchronize(e1) != hipSuccess || hipGetLastError() != hipSuccess) continue;
     float ms = 0;
@@ -479,7 +580,10 @@ static int autotuned_variant(std::map<std::array<int, 12>, int>& cache, const st
   }
   (void)hipEventDestroy(e0);
   (void)hipEventDestroy(e1);
-  if (choice >= 0) cache[key] = choice;
+  if (choice >= 0) {
+    cache[key] = choice;
+    tune_cache_append(&cache == &g_gg_choice, key, choice);
+  }
   return choice;
 }
 
@@ -497,6 +601,14 @@ struct ScopedKernelTime {
   ~ScopedKernelTime() {
     if (ev) (void)hipEventRecord(ev->second, st);
   }
+  void tag(const Geom& g, int rows, int cols, int variant, double flops) {
+    static const bool log = getenv("LHG_PROFILE_LOG") != nullptr;
+    if (!ev || !log) return;
+    char b[160];
+    snprintf(b, sizeof b, "%d,%d,%d,%d,%d,%d,%d,%d,%d,%d,%.0f", g.M, rows, cols, g.Ci, g.Co, g.T, g.istep, g.ostep, g.Hi, variant, flops);
+    t.tags.resize(t.used);
+    t.tags[t.used - 1] = b;
+  }
 };
 
 // LHG_XCD=0 keeps the hardware's round-robin tile order (for A/B measurements of the L2 effect)
@@ -505,17 +617,18 @@ static int xcd_order() {
   return on;
 }
 
-// process-wide arithmetic of the conv GEMMs (lhg_set_conv_precision).  Default: fp32-faithful split kernels; the environment
-// variable LHG_CONV_PRECISION = fp32 | fp32_split | fp32_split2 | bf16 overrides it for programs whose flags must stay the reference's.
+// process-wide arithmetic of the conv GEMMs (lhg_set_conv_precision).  Default: the fp32-faithful two-term fp16 split kernels; the environment
+// variable LHG_CONV_PRECISION = fp32 | fp32_split | fp32_split2 | fp32_split_f16 | bf16 overrides it for programs whose flags must stay the reference's.
 static int default_precision() {
   static const int d = [] {
     const char* e = getenv("LHG_CONV_PRECISION");
-    if (!e) return (int)LHG_PRECISION_F32_SPLIT;
+    if (!e) return (int)LHG_PRECISION_F32_SPLIT_F16;
     const std::string v(e);
     if (v == "fp32" || v == "f32") return (int)LHG_PRECISION_F32;
     if (v == "bf16") return (int)LHG_PRECISION_BF16;
     if (v == "fp32_split2") return (int)LHG_PRECISION_F32_SPLIT2;
-    return (int)LHG_PRECISION_F32_SPLIT;
+    if (v == "fp32_split") return (int)LHG_PRECISION_F32_SPLIT;
+    return (int)LHG_PRECISION_F32_SPLIT_F16;
   }();
   return d;
 }
@@ -524,8 +637,13 @@ static int g_precision = default_precision();
 static int launch_gg_bf16(GGParams& p, hipStream_t st);
 static int launch_gg_split(GGParams& p, hipStream_t st);
 
-static inline bool split_mode() { return g_precision == LHG_PRECISION_F32_SPLIT || g_precision == LHG_PRECISION_F32_SPLIT2; }
-static inline int split_planes() { return g_precision == LHG_PRECISION_F32_SPLIT2 ? 2 : 3; }
+static inline bool split_f16() { return g_precision == LHG_PRECISION_F32_SPLIT_F16; }
+static inline bool split_mode() { return g_precision == LHG_PRECISION_F32_SPLIT || g_precision == LHG_PRECISION_F32_SPLIT2 || split_f16(); }
+static inline int split_planes() { return g_precision == LHG_PRECISION_F32_SPLIT ? 3 : 2; }
+// fp16-split mode: max|w| sits in the 16 bytes behind the panels of a packed weight (lhg_pack_weight put it there)
+static inline const float* weight_amax(const float* wp, int taps, int rows_pad, int k_pad) {
+  return split_f16() ? wp + (size_t)taps * rows_pad * k_pad : nullptr;
+}
 
 static int launch_gg(GGParams& p, hipStream_t st) {
   const Geom& g = p.g;
@@ -580,6 +698,7 @@ static int launch_gg(GGParams& p, hipStream_t st) {
   }
   if (choice < 0) choice = heuristic();
   ScopedKernelTime timed(0, st, 2.0 * g.M * (double)p.rows_pad * g.Ci * g.T);
+  timed.tag(g, p.rows_pad, g.Ci, choice, 2.0 * g.M * (double)p.rows_pad * g.Ci * g.T);
   run(choice);
   return check_launch("gg_kernel");
 }
@@ -634,6 +753,7 @@ static int launch_gg_bf16_t(GGParams& p, hipStream_t st) {
   }
   if (choice < 0) choice = n128 && blocks(128, 128) >= 256 ? 0 : (blocks(128, 64) >= 256 ? 1 : 2);
   ScopedKernelTime timed(0, st, 2.0 * g.M * (double)p.rows_pad * g.Ci * g.T);
+  timed.tag(g, p.rows_pad, g.Ci, choice, 2.0 * g.M * (double)p.rows_pad * g.Ci * g.T);
   run(choice);
   return check_launch("gg2b_kernel");
 }
@@ -659,8 +779,13 @@ static int launch_gg_split(GGParams& p, hipStream_t st) {
   const unsigned wb = (unsigned)wp_bytes;
   auto blocks = [&](int bm, int bn) { return (unsigned)(((g.M + bm - 1) / bm) * (p.rows_pad / bn)); };
   const bool n128 = p.rows_pad % 128 == 0;
-  constexpr int NV = 5;  // 3, 4: eight consumer waves (two per SIMD) on the 128x128 / 128x64 tiles
-  auto valid = [&](int v) { return (v == 0 || v == 3) ? n128 : (NP == 3 || v < 3); };
+  constexpr int NV = 8;  // 3, 4: eight consumer waves (two per SIMD) on the 128x128 / 128x64 tiles; 5..7 (fp16 planes only): four tiles of look-ahead
+  const bool f16 = split_f16();
+  if (f16) LHG_REQUIRE(p.a_amax != nullptr && p.w_amax != nullptr, "gather-GEMM (fp32_split_f16 mode): the operand's absmax pointer is missing (lhg_absmax)");
+  auto valid = [&](int v) {
+    if (v >= 5) return f16 && (v != 7 || n128);
+    return (v == 0 || v == 3) ? n128 : (NP == 3 || f16 || v < 3);
+  };
   auto run = [&](int v) {
     if (NP == 3) {
       switch (v) {
@@ -669,6 +794,18 @@ static int launch_gg_split(GGParams& p, hipStream_t st) {
         case 0: hipLaunchKernelGGL((gg3s_kernel<128, 128, 3, 2>), dim3(blocks(128, 128)), dim3(512), 0, st, p, ib, wb); break;
         case 1: hipLaunchKernelGGL((gg3s_kernel<128, 64, 3, 2>), dim3(blocks(128, 64)), dim3(512), 0, st, p, ib, wb); break;
         case 2: hipLaunchKernelGGL((gg3s_kernel<64, 64, 3, 2>), dim3(blocks(64, 64)), dim3(512), 0, st, p, ib, wb); break;
+        default: break;
+      }
+    } else if (f16) {
+      switch (v) {
+        case 3: hipLaunchKernelGGL((gg3s_kernel<128, 128, 2, 1, 32, float, 8, _Float16>), dim3(blocks(128, 128)), dim3(768), 0, st, p, ib, wb); break;
+        case 4: hipLaunchKernelGGL((gg3s_kernel<128, 64, 2, 1, 32, float, 8, _Float16>), dim3(blocks(128, 64)), dim3(768), 0, st, p, ib, wb); break;
+        case 0: hipLaunchKernelGGL((gg3s_kernel<128, 128, 2, 2, 32, float, 4, _Float16>), dim3(blocks(128, 128)), dim3(512), 0, st, p, ib, wb); break;
+        case 1: hipLaunchKernelGGL((gg3s_kernel<128, 64, 2, 2, 32, float, 4, _Float16>), dim3(blocks(128, 64)), dim3(512), 0, st, p, ib, wb); break;
+        case 2: hipLaunchKernelGGL((gg3s_kernel<64, 64, 2, 2, 32, float, 4, _Float16>), dim3(blocks(64, 64)), dim3(512), 0, st, p, ib, wb); break;
+        case 5: hipLaunchKernelGGL((gg3s_kernel<64, 64, 2, 2, 32, float, 4, _Float16, 4>), dim3(blocks(64, 64)), dim3(512), 0, st, p, ib, wb); break;
+        case 6: hipLaunchKernelGGL((gg3s_kernel<128, 64, 2, 2, 32, float, 4, _Float16, 4>), dim3(blocks(128, 64)), dim3(512), 0, st, p, ib, wb); break;
+        case 7: hipLaunchKernelGGL((gg3s_kernel<128, 128, 2, 1, 32, float, 4, _Float16, 4>), dim3(blocks(128, 128)), dim3(512), 0, st, p, ib, wb); break;
         default: break;
       }
     } else {
@@ -687,6 +824,7 @@ static int launch_gg_split(GGParams& p, hipStream_t st) {
   }
   if (choice < 0) choice = n128 && blocks(128, 128) >= 200 ? 0 : (blocks(128, 64) >= 256 ? 1 : 2);
   ScopedKernelTime timed(0, st, 2.0 * g.M * (double)p.rows_pad * g.Ci * g.T);
+  timed.tag(g, p.rows_pad, g.Ci, choice, 2.0 * g.M * (double)p.rows_pad * g.Ci * g.T);
   run(choice);
   return check_launch("gg3s_kernel");
 }
@@ -713,7 +851,9 @@ static int launch_wg(WGParams& p, int S, hipStream_t st, const WG3Params* p3 = n
   constexpr int NV = 18;
   const bool bf16 = g_precision == LHG_PRECISION_BF16;
   const bool split = split_mode();
+  const bool f16 = split_f16();
   const int NP = split_planes();
+  if (f16) LHG_REQUIRE(p.in_amax != nullptr && p.gout_amax != nullptr, "wgrad (fp32_split_f16 mode): the operands' absmax pointers are missing (lhg_absmax)");
   if (bf16 || split) LHG_REQUIRE(small, "wgrad (bf16 / split mode): tensors of 4 GiB and more are not supported");
   auto valid = [&](int v) {
     if (v >= 14) return bf16 && act16 && (v == 14 ? m128 && n128 : v == 15 ? m128 : v == 16 ? n128 : true);
@@ -759,18 +899,22 @@ static int launch_wg(WGParams& p, int S, hipStream_t st, const WG3Params* p3 = n
       case 17: hipLaunchKernelGGL((wg3b_kernel<64, 64>), grid(64, 64), dim3(256), 0, st, p, ib, gb); break;
       case 10:
         if (NP == 3) hipLaunchKernelGGL((wg2s_kernel<128, 128, 3, 2>), grid(128, 128), dim3(512), 0, st, p, ib, gb);
+        else if (f16) hipLaunchKernelGGL((wg2s_kernel<128, 128, 2, 2, _Float16>), grid(128, 128), dim3(512), 0, st, p, ib, gb);
         else hipLaunchKernelGGL((wg2s_kernel<128, 128, 2, 2>), grid(128, 128), dim3(512), 0, st, p, ib, gb);
         break;
       case 11:
         if (NP == 3) hipLaunchKernelGGL((wg2s_kernel<128, 64, 3, 2>), grid(128, 64), dim3(512), 0, st, p, ib, gb);
+        else if (f16) hipLaunchKernelGGL((wg2s_kernel<128, 64, 2, 2, _Float16>), grid(128, 64), dim3(512), 0, st, p, ib, gb);
         else hipLaunchKernelGGL((wg2s_kernel<128, 64, 2, 2>), grid(128, 64), dim3(512), 0, st, p, ib, gb);
         break;
       case 12:
         if (NP == 3) hipLaunchKernelGGL((wg2s_kernel<64, 128, 3, 2>), grid(64, 128), dim3(512), 0, st, p, ib, gb);
+        else if (f16) hipLaunchKernelGGL((wg2s_kernel<64, 128, 2, 2, _Float16>), grid(64, 128), dim3(512), 0, st, p, ib, gb);
         else hipLaunchKernelGGL((wg2s_kernel<64, 128, 2, 2>), grid(64, 128), dim3(512), 0, st, p, ib, gb);
         break;
       case 13:
         if (NP == 3) hipLaunchKernelGGL((wg2s_kernel<64, 64, 3, 2>), grid(64, 64), dim3(512), 0, st, p, ib, gb);
+        else if (f16) hipLaunchKernelGGL((wg2s_kernel<64, 64, 2, 2, _Float16>), grid(64, 64), dim3(512), 0, st, p, ib, gb);
         else hipLaunchKernelGGL((wg2s_kernel<64, 64, 2, 2>), grid(64, 64), dim3(512), 0, st, p, ib, gb);
         break;
       default: hipLaunchKernelGGL(wg_kernel, grid(64, 64), dim3(256), 0, st, p); break;
@@ -789,6 +933,7 @@ static int launch_wg(WGParams& p, int S, hipStream_t st, const WG3Params* p3 = n
   if (choice < 0 && bf16) choice = m128 && n128 && (p.m_pad / 128) * (p.n_pad / 128) * g.T * S >= 400 ? 6 : 9;
   if (choice < 0) choice = small ? (p3 ? 5 : (m128 && n128 && (p.m_pad / 128) * (p.n_pad / 128) * g.T * S >= 400 ? 0 : 3)) : 4;
   ScopedKernelTime timed(1, st, 2.0 * g.M * (double)p.m_pad * p.n_pad * g.T);
+  timed.tag(g, p.m_pad, p.n_pad, choice + 100 * S, 2.0 * g.M * (double)p.m_pad * p.n_pad * g.T);
   run(choice);
   return check_launch("wg_kernel");
 }
@@ -844,7 +989,7 @@ int lhg_autotune(int on) {
 int lhg_profile_enable(int kernel, int on) {
   LHG_REQUIRE(kernel == 0 || kernel == 1, "profile_enable: kernel must be 0 (gather-GEMM) or 1 (wgrad-GEMM)");
   g_timer[kernel].on = on != 0;
-  if (on) { g_timer[kernel].used = 0; g_timer[kernel].executed_flops = 0; }
+  if (on) { g_timer[kernel].used = 0; g_timer[kernel].executed_flops = 0; g_timer[kernel].tags.clear(); }
   return LHG_OK;
 }
 
@@ -859,6 +1004,16 @@ int lhg_profile_read(int kernel, double* total_ms, long long* launches, double* 
     (void)hipEventElapsedTime(&dt, t.pool[i].first, t.pool[i].second);
     ms += dt;
   }
+  if (const char* path = getenv("LHG_PROFILE_LOG")) {  // debugging aid: one CSV line per launch (tools/layer_table.py)
+    if (FILE* f = fopen(path, "a")) {
+      for (size_t i = 0; i < t.used && i < t.tags.size(); ++i) {
+        float dt = 0;
+        (void)hipEventElapsedTime(&dt, t.pool[i].first, t.pool[i].second);
+        fprintf(f, "%d,%s,%.4f\n", kernel, t.tags[i].c_str(), dt);
+      }
+      fclose(f);
+    }
+  }
   *total_ms = ms;
   *launches = (long long)t.used;
   *executed_flops = t.executed_flops;
@@ -871,11 +1026,18 @@ int lhg_pack_weight(const float* w, int D0, int D1, int KH, int KW, int rows_fro
   const size_t total = (size_t)KH * KW * rows_pad * k_pad;
   const int blocks = (int)std::min<size_t>((total + 255) / 256, 4096);
   if (g_precision == LHG_PRECISION_F32_SPLIT)
-    hipLaunchKernelGGL(pack_weight_split_kernel<3>, dim3(blocks), dim3(256), 0, as_stream(s), w, D0, D1, KH * KW, rows_from_d0,
-                       reinterpret_cast<__bf16*>(dst), rows_pad, k_pad);
+    hipLaunchKernelGGL((pack_weight_split_kernel<3, __bf16>), dim3(blocks), dim3(256), 0, as_stream(s), w, D0, D1, KH * KW, rows_from_d0,
+                       reinterpret_cast<__bf16*>(dst), rows_pad, k_pad, (const float*)nullptr);
   else if (g_precision == LHG_PRECISION_F32_SPLIT2)
-    hipLaunchKernelGGL(pack_weight_split_kernel<2>, dim3(blocks), dim3(256), 0, as_stream(s), w, D0, D1, KH * KW, rows_from_d0,
-                       reinterpret_cast<__bf16*>(dst), rows_pad, k_pad);
+    hipLaunchKernelGGL((pack_weight_split_kernel<2, __bf16>), dim3(blocks), dim3(256), 0, as_stream(s), w, D0, D1, KH * KW, rows_from_d0,
+                       reinterpret_cast<__bf16*>(dst), rows_pad, k_pad, (const float*)nullptr);
+  else if (g_precision == LHG_PRECISION_F32_SPLIT_F16) {
+    float* amax = dst + total;  // two fp16 planes = 4 bytes per element: the panels end `total` floats in
+    int rc = launch_absmax(w, (long long)D0 * D1 * KH * KW, 1, 1, amax, as_stream(s), true);
+    if (rc) return rc;
+    hipLaunchKernelGGL((pack_weight_split_kernel<2, _Float16>), dim3(blocks), dim3(256), 0, as_stream(s), w, D0, D1, KH * KW, rows_from_d0,
+                       reinterpret_cast<_Float16*>(dst), rows_pad, k_pad, (const float*)amax);
+  }
   else if (g_precision == LHG_PRECISION_BF16)
     hipLaunchKernelGGL(pack_weight_bf16_kernel, dim3(blocks), dim3(256), 0, as_stream(s), w, D0, D1, KH * KW, rows_from_d0,
                        reinterpret_cast<__bf16*>(dst), rows_pad, k_pad);
@@ -885,7 +1047,7 @@ int lhg_pack_weight(const float* w, int D0, int D1, int KH, int KW, int rows_fro
 }
 
 int lhg_set_conv_precision(int precision) {
-  LHG_REQUIRE(precision >= LHG_PRECISION_F32 && precision <= LHG_PRECISION_F32_SPLIT2, "set_conv_precision: unknown precision %d", precision);
+  LHG_REQUIRE(precision >= LHG_PRECISION_F32 && precision <= LHG_PRECISION_F32_SPLIT_F16, "set_conv_precision: unknown precision %d", precision);
   g_precision = precision;
   return LHG_OK;
 }
@@ -898,23 +1060,25 @@ long long lhg_packed_weight_floats(int taps, int rows_pad, int k_pad) {
   switch (g_precision) {
     case LHG_PRECISION_F32_SPLIT: return elems * 3 / 2;   // three bf16 planes
     case LHG_PRECISION_F32_SPLIT2: return elems;          // two bf16 planes
+    case LHG_PRECISION_F32_SPLIT_F16: return elems + 4;   // two fp16 planes + 16 bytes: max|w| behind the panels
     default: return elems;                                // fp32 panels (bf16 panels use half of it)
   }
 }
 
 int lhg_conv2d_forward(const float* x, int N, int H, int W, int Ci, int ldx, const float* wp, int rows_pad, int KH, int KW, int stride,
                        float* y, int Co, int ldy, const float* bias, const float* scale, const float* shift,
-                       const float* res, int ldres, int act, float slope, int planar_out, lhg_stream_t s) {
+                       const float* res, int ldres, int act, float slope, int planar_out, const float* x_absmax, lhg_stream_t s) {
   LHG_REQUIRE(conv_args_ok(KH, KW, stride), "conv2d_forward: unsupported kernel %dx%d stride %d", KH, KW, stride);
   GGParams p{};
   conv_fwd_geom(p.g, N, H, W, Ci, ldx, Co, ldy, KH, KW, stride);
+  p.a_amax = x_absmax; p.w_amax = weight_amax(wp, KH * KW, rows_pad, Ci);
   p.in = x; p.wp = wp; p.out = y; p.bias = bias; p.scale = scale; p.shift = shift; p.res = res; p.ldres = ldres;
   p.rows_pad = rows_pad; p.act = act; p.slope = slope; p.planar_out = planar_out;
   return launch_gg(p, as_stream(s));
 }
 
 int lhg_conv2d_backward_input(const float* gy, int N, int H, int W, int Co, int ldgy, const float* wp, int rows_pad, int KH, int KW, int stride,
-                              float* gx, int Ci, int ldgx, lhg_stream_t s) {
+                              float* gx, int Ci, int ldgx, const float* gy_absmax, lhg_stream_t s) {
   LHG_REQUIRE(conv_args_ok(KH, KW, stride), "conv2d_backward_input: unsupported kernel %dx%d stride %d", KH, KW, stride);
   const int ph = KH / 2, pw = KW / 2;
   const int Ho = (H + 2 * ph - KH) / stride + 1, Wo = (W + 2 * pw - KW) / stride + 1;
@@ -923,6 +1087,7 @@ int lhg_conv2d_backward_input(const float* gy, int N, int H, int W, int Co, int 
   g.N = N; g.Hi = Ho; g.Wi = Wo; g.Ci = Co; g.ldi = ldgy;  // gathered tensor = gy
   g.Ho = H; g.Wo = W; g.Co = Ci; g.ldo = ldgx;             // scattered tensor = gx
   p.in = gy; p.wp = wp; p.out = gx; p.rows_pad = rows_pad; p.act = LHG_ACT_NONE;
+  p.a_amax = gy_absmax; p.w_amax = weight_amax(wp, KH * KW, rows_pad, Co);
   if (stride == 1) {
     g.gh = H; g.gw = W; g.oy0 = g.ox0 = 0; g.ostep = 1; g.istep = 1; g.T = KH * KW;
     for (int kh = 0; kh < KH; ++kh)
@@ -982,9 +1147,11 @@ int lhg_conv2d_wgrad_splits(int N, int H, int W, int Ci, int Co, int KH, int KW,
 }
 
 int lhg_conv2d_backward_weight(const float* x, int N, int H, int W, int Ci, int ldx, const float* gy, int Co, int ldgy,
-                               int KH, int KW, int stride, float* slabs, int S, int ci_pad, int co_pad, lhg_stream_t s) {
+                               int KH, int KW, int stride, float* slabs, int S, int ci_pad, int co_pad, const float* x_absmax,
+                               const float* gy_absmax, lhg_stream_t s) {
   LHG_REQUIRE(conv_args_ok(KH, KW, stride), "conv2d_backward_weight: unsupported kernel %dx%d stride %d", KH, KW, stride);
   WGParams p{};
+  p.in_amax = x_absmax; p.gout_amax = gy_absmax;
   conv_fwd_geom(p.g, N, H, W, Ci, ldx, Co, ldgy, KH, KW, stride);
   p.in = x; p.gout = gy; p.slabs = slabs; p.m_pad = ci_pad; p.n_pad = co_pad; p.Tslabs = KH * KW;
   if (KH == 3 && KW == 3 && stride == 1 && g_precision == LHG_PRECISION_F32) {
@@ -1009,11 +1176,12 @@ static void convt_geom(Geom& g, int N, int H, int W, int Ci, int ldx, int Co, in
 }
 
 int lhg_conv_transpose2x2_forward(const float* x, int N, int H, int W, int Ci, int ldx, const float* wp, int rows_pad,
-                                  float* y, int Co, int ldy, const float* bias, lhg_stream_t s) {
+                                  float* y, int Co, int ldy, const float* bias, const float* x_absmax, lhg_stream_t s) {
   for (int py = 0; py < 2; ++py)
     for (int px = 0; px < 2; ++px) {
       GGParams p{};
       convt_geom(p.g, N, H, W, Ci, ldx, Co, ldy, py, px);
+      p.a_amax = x_absmax; p.w_amax = weight_amax(wp, 4, rows_pad, Ci);
       p.in = x; p.wp = wp; p.out = y; p.bias = bias; p.rows_pad = rows_pad; p.act = LHG_ACT_NONE;
       int rc = launch_gg(p, as_stream(s));
       if (rc) return rc;
@@ -1022,8 +1190,9 @@ int lhg_conv_transpose2x2_forward(const float* x, int N, int H, int W, int Ci, i
 }
 
 int lhg_conv_transpose2x2_backward_input(const float* gy, int N, int H, int W, int Co, int ldgy, const float* wp, int rows_pad,
-                                         float* gx, int Ci, int ldgx, lhg_stream_t s) {
+                                         float* gx, int Ci, int ldgx, const float* gy_absmax, lhg_stream_t s) {
   GGParams p{};
+  p.a_amax = gy_absmax; p.w_amax = weight_amax(wp, 4, rows_pad, Co);
   Geom& g = p.g;
   g.N = N; g.Hi = 2 * H; g.Wi = 2 * W; g.Ci = Co; g.ldi = ldgy;
   g.Ho = H; g.Wo = W; g.Co = Ci; g.ldo = ldgx;
@@ -1039,16 +1208,24 @@ int lhg_conv_transpose2x2_wgrad_splits(int N, int H, int W, int Ci, int Co) {
 }
 
 int lhg_conv_transpose2x2_backward_weight(const float* x, int N, int H, int W, int Ci, int ldx, const float* gy, int Co, int ldgy,
-                                          float* slabs, int S, int ci_pad, int co_pad, lhg_stream_t s) {
+                                          float* slabs, int S, int ci_pad, int co_pad, const float* x_absmax, const float* gy_absmax,
+                                          lhg_stream_t s) {
   for (int py = 0; py < 2; ++py)
     for (int px = 0; px < 2; ++px) {
       WGParams p{};
+      p.in_amax = x_absmax; p.gout_amax = gy_absmax;
       convt_geom(p.g, N, H, W, Ci, ldx, Co, ldgy, py, px);
       p.in = x; p.gout = gy; p.slabs = slabs; p.m_pad = ci_pad; p.n_pad = co_pad; p.Tslabs = 4;
       int rc = launch_wg(p, S, as_stream(s));
       if (rc) return rc;
     }
   return LHG_OK;
+}
+
+int lhg_absmax(const float* x, long long pixels, int C, int ld, float* out, lhg_stream_t s) {
+  LHG_REQUIRE(pixels >= 0 && C > 0 && ld >= C, "absmax: bad extents (pixels %lld, C %d, ld %d)", pixels, C, ld);
+  LHG_REQUIRE(!act_is_bf16(), "absmax: fp32 tensors only (the bf16 storage mode does not use it)");
+  return launch_absmax(x, pixels, C, ld, out, as_stream(s), false);
 }
 
 int lhg_wgrad_reduce(const float* slabs, int S, int T, int m_pad, int n_pad, float* grad, int D0, int D1, int m_is_d1, int accumulate,

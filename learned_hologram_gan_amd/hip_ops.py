@@ -323,8 +323,9 @@ def _small_grad_slot(p):
 
 
 # --------------------------------------------------------------------------- operand precision of the conv GEMMs
-_PRECISIONS = {"fp32": 0, "f32": 0, "bf16": 1, "fp32_split": 2, "fp32_split2": 3}
-_PRECISION_NAMES = {0: "fp32", 1: "bf16", 2: "fp32_split", 3: "fp32_split2"}
+_PRECISIONS = {"fp32": 0, "f32": 0, "bf16": 1, "fp32_split": 2, "fp32_split2": 3, "fp32_split_f16": 4}
+_PRECISION_NAMES = {0: "fp32", 1: "bf16", 2: "fp32_split", 3: "fp32_split2", 4: "fp32_split_f16"}
+_F16_SPLIT = 4
 _precision = None  # read from the library on first use (it starts in lhg_default_conv_precision())
 
 
@@ -336,12 +337,15 @@ def _mode() -> int:
 
 
 def default_precision() -> str:
-    """The mode the library starts in: "fp32_split" unless LHG_CONV_PRECISION (fp32 | fp32_split | fp32_split2 | bf16) says otherwise."""
+    """The mode the library starts in: "fp32_split_f16" unless LHG_CONV_PRECISION (fp32 | fp32_split | fp32_split2 | fp32_split_f16 | bf16)
+    says otherwise."""
     return _PRECISION_NAMES[int(native.load().lhg_default_conv_precision())]
 
 
 def set_conv_precision(name: str) -> None:
     """Arithmetic of the conv GEMMs (tensors are fp32 in every mode), see lhg_set_conv_precision:
+    "fp32_split_f16" fp32-faithful on the fp16 matrix pipe: tensor-scaled operands as sums of two fp16 terms, three MFMA products,
+                  fp32 accumulate (the GEMM operands' max|x| is measured with lhg_absmax, see operand_absmax);
     "fp32_split"  fp32-faithful on the bf16 matrix pipe: operands as exact sums of three bf16 terms, six MFMA products, fp32 accumulate;
     "fp32"        exact fp32 MFMA (v_mfma_f32_32x32x2_f32);
     "fp32_split2" two bf16 terms, three products (~2^-16 per product), measurements only;
@@ -358,6 +362,33 @@ def set_conv_precision(name: str) -> None:
 
 def conv_precision() -> str:
     return _PRECISION_NAMES[_mode()]
+
+
+def operand_absmax(t):
+    """max|t| of an NHWC fp32 GEMM operand as a one-element device tensor (lhg_absmax on the current stream) — the tensor scale of
+    the "fp32_split_f16" mode; None in every other mode.  Measured once per operand and handed to each GEMM that reads it."""
+    if _mode() != _F16_SPLIT:
+        return None
+    p, N, H, W, Cc, ld = nhwc(t)
+    out = _amax_slot(t.device)
+    call("lhg_absmax", p, N * H * W, Cc, ld, ptr(out), stream_ptr())
+    return out
+
+
+_AMAX_POOL = {}  # (device, stream, capturing) -> [zero-filled tensor, next free index]; a slot is handed out once
+
+
+def _amax_slot(device):
+    """A zeroed one-float slot for lhg_absmax (it max-accumulates).  One fill launch prepares 1024 slots.  Pools are per stream — the fill
+    and the measurement are ordered by the stream they both run on — and a pool filled outside a graph capture is not used inside one
+    (the fill has to be part of the graph for the replays to start from zero)."""
+    key = (device, stream_ptr(), torch.cuda.is_current_stream_capturing())
+    pool = _AMAX_POOL.get(key)
+    if pool is None or pool[1] >= pool[0].numel():
+        pool = _AMAX_POOL[key] = [torch.zeros((1024,), dtype=torch.float32, device=device), 0]
+    i = pool[1]
+    pool[1] = i + 1
+    return pool[0][i:i + 1]
 
 
 def apply_env_precision() -> None:
@@ -387,7 +418,9 @@ def pack_weight(w: torch.Tensor, rows_from_d0: bool, k_pad_to: int = 32) -> torc
     if not wd.is_contiguous():
         wd = wd.contiguous()
     floats = int(native.load().lhg_packed_weight_floats(KH * KW, rows_pad, k_pad))
-    out = torch.empty((KH * KW, rows_pad, floats // (KH * KW * rows_pad)), dtype=torch.float32, device=w.device)
+    panel_rows = KH * KW * rows_pad
+    buf = torch.empty((floats,), dtype=torch.float32, device=w.device)  # panels (+ 16 bytes behind them in the fp16-split mode: max|w|)
+    out = buf[: panel_rows * (floats // panel_rows)].view(KH * KW, rows_pad, floats // panel_rows)
     call("lhg_pack_weight", ptr(wd), D0, D1, KH, KW, int(rows_from_d0), ptr(out), rows_pad, k_pad, stream_ptr())
     cache[(rows_from_d0, k_pad, _mode())] = (stamp, out)
     return out
@@ -459,7 +492,7 @@ def _raw_weight(w):
     return wd if wd.is_contiguous() else wd.contiguous()
 
 
-def conv2d_forward_raw(x, w, bias, stride, act=ACT_NONE, slope=0.0, scale=None, shift=None, res=None, out=None, planar=False):
+def conv2d_forward_raw(x, w, bias, stride, act=ACT_NONE, slope=0.0, scale=None, shift=None, res=None, out=None, planar=False, x_amax=None):
     """y = act((conv(x, w) + bias) * scale + shift + res); no autograd."""
     px, N, H, W, Ci, ldx = nhwc(x)
     Co, Ciw, KH, KW = w.shape
@@ -488,8 +521,10 @@ def conv2d_forward_raw(x, w, bias, stride, act=ACT_NONE, slope=0.0, scale=None, 
     if res is not None:
         pres, _, _, _, _, ldres = nhwc(res)
     native.count_flops(0, 2.0 * N * Ho * Wo * Co * (w.shape[1] * w.shape[2] * w.shape[3]))
+    if x_amax is None:
+        x_amax = operand_absmax(x)
     call("lhg_conv2d_forward", px, N, H, W, Ci, ldx, ptr(wp), wp.shape[1], KH, KW, stride, py, Co, ldy,
-         ptr(bias), ptr(scale), ptr(shift), pres, ldres, act, float(slope), int(planar), stream_ptr())
+         ptr(bias), ptr(scale), ptr(shift), pres, ldres, act, float(slope), int(planar), ptr(x_amax), stream_ptr())
     return y
 
 
@@ -521,19 +556,24 @@ class Conv2dFn(TrackedFunction):
         note_use(w, ctx.needs_input_grad[1])
         ctx.bias = bias if (bias is not None and ctx.needs_input_grad[2]) else None  # its gradient never passes through autograd
         note_use(ctx.bias)
-        return conv2d_forward_raw(x, w, bias, stride, out=out)
+        gemm = not (w.shape[2] == w.shape[3] and thin_mode(w.shape[1], w.shape[0], w.shape[2], stride))
+        ctx.x_amax = operand_absmax(x) if gemm else None  # measured once: the forward GEMM and the weight-gradient GEMM both scale x by it
+        return conv2d_forward_raw(x, w, bias, stride, out=out, x_amax=ctx.x_amax)
 
     @staticmethod
     def backward(ctx, gy):
         x, w = ctx.saved_tensors
         gy = _as_nhwc_view(gy)  # autograd may hand out an expanded (zero-stride) gradient, e.g. from .sum()
         gx = gw = gb = None
+        gemm = not (w.shape[2] == w.shape[3] and thin_mode(w.shape[1], w.shape[0], w.shape[2], ctx.stride))
+        gy_amax = operand_absmax(gy) if gemm and gy.shape[-1] % 32 == 0 else None  # one measurement for both backward GEMMs
         if ctx.needs_input_grad[0]:
-            gx = Conv2dInputGradFn.apply(gy, w, ctx.stride, x.shape[1], x.shape[2], x.shape[3])
+            gx = Conv2dInputGradFn.apply(gy, w, ctx.stride, x.shape[1], x.shape[2], x.shape[3], gy_amax)
         if not param_grads_wanted():  # inside only_input_gradients(): the caller differentiates with respect to activations only
             return gx, None, None, None, None
         if ctx.needs_input_grad[1]:
-            gw = _weight_grad(w, (x, gy), lambda slot: conv2d_weight_grad(x, gy, w.shape, ctx.stride, slot))
+            xa = ctx.x_amax
+            gw = _weight_grad(w, (x, gy), lambda slot: conv2d_weight_grad(x, gy, w.shape, ctx.stride, slot, xa, gy_amax))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = _bias_grad(ctx.bias, gy, ctx.bias_grad_is_zero, w.shape[0])
         return gx, gw, gb, None, None
@@ -543,7 +583,7 @@ class Conv2dInputGradFn(TrackedFunction):
     """gx = d conv2d / d x contracted with gy.  Returns (N, H, W, pad32(Ci))."""
 
     @staticmethod
-    def forward(ctx, gy, w, stride, H, W, Cx):
+    def forward(ctx, gy, w, stride, H, W, Cx, gy_amax=None):
         ctx.save_for_backward(gy, w)
         ctx.stride = stride
         note_use(w, ctx.needs_input_grad[1])
@@ -567,7 +607,9 @@ class Conv2dInputGradFn(TrackedFunction):
             gx[..., Ci:].zero_()
         pgx, _, _, _, _, ldgx = nhwc(gx)
         native.count_flops(0, 2.0 * N * Ho * Wo * Co * (w.shape[1] * w.shape[2] * w.shape[3]))
-        call("lhg_conv2d_backward_input", pg, N, H, W, Cg, ldg, ptr(wp), wp.shape[1], KH, KW, stride, pgx, Ci, ldgx, stream_ptr())
+        if gy_amax is None or gyp is not gy:
+            gy_amax = operand_absmax(gyp)
+        call("lhg_conv2d_backward_input", pg, N, H, W, Cg, ldg, ptr(wp), wp.shape[1], KH, KW, stride, pgx, Ci, ldgx, ptr(gy_amax), stream_ptr())
         return gx
 
     @staticmethod
@@ -578,10 +620,10 @@ class Conv2dInputGradFn(TrackedFunction):
             g_gy = Conv2dFn.apply(ggx, w, None, ctx.stride, None)
         if ctx.needs_input_grad[1] and param_grads_wanted():
             g_w = _weight_grad(w, (ggx, gy), lambda slot: conv2d_weight_grad(ggx, gy, w.shape, ctx.stride, slot))
-        return g_gy, g_w, None, None, None, None
+        return g_gy, g_w, None, None, None, None, None
 
 
-def conv2d_weight_grad_raw(x, gy, wshape, stride, slot=None):
+def conv2d_weight_grad_raw(x, gy, wshape, stride, slot=None, x_amax=None, gy_amax=None):
     """gw (OIHW) = sum over pixels of x (gathered) outer gy; no autograd.  With ``slot`` the slab reduction accumulates straight into
     it (the parameter's view of the flat gradient buffer) and nothing is returned."""
     Co, Ci, KH, KW = wshape
@@ -605,7 +647,12 @@ def conv2d_weight_grad_raw(x, gy, wshape, stride, slot=None):
     ci_pad, co_pad = pad_to(Cx, 64), pad_to(Cg, 64)
     slabs = torch.empty((S, KH * KW, ci_pad, co_pad), dtype=torch.float32, device=x.device)
     native.count_flops(1, 2.0 * N * gy.shape[1] * gy.shape[2] * Co * Ci * KH * KW)
-    call("lhg_conv2d_backward_weight", px, N, H, W, Cx, ldx, pg, Cg, ldg, KH, KW, stride, ptr(slabs), S, ci_pad, co_pad, stream_ptr())
+    if x_amax is None:
+        x_amax = operand_absmax(x)
+    if gy_amax is None or gyp is not gy:
+        gy_amax = operand_absmax(gyp)
+    call("lhg_conv2d_backward_weight", px, N, H, W, Cx, ldx, pg, Cg, ldg, KH, KW, stride, ptr(slabs), S, ci_pad, co_pad,
+         ptr(x_amax), ptr(gy_amax), stream_ptr())
     gw = slot if slot is not None else torch.empty(tuple(wshape), dtype=torch.float32, device=x.device)
     if not gw.is_contiguous():
         raise ValueError("weight-gradient slot must be contiguous")
@@ -613,11 +660,11 @@ def conv2d_weight_grad_raw(x, gy, wshape, stride, slot=None):
     return None if slot is not None else gw
 
 
-def conv2d_weight_grad(x, gy, wshape, stride, slot):
+def conv2d_weight_grad(x, gy, wshape, stride, slot, x_amax=None, gy_amax=None):
     """Differentiable op without a slot, raw accumulation with one."""
     if slot is None:
         return Conv2dWeightGradFn.apply(x, gy, wshape, stride)
-    return conv2d_weight_grad_raw(x, gy, wshape, stride, slot)
+    return conv2d_weight_grad_raw(x, gy, wshape, stride, slot, x_amax, gy_amax)
 
 
 def _bias_grad(bias, gy, is_zero, Co):
@@ -677,7 +724,8 @@ class ConvTranspose2x2Fn(TrackedFunction):
         y = _resolve_out(out, (N, 2 * H, 2 * W, Co), x.device)
         py, _, _, _, _, ldy = nhwc(y)
         native.count_flops(0, 2.0 * N * H * W * 4 * Ci * Co)
-        call("lhg_conv_transpose2x2_forward", px, N, H, W, Ci, ldx, ptr(wp), wp.shape[1], py, Co, ldy, ptr(bias), stream_ptr())
+        ctx.x_amax = operand_absmax(x)
+        call("lhg_conv_transpose2x2_forward", px, N, H, W, Ci, ldx, ptr(wp), wp.shape[1], py, Co, ldy, ptr(bias), ptr(ctx.x_amax), stream_ptr())
         return y
 
     @staticmethod
@@ -686,13 +734,15 @@ class ConvTranspose2x2Fn(TrackedFunction):
         gy = _as_nhwc_view(gy)
         gx = gw = gb = None
         Ci, Co = w.shape[0], w.shape[1]
+        gy_amax = operand_absmax(gy)
         if ctx.needs_input_grad[0]:
             pg, N, H2, W2, Cg, ldg = nhwc(gy)
             wp = pack_weight(w, True)  # rows = Cin, K = Cout
             gx = new_nhwc(N, H2 // 2, W2 // 2, Ci, gy.device)
             pgx, _, _, _, _, ldgx = nhwc(gx)
             native.count_flops(0, 2.0 * N * (H2 // 2) * (W2 // 2) * 4 * Ci * Co)
-            call("lhg_conv_transpose2x2_backward_input", pg, N, H2 // 2, W2 // 2, Cg, ldg, ptr(wp), wp.shape[1], pgx, Ci, ldgx, stream_ptr())
+            call("lhg_conv_transpose2x2_backward_input", pg, N, H2 // 2, W2 // 2, Cg, ldg, ptr(wp), wp.shape[1], pgx, Ci, ldgx, ptr(gy_amax),
+                 stream_ptr())
         if not param_grads_wanted():
             return gx, None, None, None
         if ctx.needs_input_grad[1]:
@@ -703,7 +753,8 @@ class ConvTranspose2x2Fn(TrackedFunction):
                 ci_pad, co_pad = pad_to(Cx, 64), pad_to(Cg, 64)
                 slabs = torch.empty((S, 4, ci_pad, co_pad), dtype=torch.float32, device=x.device)
                 native.count_flops(1, 2.0 * N * H * W * 4 * Ci * Co)
-                call("lhg_conv_transpose2x2_backward_weight", px, N, H, W, Cx, ldx, pg, Cg, ldg, ptr(slabs), S, ci_pad, co_pad, stream_ptr())
+                call("lhg_conv_transpose2x2_backward_weight", px, N, H, W, Cx, ldx, pg, Cg, ldg, ptr(slabs), S, ci_pad, co_pad,
+                     ptr(ctx.x_amax), ptr(gy_amax), stream_ptr())
                 out = slot if slot is not None else torch.empty(w.shape, dtype=torch.float32, device=x.device)
                 call("lhg_wgrad_reduce", ptr(slabs), S, 4, ci_pad, co_pad, ptr(out), Ci, Co, 0, int(slot is not None), stream_ptr())
                 return None if slot is not None else out

@@ -45,19 +45,20 @@ _SIGNATURES = {
     "lhg_default_conv_precision": [],
     "lhg_packed_weight_floats": [C.c_int, C.c_int, C.c_int],
     "lhg_pack_weight": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _p],
-    "lhg_conv2d_forward": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _i, _i, _f, _i, _p],
-    "lhg_conv2d_backward_input": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p],
+    "lhg_conv2d_forward": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _i, _i, _f, _i, _p, _p],
+    "lhg_conv2d_backward_input": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p, _p],
     "lhg_conv2d_wgrad_splits": [_i, _i, _i, _i, _i, _i, _i, _i],
-    "lhg_conv2d_backward_weight": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _p],
+    "lhg_conv2d_backward_weight": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _p, _p, _p],
     "lhg_conv2d_thin_supported": [_i, _i, _i, _i],
     "lhg_conv2d_thin_forward": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _i, _p, _p, _p, _i, _f, _i, _p],
     "lhg_conv2d_thin_backward_input": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _i, _p],
     "lhg_conv2d_thin_wgrad_workspace": [_i, _i, _i, _i, _i, _i],
     "lhg_conv2d_thin_backward_weight": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _p, _p, _sz, _p],
-    "lhg_conv_transpose2x2_forward": [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _i, _p, _p],
-    "lhg_conv_transpose2x2_backward_input": [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _i, _p],
+    "lhg_conv_transpose2x2_forward": [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _i, _p, _p, _p],
+    "lhg_conv_transpose2x2_backward_input": [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _i, _p, _p],
     "lhg_conv_transpose2x2_wgrad_splits": [_i, _i, _i, _i, _i],
-    "lhg_conv_transpose2x2_backward_weight": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _i, _i, _i, _p],
+    "lhg_conv_transpose2x2_backward_weight": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _i, _i, _i, _p, _p, _p],
+    "lhg_absmax": [_p, _ll, _i, _i, _p, _p],
     "lhg_wgrad_reduce": [_p, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p],
     "lhg_channel_sum": [_p, _ll, _i, _i, _p, _i, _p, _p],
     "lhg_bn_stats": [_p, _ll, _i, _i, _p, _p, _p, _f, _f, _p, _p],
@@ -122,8 +123,8 @@ def load():
         fn.argtypes = argtypes
         fn.restype = _RESTYPE.get(name, C.c_int)
     got = lib.lhg_abi_version()
-    if got != 2:
-        raise NativeLibraryError(f"ABI version mismatch: library {got}, binding 2")
+    if got != 3:
+        raise NativeLibraryError(f"ABI version mismatch: library {got}, binding 3")
     _lib = lib
     return lib
 

@@ -92,16 +92,23 @@ def test_conv2d_forward_and_gradients(ops, case):
 
 @pytest.mark.parametrize("case", [(2, 64, 64, 48, 48, 3, 1), (2, 128, 256, 24, 24, 3, 1), (2, 512, 512, 12, 12, 3, 1), (2, 64, 128, 24, 24, 1, 1),
                                   (2, 64, 128, 32, 32, 3, 2), (4, 1024, 1024, 8, 8, 3, 1), (1, 96, 160, 17, 23, 3, 1)], ids=lambda c: "x".join(map(str, c)))
-def test_split_bf16_gemm_is_fp32_faithful(ops, case):
-    """The default GEMM mode ("fp32_split": every operand an exact sum of three bf16 terms, six MFMA products, fp32 accumulation) against a
-    FLOAT64 convolution, next to the exact fp32 MFMA kernels ("fp32") on the same data: forward, input gradient and weight gradient must
-    be as close to the truth as the exact kernels are (same order of rounding error: the sum is accumulated in fp32 either way) and far
-    inside the 2e-5 the per-op parity tests use."""
+@pytest.mark.parametrize("mode,spread", [("fp32_split", 0), ("fp32_split_f16", 0), ("fp32_split_f16", 6)])
+def test_split_gemm_is_fp32_faithful(ops, case, mode, spread):
+    """The split GEMM modes — "fp32_split": every operand an exact sum of three bf16 terms, six MFMA products; "fp32_split_f16": tensor-
+    scaled operands as sums of two fp16 terms, three products; fp32 accumulation in both — against a FLOAT64 convolution, next to the
+    exact fp32 MFMA kernels ("fp32") on the same data: forward, input gradient and weight gradient must be as close to the truth as the
+    exact kernels are (same order of rounding error: the sum is accumulated in fp32 either way) and far inside the 2e-5 the per-op
+    parity tests use.  spread > 0: element magnitudes spread log-uniformly over 10^spread (the fp16 scheme's tensor scale keeps full
+    relative accuracy over a 2^18 window and an absolute error below 2^-39 of the tensor maximum under it) at a gradient-like level."""
     N, Ci, Co, H, W, k, stride = case
     x = rnd(N, Ci, H, W, seed=11)
     w = rnd(Co, Ci, k, k, seed=12, scale=(Ci * k * k) ** -0.5)
     Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
     gy = rnd(N, Co, Ho, Wo, seed=13)
+    if spread:
+        g = torch.Generator().manual_seed(14)
+        x = x * torch.pow(10.0, -spread * torch.rand(x.shape, generator=g)) * 1e3
+        gy = gy * torch.pow(10.0, -spread * torch.rand(gy.shape, generator=g)) * 1e-7
     xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
     yd = F.conv2d(xd, wd, None, stride=stride, padding=k // 2)
     gxd, gwd = torch.autograd.grad(yd, (xd, wd), gy.double())
@@ -120,20 +127,20 @@ def test_split_bf16_gemm_is_fp32_faithful(ops, case):
             ops.set_conv_precision("default")
         return [rel_err(a.double(), b) for a, b in zip((y, gx, gw), truth)]
 
-    e_split, e_exact = errors("fp32_split"), errors("fp32")
+    e_split, e_exact = errors(mode), errors("fp32")
     for es, ee in zip(e_split, e_exact):
         assert es < 1e-5 and es <= 3.0 * ee + 5e-7, (e_split, e_exact)
 
 
 def test_default_gemm_mode_and_env_override():
-    """The library starts in the fp32-faithful split mode unless LHG_CONV_PRECISION names another one (read at load time)."""
+    """The library starts in the fp32-faithful two-term fp16 split mode unless LHG_CONV_PRECISION names another one (read at load time)."""
     import os
     import subprocess
     import sys
 
     from learned_hologram_gan_amd import hip_ops
 
-    want = os.environ.get("LHG_CONV_PRECISION", "fp32_split")
+    want = os.environ.get("LHG_CONV_PRECISION", "fp32_split_f16")
     assert hip_ops.default_precision() == want and hip_ops.conv_precision() == want
     code = "from learned_hologram_gan_amd import hip_ops; print(hip_ops.conv_precision())"
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
