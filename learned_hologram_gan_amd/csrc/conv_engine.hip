@@ -335,6 +335,7 @@ __global__ __launch_bounds__(256, 2) void wg_kernel(const WGParams p) {
 #include "wg2b_kernel.inc"
 #include "wg2s_kernel.inc"
 #include "wg3b_kernel.inc"
+#include "wg4s_kernel.inc"
 #include "wg3_kernel.inc"
 
 // ------------------------------------------------------------------------------------ small kernels
@@ -847,8 +848,8 @@ static int launch_wg(WGParams& p, int S, hipStream_t st, const WG3Params* p3 = n
   const unsigned ib = (unsigned)in_bytes, gb = (unsigned)go_bytes;
   const bool m128 = p.m_pad % 128 == 0, n128 = p.n_pad % 128 == 0;
   // 5: nine-tap fused kernel for 3x3 stride 1; 6..9: bf16-operand kernels; 10..13: split (fp32-faithful) kernels;
-  // 14..17: bf16 STORAGE kernels with transposed LDS reads (wg3b_kernel)
-  constexpr int NV = 18;
+  // 14..17: bf16 STORAGE kernels with transposed LDS reads (wg3b_kernel); 18..21: fp16-split kernels with transposed LDS reads (wg4s_kernel)
+  constexpr int NV = 22;
   const bool bf16 = g_precision == LHG_PRECISION_BF16;
   const bool split = split_mode();
   const bool f16 = split_f16();
@@ -856,6 +857,7 @@ static int launch_wg(WGParams& p, int S, hipStream_t st, const WG3Params* p3 = n
   if (f16) LHG_REQUIRE(p.in_amax != nullptr && p.gout_amax != nullptr, "wgrad (fp32_split_f16 mode): the operands' absmax pointers are missing (lhg_absmax)");
   if (bf16 || split) LHG_REQUIRE(small, "wgrad (bf16 / split mode): tensors of 4 GiB and more are not supported");
   auto valid = [&](int v) {
+    if (v >= 18) return f16 && (v == 18 ? m128 && n128 : v == 19 ? m128 : v == 20 ? n128 : true);
     if (v >= 14) return bf16 && act16 && (v == 14 ? m128 && n128 : v == 15 ? m128 : v == 16 ? n128 : true);
     if (split) return v >= 10 && (v == 10 ? m128 && n128 : v == 11 ? m128 : v == 12 ? n128 : true);
     if (v >= 10) return false;
@@ -893,6 +895,10 @@ static int launch_wg(WGParams& p, int S, hipStream_t st, const WG3Params* p3 = n
         if (act16) hipLaunchKernelGGL((wg2b_kernel<64, 64, __bf16>), grid(64, 64), dim3(256), 0, st, p, ib, gb);
         else hipLaunchKernelGGL((wg2b_kernel<64, 64, float>), grid(64, 64), dim3(256), 0, st, p, ib, gb);
         break;
+      case 18: hipLaunchKernelGGL((wg4s_kernel<128, 128>), grid(128, 128), dim3(256), 0, st, p, ib, gb); break;
+      case 19: hipLaunchKernelGGL((wg4s_kernel<128, 64>), grid(128, 64), dim3(256), 0, st, p, ib, gb); break;
+      case 20: hipLaunchKernelGGL((wg4s_kernel<64, 128>), grid(64, 128), dim3(256), 0, st, p, ib, gb); break;
+      case 21: hipLaunchKernelGGL((wg4s_kernel<64, 64>), grid(64, 64), dim3(256), 0, st, p, ib, gb); break;
       case 14: hipLaunchKernelGGL((wg3b_kernel<128, 128>), grid(128, 128), dim3(256), 0, st, p, ib, gb); break;
       case 15: hipLaunchKernelGGL((wg3b_kernel<128, 64>), grid(128, 64), dim3(256), 0, st, p, ib, gb); break;
       case 16: hipLaunchKernelGGL((wg3b_kernel<64, 128>), grid(64, 128), dim3(256), 0, st, p, ib, gb); break;
@@ -928,6 +934,7 @@ static int launch_wg(WGParams& p, int S, hipStream_t st, const WG3Params* p3 = n
     const std::array<int, 12> key = {g.M, p.m_pad, p.n_pad, g.T, S, g.istep, g.ostep, g.Hi, g.Wi, g.ldi, g.ldo, g.ws[0] + 100 * g_precision + (act16 ? 1000 : 0)};
     choice = autotuned_variant(g_wg_choice, key, NV, valid, run, st);
   }
+  if (choice < 0 && f16) choice = m128 && n128 && (p.m_pad / 128) * (p.n_pad / 128) * g.T * S >= 400 ? 18 : 21;
   if (choice < 0 && split) choice = m128 && n128 && (p.m_pad / 128) * (p.n_pad / 128) * g.T * S >= 200 ? 10 : 13;
   if (choice < 0 && bf16 && act16) choice = m128 && n128 && (p.m_pad / 128) * (p.n_pad / 128) * g.T * S >= 400 ? 14 : 17;
   if (choice < 0 && bf16) choice = m128 && n128 && (p.m_pad / 128) * (p.n_pad / 128) * g.T * S >= 400 ? 6 : 9;
