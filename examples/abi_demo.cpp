@@ -63,12 +63,12 @@ int main() {
   HIP_OK(hipMalloc(&db, b.size() * 4));
   HIP_OK(hipMalloc(&dy, y.size() * 4));
   HIP_OK(hipMalloc(&dwp, (size_t)lhg_packed_weight_floats(K * K, rows_pad, Ci) * 4));  // panel size depends on the precision mode
-  HIP_OK(hipMalloc(&dxmax, 4));
+  HIP_OK(hipMalloc(&dxmax, LHG_ABSMAX_WORDS * 4));
   HIP_OK(hipMemcpyAsync(dx, x.data(), x.size() * 4, hipMemcpyHostToDevice, stream));
   HIP_OK(hipMemcpyAsync(dw, w.data(), w.size() * 4, hipMemcpyHostToDevice, stream));
   HIP_OK(hipMemcpyAsync(db, b.data(), b.size() * 4, hipMemcpyHostToDevice, stream));
   LHG_OK_OR_DIE(lhg_pack_weight(dw, Co, Ci, K, K, /*rows_from_d0=*/1, dwp, rows_pad, Ci, stream));
-  HIP_OK(hipMemsetAsync(dxmax, 0, 4, stream));  // lhg_absmax max-accumulates into its slot
+  HIP_OK(hipMemsetAsync(dxmax, 0, LHG_ABSMAX_WORDS * 4, stream));  // lhg_absmax max-accumulates into its slot
   LHG_OK_OR_DIE(lhg_absmax(dx, (long long)N * H * W, Ci, Ci, dxmax, stream));  // the tensor scale of the fp16-split GEMM mode (ignored by the others)
   LHG_OK_OR_DIE(lhg_conv2d_forward(dx, N, H, W, Ci, Ci, dwp, rows_pad, K, K, /*stride=*/1, dy, Co, Co, db, nullptr, nullptr, nullptr, 0,
                                    LHG_ACT_RELU, 0.f, /*planar_out=*/0, dxmax, stream));

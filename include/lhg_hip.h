@@ -113,8 +113,11 @@ int lhg_get_conv_precision(void);
 int lhg_default_conv_precision(void);
 /* floats the caller must allocate for lhg_pack_weight's `dst` in the current precision mode */
 long long lhg_packed_weight_floats(int taps, int rows_pad, int k_pad);
-/* *out = max(*out, max |x|) over the first C of ld channels of `pixels` pixels (fp32 tensors; stream-ordered, no host
- * synchronisation).  The caller zero-fills `out` first (one fill can prepare many slots); several calls on one slot give the
+/* An operand's `*_absmax` argument points to LHG_ABSMAX_WORDS floats whose MAXIMUM is (an upper bound of) max|x|.  One word today:
+ * spreading the producers' atomics over 16 words was measured and is slower (each word ramps up from zero on its own). */
+#define LHG_ABSMAX_WORDS 1
+/* out[0] = max(out[0], max |x|) over the first C of ld channels of `pixels` pixels (fp32 tensors; stream-ordered, no host
+ * synchronisation).  The caller zero-fills the LHG_ABSMAX_WORDS floats of `out` first (one fill can prepare many slots); several calls on one slot give the
  * maximum over several tensors.  The tensor-scale input of LHG_PRECISION_F32_SPLIT_F16: measure each GEMM operand once and pass
  * `out` as its `*_absmax`; any upper bound of max|x| is valid, a loose one only narrows the window of full relative accuracy. */
 int lhg_absmax(const float* x, long long pixels, int C, int ld, float* out, lhg_stream_t s);
@@ -209,17 +212,19 @@ int lhg_channel_sum(const float* x, long long pixels, int C, int ld, float* out,
 int lhg_bn_stats(const float* x, long long pixels, int C, int ld, float* stats,
                  float* running_mean, float* running_var, float momentum, float eps,
                  float* ws, lhg_stream_t s);
-/* y = act((x - mean)*invstd*gamma + beta + res) */
+/* y = act((x - mean)*invstd*gamma + beta + res).  y_absmax (may be NULL, else LHG_ABSMAX_WORDS zero-filled floats): max-accumulates max|y| on the way out — the
+ * lhg_absmax of the output for free, for a following GEMM in the LHG_PRECISION_F32_SPLIT_F16 mode (zero-filled slot, fp32 storage). */
 int lhg_bn_apply(const float* x, int ldx, long long pixels, int C, const float* stats,
                  const float* gamma, const float* beta, const float* res, int ldres,
-                 int act, float slope, float* y, int ldy, lhg_stream_t s);
+                 int act, float slope, float* y, int ldy, float* y_absmax, lhg_stream_t s);
 /* Backward of y = act(bn(x) + res) given gy:  g = gy * act'(y);  gres = g (if non-NULL);
  * gx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); ggamma (+)= sum g*xhat; gbeta (+)= sum g  (accumulate != 0 adds).
- * `y` is the forward OUTPUT (sign gives the activation mask).  ws: >= 8192*C floats. */
+ * `y` is the forward OUTPUT (sign gives the activation mask).  ws: >= 8192*C floats.
+ * gx_absmax (may be NULL): max-accumulates max|gx|, as y_absmax above (gx is the gy operand of the preceding conv's backward GEMMs). */
 int lhg_bn_backward(const float* gy, int ldgy, const float* x, int ldx, const float* y, int ldy,
                     long long pixels, int C, const float* stats, const float* gamma,
                     int act, float slope, float* gx, int ldgx, float* gres, int ldgres,
-                    float* ggamma, float* gbeta, int accumulate, float* ws, lhg_stream_t s);
+                    float* ggamma, float* gbeta, int accumulate, float* ws, float* gx_absmax, lhg_stream_t s);
 /* Double backward of the gx output above (WGAN-GP, ref: watermelon.py:466-473):
  * given ggx (cotangent of gx) returns ggy (cotangent of gy), gx2 (cotangent of x) and
  * ggamma2 (cotangent of gamma).  ws: >= 5*4096*C floats. */

@@ -100,6 +100,29 @@ __device__ __forceinline__ f32x4 act_grad4(f32x4 yy, int act, float slope) {
   return m;
 }
 
+// Running max|v| of what a streaming kernel writes — the tensor scale the fp16-split GEMMs need of their operands (lhg_absmax):
+// folded into the producer it costs no pass of its own.  Magnitude bits compare as unsigned (NaN > inf > finite).
+__device__ __forceinline__ unsigned amax4(unsigned m, f32x4 v) {
+#pragma unroll
+  for (int e = 0; e < 4; ++e) m = max(m, __float_as_uint(v[e]) & 0x7fffffffu);
+  return m;
+}
+// `seen`: the slot's value loaded when the workgroup started (its latency hides behind the streaming loop); only a workgroup that beat
+// it goes back to memory at all, and then re-reads before the atomic: a few dozen atomics per launch instead of one per workgroup.
+__device__ __forceinline__ unsigned amax_peek(const float* out) { return out ? *reinterpret_cast<const volatile unsigned*>(out) : 0u; }
+__device__ __forceinline__ void amax_commit(unsigned m, float* out, unsigned seen) {  // every thread of the (256-thread) workgroup calls this
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+  __shared__ unsigned red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = max(max(red[0], red[1]), max(red[2], red[3]));
+    unsigned* o = reinterpret_cast<unsigned*>(out);
+    if (m > seen && m > *reinterpret_cast<volatile unsigned*>(o)) atomicMax(o, m);
+  }
+}
+
 // ------------------------------------------------------------------ BN statistics
 template <class T>
 __global__ __launch_bounds__(256) void bn_stats_partial(const T* __restrict__ x, long long pixels, int C, int ld,
@@ -139,8 +162,11 @@ template <class T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, int ldx, long long pixels, int C,
                                                        const float* __restrict__ stats, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const T* __restrict__ res, int ldres,
-                                                       int act, float slope, T* __restrict__ y, int ldy, int lanes_c, int rows) {
+                                                       int act, float slope, T* __restrict__ y, int ldy, int lanes_c, int rows,
+                                                       float* __restrict__ y_amax) {
   const int tx = threadIdx.x % lanes_c, ty = threadIdx.x / lanes_c;
+  unsigned am = 0;
+  const unsigned seen = amax_peek(y_amax);
   for (int cb = (blockIdx.y * lanes_c + tx) * 4; cb < C; cb += gridDim.y * lanes_c * 4) {
     const f32x4 mean = ld4(stats + cb), inv = ld4(stats + C + cb);
     const f32x4 a = inv * ld4(gamma + cb);
@@ -159,8 +185,10 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act, slope);
           st4(y + (size_t)q * ldy + cb, v);
+          am = amax4(am, v);
         });
   }
+  if (y_amax) amax_commit(am, y_amax, seen);
 }
 
 // ------------------------------------------------------------------ BN backward
@@ -227,9 +255,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const T* __restrict__ gy, in
                                                     const float* __restrict__ sums, int act, float slope,
                                                     T* __restrict__ gx, int ldgx, T* __restrict__ gres, int ldgres,
                                                     float* __restrict__ ggamma, float* __restrict__ gbeta, int accumulate, int lanes_c,
-                                                    int rows) {
+                                                    int rows, float* __restrict__ gx_amax) {
   const int tx = threadIdx.x % lanes_c, ty = threadIdx.x / lanes_c;
   const float invn = 1.f / (float)pixels;
+  unsigned am = 0;
+  const unsigned seen = amax_peek(gx_amax);
   for (int cb = (blockIdx.y * lanes_c + tx) * 4; cb < C; cb += gridDim.y * lanes_c * 4) {
     const f32x4 mean = ld4(stats + cb), inv = ld4(stats + C + cb), gam = ld4(gamma + cb);
     const f32x4 sg = ld4(sums + cb), sgx = ld4(sums + C + cb);
@@ -252,9 +282,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const T* __restrict__ gy, in
           if (act != LHG_ACT_NONE) g *= act_grad4(v.c, act, slope);
           if (gres) st4(gres + (size_t)q * ldgres + cb, g);
           const f32x4 xh = (v.b - mean) * inv;
-          st4(gx + (size_t)q * ldgx + cb, k * (g - mg - xh * mgx));
+          const f32x4 o = k * (g - mg - xh * mgx);
+          st4(gx + (size_t)q * ldgx + cb, o);
+          am = amax4(am, o);
         });
   }
+  if (gx_amax) amax_commit(am, gx_amax, seen);
 }
 
 // ------------------------------------------------------------------ BN double backward (WGAN-GP)
@@ -532,21 +565,21 @@ static int bn_stats_impl(const float* x, long long pixels, int C, int ld, float*
 
 template <class T>
 static int bn_apply_impl(const float* x, int ldx, long long pixels, int C, const float* stats, const float* gamma, const float* beta,
-                         const float* res, int ldres, int act, float slope, float* y, int ldy, lhg_stream_t s) {
+                         const float* res, int ldres, int act, float slope, float* y, int ldy, float* y_absmax, lhg_stream_t s) {
   LHG_NHWC_OK(x, C, ldx, "bn_apply(x)");
   LHG_NHWC_OK(y, C, ldy, "bn_apply(y)");
   if (res) LHG_NHWC_OK(res, C, ldres, "bn_apply(res)");
   const ColMap cm = col_map(C);
-  const int nblk = grid_for((size_t)pixels, cm.rows * 4, std::max(1, 4096 / cm.gy));
+  const int nblk = grid_for((size_t)pixels, cm.rows * 4, std::max(1, 2048 / cm.gy));
   hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(nblk, cm.gy), dim3(256), 0, as_stream(s), as_act<T>(x), ldx, pixels, C, stats, gamma, beta, as_act<T>(res),
-                     ldres, act, slope, as_act<T>(y), ldy, cm.lanes_c, cm.rows);
+                     ldres, act, slope, as_act<T>(y), ldy, cm.lanes_c, cm.rows, y_absmax);
   return check_launch("bn_apply");
 }
 
 template <class T>
 static int bn_backward_impl(const float* gy, int ldgy, const float* x, int ldx, const float* y, int ldy, long long pixels, int C,
                             const float* stats, const float* gamma, int act, float slope, float* gx, int ldgx, float* gres, int ldgres,
-                            float* ggamma, float* gbeta, int accumulate, float* ws, lhg_stream_t s) {
+                            float* ggamma, float* gbeta, int accumulate, float* ws, float* gx_absmax, lhg_stream_t s) {
   LHG_NHWC_OK(gy, C, ldgy, "bn_backward(gy)");
   LHG_NHWC_OK(x, C, ldx, "bn_backward(x)");
   LHG_NHWC_OK(gx, C, ldgx, "bn_backward(gx)");
@@ -558,9 +591,9 @@ static int bn_backward_impl(const float* gy, int ldgy, const float* x, int ldx, 
   hipLaunchKernelGGL((bn_bwd_partial<T>), dim3(nblk, cm.gy), dim3(256), 0, as_stream(s), as_act<T>(gy), ldgy, as_act<T>(x), ldx, as_act<T>(y), ldy, pixels, C,
                      stats, act, slope, cm.lanes_c, cm.rows, ws);
   hipLaunchKernelGGL(reduce_partials<2>, dim3((C + 31) / 32, 2), dim3(1024), 0, as_stream(s), ws, nblk, C, sums, 0);
-  const int nb2 = grid_for((size_t)pixels, cm.rows * 4, std::max(1, 4096 / cm.gy));
+  const int nb2 = grid_for((size_t)pixels, cm.rows * 4, std::max(1, 2048 / cm.gy));
   hipLaunchKernelGGL((bn_bwd_apply<T>), dim3(nb2, cm.gy), dim3(256), 0, as_stream(s), as_act<T>(gy), ldgy, as_act<T>(x), ldx, as_act<T>(y), ldy, pixels, C, stats,
-                     gamma, sums, act, slope, as_act<T>(gx), ldgx, as_act<T>(gres), ldgres, ggamma, gbeta, accumulate, cm.lanes_c, cm.rows);
+                     gamma, sums, act, slope, as_act<T>(gx), ldgx, as_act<T>(gres), ldgres, ggamma, gbeta, accumulate, cm.lanes_c, cm.rows, gx_absmax);
   return check_launch("bn_backward");
 }
 
@@ -638,14 +671,14 @@ int lhg_bn_stats(const float* x, long long pixels, int C, int ld, float* stats, 
   return LHG_ACT_CALL(bn_stats_impl, x, pixels, C, ld, stats, running_mean, running_var, momentum, eps, ws, s);
 }
 int lhg_bn_apply(const float* x, int ldx, long long pixels, int C, const float* stats, const float* gamma, const float* beta,
-                 const float* res, int ldres, int act, float slope, float* y, int ldy, lhg_stream_t s) {
-  return LHG_ACT_CALL(bn_apply_impl, x, ldx, pixels, C, stats, gamma, beta, res, ldres, act, slope, y, ldy, s);
+                 const float* res, int ldres, int act, float slope, float* y, int ldy, float* y_absmax, lhg_stream_t s) {
+  return LHG_ACT_CALL(bn_apply_impl, x, ldx, pixels, C, stats, gamma, beta, res, ldres, act, slope, y, ldy, y_absmax, s);
 }
 int lhg_bn_backward(const float* gy, int ldgy, const float* x, int ldx, const float* y, int ldy, long long pixels, int C,
                     const float* stats, const float* gamma, int act, float slope, float* gx, int ldgx, float* gres, int ldgres,
-                    float* ggamma, float* gbeta, int accumulate, float* ws, lhg_stream_t s) {
+                    float* ggamma, float* gbeta, int accumulate, float* ws, float* gx_absmax, lhg_stream_t s) {
   return LHG_ACT_CALL(bn_backward_impl, gy, ldgy, x, ldx, y, ldy, pixels, C, stats, gamma, act, slope, gx, ldgx, gres, ldgres, ggamma, gbeta,
-                      accumulate, ws, s);
+                      accumulate, ws, gx_absmax, s);
 }
 int lhg_bn_backward_backward(const float* ggx, const float* gy, const float* x, const float* y, long long pixels, int C,
                              const float* stats, const float* gamma, int act, float slope, float* ggy, float* gx2, float* ggamma2,

@@ -369,12 +369,42 @@ def operand_absmax(t):
     the "fp32_split_f16" mode; None in every other mode.  Measured once per operand and handed to each GEMM that reads it."""
     if _mode() != _F16_SPLIT:
         return None
+    known = t.__dict__.get("_lhg_amax")
+    if known is not None and known[0] == t._version:
+        return known[1]
     p, N, H, W, Cc, ld = nhwc(t)
     out = _amax_slot(t.device)
     call("lhg_absmax", p, N * H * W, Cc, ld, ptr(out), stream_ptr())
+    tag_absmax(t, out)
     return out
 
 
+def fused_absmax_slot(device):
+    """A zeroed slot for a producer kernel that measures max|output| on its way out (lhg_bn_apply, lhg_bn_backward), or None when the
+    current modes have no use for it."""
+    if _mode() != _F16_SPLIT or _ACT_DTYPE != torch.float32 or not _FUSED_ABSMAX:
+        return None
+    return _amax_slot(device)
+
+
+def _inherit_absmax(dst, src):
+    """dst's elements are a subset of src's (or zeros): src's known max|.| bounds dst's."""
+    known = src.__dict__.get("_lhg_amax")
+    if known is not None and known[0] == src._version:
+        tag_absmax(dst, known[1])
+    return dst
+
+
+def tag_absmax(t, slot):
+    """Remember max|t| on the tensor object (with its version counter: an in-place update — autograd's gradient accumulation included —
+    invalidates it).  Only for tensors nobody writes through raw pointers after this point."""
+    if slot is not None:
+        t.__dict__["_lhg_amax"] = (t._version, slot)
+    return t
+
+
+_FUSED_ABSMAX = os.environ.get("LHG_FUSED_ABSMAX", "1") != "0"  # 0: every operand is measured by lhg_absmax (A/B measurements)
+ABSMAX_WORDS = 1  # LHG_ABSMAX_WORDS: an operand's max|x| is the maximum of this many floats (include/lhg_hip.h)
 _AMAX_POOL = {}  # (device, stream, capturing) -> [zero-filled tensor, next free index]; a slot is handed out once
 
 
@@ -385,10 +415,10 @@ def _amax_slot(device):
     key = (device, stream_ptr(), torch.cuda.is_current_stream_capturing())
     pool = _AMAX_POOL.get(key)
     if pool is None or pool[1] >= pool[0].numel():
-        pool = _AMAX_POOL[key] = [torch.zeros((1024,), dtype=torch.float32, device=device), 0]
+        pool = _AMAX_POOL[key] = [torch.zeros((1024 * ABSMAX_WORDS,), dtype=torch.float32, device=device), 0]
     i = pool[1]
-    pool[1] = i + 1
-    return pool[0][i:i + 1]
+    pool[1] = i + ABSMAX_WORDS
+    return pool[0][i:i + ABSMAX_WORDS]
 
 
 def apply_env_precision() -> None:
@@ -866,7 +896,10 @@ class BatchNormTrainFn(TrackedFunction):
         pres, ldres = (None, 0)
         if res is not None:
             pres, _, _, _, _, ldres = nhwc(res)
-        call("lhg_bn_apply", px, ldx, pixels, Cc, ptr(stats), ptr(gamma), ptr(beta), pres, ldres, act, float(slope), py, ldy, stream_ptr())
+        y_amax = fused_absmax_slot(x.device)  # max|y| measured by the kernel that writes y: the next conv's GEMMs need no pass of their own
+        call("lhg_bn_apply", px, ldx, pixels, Cc, ptr(stats), ptr(gamma), ptr(beta), pres, ldres, act, float(slope), py, ldy, ptr(y_amax),
+             stream_ptr())
+        tag_absmax(y, y_amax)
         ctx.save_for_backward(x, y, gamma, stats)
         ctx.act, ctx.slope, ctx.has_res = act, slope, res is not None
         ctx.beta = beta if ctx.needs_input_grad[2] else None
@@ -897,8 +930,10 @@ def bn_backward_raw(gy, x, y, gamma, stats, act, slope, want_res, ggamma, gbeta,
     py, _, _, _, _, ldy = nhwc(y)
     gx = new_nhwc(N, H, W, Cc, gy.device)
     gres = new_nhwc(N, H, W, Cc, gy.device) if want_res else None
+    gx_amax = fused_absmax_slot(gy.device)  # gx is the gy of the preceding conv's two backward GEMMs
     call("lhg_bn_backward", pg, ldg, px, ldx, py, ldy, N * H * W, Cc, ptr(stats), ptr(gamma), act, float(slope),
-         ptr(gx), Cc, ptr(gres), Cc, ptr(ggamma), ptr(gbeta), int(accumulate), ptr(_bn_ws(Cc, gy.device)), stream_ptr())
+         ptr(gx), Cc, ptr(gres), Cc, ptr(ggamma), ptr(gbeta), int(accumulate), ptr(_bn_ws(Cc, gy.device)), ptr(gx_amax), stream_ptr())
+    tag_absmax(gx, gx_amax)
     return gx, gres
 
 
@@ -952,7 +987,7 @@ class MaxPool2x2Fn(Function):
         y = new_nhwc(N, H // 2, W // 2, Cc, x.device)
         call("lhg_maxpool2x2_forward", px, N, H, W, Cc, ldx, ptr(y), Cc, stream_ptr())
         ctx.save_for_backward(x)
-        return y
+        return _inherit_absmax(y, x)  # max|pool(x)| <= max|x|: any upper bound is a valid tensor scale
 
     @staticmethod
     def backward(ctx, gy):
@@ -961,7 +996,7 @@ class MaxPool2x2Fn(Function):
         pg, _, _, _, _, ldg = nhwc(gy)
         gx = new_nhwc(N, H, W, Cc, x.device)
         call("lhg_maxpool2x2_backward", px, ldx, pg, ldg, N, H, W, Cc, ptr(gx), Cc, stream_ptr())
-        return gx
+        return _inherit_absmax(gx, gy)  # gx holds gy's values and zeros
 
 
 # --------------------------------------------------------------------------- sigmoid head (planar output)
