@@ -780,11 +780,10 @@ static int launch_gg_split(GGParams& p, hipStream_t st) {
   const unsigned wb = (unsigned)wp_bytes;
   auto blocks = [&](int bm, int bn) { return (unsigned)(((g.M + bm - 1) / bm) * (p.rows_pad / bn)); };
   const bool n128 = p.rows_pad % 128 == 0;
-  constexpr int NV = 8;  // 3, 4: eight consumer waves (two per SIMD) on the 128x128 / 128x64 tiles; 5..7 (fp16 planes only): four tiles of look-ahead
+  constexpr int NV = 5;  // 3, 4: eight consumer waves (two per SIMD) on the 128x128 / 128x64 tiles
   const bool f16 = split_f16();
   if (f16) LHG_REQUIRE(p.a_amax != nullptr && p.w_amax != nullptr, "gather-GEMM (fp32_split_f16 mode): the operand's absmax pointer is missing (lhg_absmax)");
   auto valid = [&](int v) {
-    if (v >= 5) return f16 && (v != 7 || n128);
     return (v == 0 || v == 3) ? n128 : (NP == 3 || f16 || v < 3);
   };
   auto run = [&](int v) {
@@ -804,9 +803,6 @@ static int launch_gg_split(GGParams& p, hipStream_t st) {
         case 0: hipLaunchKernelGGL((gg3s_kernel<128, 128, 2, 2, 32, float, 4, _Float16>), dim3(blocks(128, 128)), dim3(512), 0, st, p, ib, wb); break;
         case 1: hipLaunchKernelGGL((gg3s_kernel<128, 64, 2, 2, 32, float, 4, _Float16>), dim3(blocks(128, 64)), dim3(512), 0, st, p, ib, wb); break;
         case 2: hipLaunchKernelGGL((gg3s_kernel<64, 64, 2, 2, 32, float, 4, _Float16>), dim3(blocks(64, 64)), dim3(512), 0, st, p, ib, wb); break;
-        case 5: hipLaunchKernelGGL((gg3s_kernel<64, 64, 2, 2, 32, float, 4, _Float16, 4>), dim3(blocks(64, 64)), dim3(512), 0, st, p, ib, wb); break;
-        case 6: hipLaunchKernelGGL((gg3s_kernel<128, 64, 2, 2, 32, float, 4, _Float16, 4>), dim3(blocks(128, 64)), dim3(512), 0, st, p, ib, wb); break;
-        case 7: hipLaunchKernelGGL((gg3s_kernel<128, 128, 2, 1, 32, float, 4, _Float16, 4>), dim3(blocks(128, 128)), dim3(512), 0, st, p, ib, wb); break;
         default: break;
       }
     } else {
