@@ -278,7 +278,12 @@ int lhg_asm_from_spectrum(const float* spectrum, int planes, int rows0, int cols
                           float* out_a, float* out_b, float* out_complex, int out_mode,
                           float* ws, size_t ws_bytes, const float* twiddle_rows, const float* twiddle_cols,
                           lhg_stream_t s);
-/* twiddle[k] = exp(-2 pi i k / n), k < n, computed in double on the device. */
+/* The `twiddle_rows` / `twiddle_cols` table of a transform length n: lhg_fft_table_floats(n) floats, filled by lhg_fft_twiddles.
+ * n = 2^a 3^b in [16, 4096] (<= 3072 with a factor 3): twiddle[k] = exp(-2 pi i k / n), k < n (2n floats), computed in double on the
+ * device.  Any other n in [16, 8192] runs as a Bluestein (chirp-z) convolution of power-of-two length m >= 2n - 1 inside the same
+ * kernels; its table is [m twiddles of length m][n chirp values exp(i pi j^2 / n)][FFT_m(wrapped chirp) / m].
+ * ref: torch.fft.fft2 / ifft2 accept any extent, angular_spectrum_method.py:382-383 (e.g. 192 + 2*320 = 832 = 2^6 * 13). */
+long long lhg_fft_table_floats(int n);
 int lhg_fft_twiddles(float* twiddle, int n, lhg_stream_t s);
 
 /* ------------------------------------------------------------------ AP2POH tail (A6 A7), forward and backward

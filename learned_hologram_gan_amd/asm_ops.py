@@ -29,14 +29,15 @@ def twiddles(n: int, device) -> torch.Tensor:
     key = (n, str(device))
     t = _twiddle_cache.get(key)
     if t is None:
-        t = torch.empty((n, 2), dtype=torch.float32, device=device)
+        floats = int(native.load().lhg_fft_table_floats(n))  # 2n for a direct transform, the Bluestein table otherwise
+        t = torch.empty((floats // 2, 2), dtype=torch.float32, device=device)
         call("lhg_fft_twiddles", ptr(t), n, stream_ptr())
         _twiddle_cache[key] = t
     return t
 
 
-def supported_extent(n: int) -> bool:
-    """Lengths the LDS FFT handles: 2^a * 3^b in [16, 4096], at most 3072 with a factor 3 (radix 4 / 2 / 3
+def smooth_extent(n: int) -> bool:
+    """Lengths the LDS FFT transforms directly: 2^a * 3^b in [16, 4096], at most 3072 with a factor 3 (radix 4 / 2 / 3
     stages); 4K frames use 2304 x 4096."""
     if not 16 <= n <= (3072 if n % 3 == 0 else 4096):
         return False
@@ -45,6 +46,13 @@ def supported_extent(n: int) -> bool:
     while n % 3 == 0:
         n //= 3
     return n == 1
+
+
+def supported_extent(n: int) -> bool:
+    """Lengths the fused operator handles: the direct ones, and ANY length in [16, 8192] through a Bluestein convolution of
+    power-of-two length >= 2n - 1 (at most 16384) inside the same kernels: 832 = 192 + 2*320 (the CLI's default pad on the 192^2
+    frames), 2800 x 4976 (a 4K frame with that pad)."""
+    return smooth_extent(n) or 16 <= n <= 8192
 
 
 @dataclass

@@ -131,6 +131,8 @@ __device__ void lds_fft(float2* buf, int n, int nf, int stride, const float2* tw
     case 1024: return stages_pow2<1024, 1, INV>(buf, nf, stride, tw);
     case 2048: return stages_pow2<2048, 1, INV>(buf, nf, stride, tw);
     case 4096: return stages_pow2<4096, 1, INV>(buf, nf, stride, tw);
+    case 8192: return stages_pow2<8192, 1, INV>(buf, nf, stride, tw);    // Bluestein convolution lengths of the large non-smooth extents
+    case 16384: return stages_pow2<16384, 1, INV>(buf, nf, stride, tw);  // (512 / 1024 threads, twiddles read from global memory)
     default: break;
   }
   const int nthreads = blockDim.x, tid = threadIdx.x;
@@ -263,21 +265,73 @@ __device__ __forceinline__ float2 apply_filter(float2 z, float2 f, int op) {
   }
 }
 
+// ---------------------------------------------------------------------------------------- Bluestein (chirp-z) lengths
+// A length n outside 2^a 3^b (832 = 2^6 13: the 192^2 frame with the CLI's default pad 320) is transformed as a circular convolution of
+// power-of-two length m >= 2n - 1 with the chirp c[j] = exp(i pi j^2 / n):
+//     X[k] = conj(c[k]) * sum_j (x[j] conj(c[j])) c[k - j]            (n k = (j^2 + k^2 - (k - j)^2) / 2)
+// = conj(c) . IFFT_m( FFT_m(x conj(c), zero-extended) . FFT_m(c wrapped) ): two Stockham transforms of length m on the same LDS line plus
+// three pointwise passes.  The table lhg_fft_twiddles builds for such an n is [m twiddles of length m][n chirp values][m values of
+// FFT_m(c wrapped) / m], all evaluated from exact integer j^2 mod 2n in double.  The inverse transform is conj(forward(conj(x))).
+// tw: the m twiddles (LDS); tab: the table in global memory.  All threads of the workgroup call this.
+template <bool INV>
+__device__ void bluestein_fft(float2* buf, int n, int m, int nf, int stride, const float2* tw, const float2* __restrict__ tab) {
+  const float2* chirp = tab + m;
+  const float2* bf = tab + m + n;
+  const int tid = threadIdx.x, nth = blockDim.x;
+  for (int i = tid; i < nf * m; i += nth) {
+    const int f = i / m, j = i - f * m;
+    float2 z = make_float2(0.f, 0.f);
+    if (j < n) {
+      z = buf[f * stride + j];
+      if (INV) z.y = -z.y;
+      const float2 c = chirp[j];
+      z = cmul(z, make_float2(c.x, -c.y));
+    }
+    buf[f * stride + j] = z;
+  }
+  __syncthreads();
+  lds_fft<false>(buf, m, nf, stride, tw);
+  for (int i = tid; i < nf * m; i += nth) {
+    const int f = i / m, j = i - f * m;
+    buf[f * stride + j] = cmul(buf[f * stride + j], bf[j]);
+  }
+  __syncthreads();
+  lds_fft<true>(buf, m, nf, stride, tw);
+  for (int i = tid; i < nf * n; i += nth) {
+    const int f = i / n, k = i - f * n;
+    const float2 c = chirp[k];
+    float2 z = cmul(buf[f * stride + k], make_float2(c.x, -c.y));
+    if (INV) z.y = -z.y;
+    buf[f * stride + k] = z;
+  }
+  __syncthreads();
+}
+
+// one 1-D transform per line: directly (m == 0) or through Bluestein's convolution of length m
+template <bool INV>
+__device__ __forceinline__ void fft_line(float2* buf, int n, int m, int nf, int stride, const float2* tw, const float2* __restrict__ tab) {
+  if (m == 0) lds_fft<INV>(buf, n, nf, stride, tw);
+  else bluestein_fft<INV>(buf, n, m, nf, stride, tw, tab);
+}
+
 extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 
 // ---------------------------------------------------------------------------------------- pass 1
 // grid.x = ceil(planes*rows0 / nf); block 256 threads; LDS: tw[n] + nf*n complex
-__global__ __launch_bounds__(256) void rows_forward_kernel(const float* __restrict__ in_a, const float* __restrict__ in_b, int in_mode,
-                                                           float phase_scale, int total_rows, int cols0, int pad_c, int n, int nf,
-                                                           const float2* __restrict__ twg, float2* __restrict__ t1) {
-  float2* tw = reinterpret_cast<float2*>(lds_raw);
-  float2* buf = tw + n;
-  const int tid = threadIdx.x;
-  for (int i = tid; i < n; i += 256) tw[i] = twg[i];
-  for (int i = tid; i < nf * n; i += 256) buf[i] = make_float2(0.f, 0.f);
+__global__ __launch_bounds__(1024) void rows_forward_kernel(const float* __restrict__ in_a, const float* __restrict__ in_b, int in_mode,
+                                                            float phase_scale, int total_rows, int cols0, int pad_c, int n, int m, int nf,
+                                                            int tw_in_lds, const float2* __restrict__ twg, float2* __restrict__ t1) {
+  const int L = m ? m : n;  // LDS line length (Bluestein: the convolution length)
+  float2* twl = reinterpret_cast<float2*>(lds_raw);
+  float2* buf = tw_in_lds ? twl + L : twl;
+  const float2* tw = tw_in_lds ? twl : twg;  // the longest lines leave no room for the twiddles: read them from global memory
+  const int tid = threadIdx.x, nth = blockDim.x;
+  if (tw_in_lds)
+    for (int i = tid; i < L; i += nth) twl[i] = twg[i];
+  for (int i = tid; i < nf * L; i += nth) buf[i] = make_float2(0.f, 0.f);
   __syncthreads();
   const int row0 = blockIdx.x * nf;
-  for (int i = tid; i < nf * cols0; i += 256) {
+  for (int i = tid; i < nf * cols0; i += nth) {
     const int f = i / cols0, x = i - f * cols0;
     const int row = row0 + f;
     if (row < total_rows) {
@@ -292,15 +346,15 @@ __global__ __launch_bounds__(256) void rows_forward_kernel(const float* __restri
         const float a = in_mode == IN_POLAR ? in_a[o] : 1.f;
         z = make_float2(a * cs, a * sn);
       }
-      buf[f * n + pad_c + x] = z;
+      buf[f * L + pad_c + x] = z;
     }
   }
   __syncthreads();
-  lds_fft<false>(buf, n, nf, n, tw);
-  for (int i = tid; i < nf * n; i += 256) {
+  fft_line<false>(buf, n, m, nf, L, tw, twg);
+  for (int i = tid; i < nf * n; i += nth) {
     const int f = i / n;
     const int row = row0 + f;
-    if (row < total_rows) t1[(size_t)row * n + (i - f * n)] = buf[i];
+    if (row < total_rows) t1[(size_t)row * n + (i - f * n)] = buf[f * L + (i - f * n)];
   }
 }
 
@@ -309,6 +363,8 @@ struct ColsParams {
   const float2* src; int src_rows, src_off;   // rows present in src (rows0 or R) and their offset inside R
   float2* dst; int dst_rows, dst_off;
   int planes, R, C, G;                        // G columns per workgroup
+  int M;                                      // 0, or the Bluestein convolution length of R
+  int tw_in_lds;                              // 0: the line leaves no room for the twiddles in LDS
   int do_fwd, do_inv;
   float scale;
   const float2* f1; const int* f1_index; int f1_op;
@@ -317,13 +373,16 @@ struct ColsParams {
 };
 
 __global__ __launch_bounds__(1024) void cols_filter_kernel(const ColsParams p) {
-  float2* tw = reinterpret_cast<float2*>(lds_raw);
-  float2* buf = tw + p.R;
-  const int stride = p.R + 1;
+  const int L = p.M ? p.M : p.R;
+  float2* twl = reinterpret_cast<float2*>(lds_raw);
+  float2* buf = p.tw_in_lds ? twl + L : twl;
+  const float2* tw = p.tw_in_lds ? twl : p.tw;
+  const int stride = L + 1;
   const int tid = threadIdx.x, nth = blockDim.x;
   const int groups = p.C / p.G;
   const int plane = blockIdx.x / groups, c0 = (blockIdx.x - plane * groups) * p.G;
-  for (int i = tid; i < p.R; i += nth) tw[i] = p.tw[i];
+  if (p.tw_in_lds)
+    for (int i = tid; i < L; i += nth) twl[i] = p.tw[i];
   // load G columns (zero outside the stored rows)
   const int lg = __ffs(p.G) - 1, gm = p.G - 1;  // G is a power of two
   for (int i = tid; i < p.R * p.G; i += nth) {
@@ -334,7 +393,7 @@ __global__ __launch_bounds__(1024) void cols_filter_kernel(const ColsParams p) {
     buf[g * stride + r] = z;
   }
   __syncthreads();
-  if (p.do_fwd) lds_fft<false>(buf, p.R, p.G, stride, tw);
+  if (p.do_fwd) fft_line<false>(buf, p.R, p.M, p.G, stride, tw, p.tw);
   const int s1 = p.f1_op ? (p.f1_index ? p.f1_index[plane] : 0) : 0;
   const int s2 = p.f2_op ? (p.f2_index ? p.f2_index[plane] : 0) : 0;
   if (p.f1_op || p.f2_op || p.scale != 1.f) {
@@ -348,7 +407,7 @@ __global__ __launch_bounds__(1024) void cols_filter_kernel(const ColsParams p) {
     }
     __syncthreads();
   }
-  if (p.do_inv) lds_fft<true>(buf, p.R, p.G, stride, tw);
+  if (p.do_inv) fft_line<true>(buf, p.R, p.M, p.G, stride, tw, p.tw);
   for (int i = tid; i < p.dst_rows * p.G; i += nth) {
     const int g = i & gm, r = i >> lg;
     p.dst[((size_t)plane * p.dst_rows + r) * p.C + c0 + g] = buf[g * stride + r + p.dst_off];
@@ -358,26 +417,29 @@ __global__ __launch_bounds__(1024) void cols_filter_kernel(const ColsParams p) {
 #include "asm_cols_reg.inc"
 
 // ---------------------------------------------------------------------------------------- pass 3
-__global__ __launch_bounds__(256) void rows_inverse_kernel(const float2* __restrict__ t2, int total_rows, int cols0, int pad_c, int n, int nf,
-                                                           const float2* __restrict__ twg, float* __restrict__ out_a, float* __restrict__ out_b,
-                                                           float2* __restrict__ out_c, int out_mode) {
-  float2* tw = reinterpret_cast<float2*>(lds_raw);
-  float2* buf = tw + n;
-  const int tid = threadIdx.x;
-  for (int i = tid; i < n; i += 256) tw[i] = twg[i];
+__global__ __launch_bounds__(1024) void rows_inverse_kernel(const float2* __restrict__ t2, int total_rows, int cols0, int pad_c, int n, int m, int nf,
+                                                            int tw_in_lds, const float2* __restrict__ twg, float* __restrict__ out_a,
+                                                            float* __restrict__ out_b, float2* __restrict__ out_c, int out_mode) {
+  const int L = m ? m : n;
+  float2* twl = reinterpret_cast<float2*>(lds_raw);
+  float2* buf = tw_in_lds ? twl + L : twl;
+  const float2* tw = tw_in_lds ? twl : twg;
+  const int tid = threadIdx.x, nth = blockDim.x;
+  if (tw_in_lds)
+    for (int i = tid; i < L; i += nth) twl[i] = twg[i];
   const int row0 = blockIdx.x * nf;
-  for (int i = tid; i < nf * n; i += 256) {
+  for (int i = tid; i < nf * n; i += nth) {
     const int f = i / n;
     const int row = row0 + f;
-    buf[i] = row < total_rows ? t2[(size_t)row * n + (i - f * n)] : make_float2(0.f, 0.f);
+    buf[f * L + (i - f * n)] = row < total_rows ? t2[(size_t)row * n + (i - f * n)] : make_float2(0.f, 0.f);
   }
   __syncthreads();
-  lds_fft<true>(buf, n, nf, n, tw);
-  for (int i = tid; i < nf * cols0; i += 256) {
+  fft_line<true>(buf, n, m, nf, L, tw, twg);
+  for (int i = tid; i < nf * cols0; i += nth) {
     const int f = i / cols0, x = i - f * cols0;
     const int row = row0 + f;
     if (row >= total_rows) continue;
-    const float2 z = buf[f * n + pad_c + x];
+    const float2 z = buf[f * L + pad_c + x];
     const size_t o = (size_t)row * cols0 + x;
     if (out_mode == OUT_COMPLEX) {
       out_c[o] = z;
@@ -387,6 +449,33 @@ __global__ __launch_bounds__(256) void rows_inverse_kernel(const float2* __restr
       if (out_c) out_c[o] = z;
     }
   }
+}
+
+// Bluestein table pieces (after the m twiddles): chirp c[j] = exp(i pi j^2 / n), j < n, with j^2 reduced mod 2n in integers
+__global__ void chirp_kernel(float2* chirp, int n) {
+  const int j = blockIdx.x * blockDim.x + threadIdx.x;
+  if (j >= n) return;
+  const long long r = ((long long)j * j) % (2ll * n);
+  double s, c;
+  sincospi((double)r / (double)n, &s, &c);
+  chirp[j] = make_float2((float)c, (float)s);
+}
+
+// bf = FFT_m(c wrapped: b[j] = c[j], b[m - j] = c[j], 0 elsewhere) / m.  One workgroup; LDS: m twiddles + m values.
+__global__ __launch_bounds__(1024) void bluestein_filter_kernel(float2* tab, int n, int m) {
+  float2* buf = reinterpret_cast<float2*>(lds_raw);
+  const float2* tw = tab;  // global memory: one workgroup, once per length
+  const float2* chirp = tab + m;
+  for (int i = threadIdx.x; i < m; i += blockDim.x) {
+    float2 b = make_float2(0.f, 0.f);
+    if (i < n) b = chirp[i];
+    else if (m - i < n) b = chirp[m - i];
+    buf[i] = b;
+  }
+  __syncthreads();
+  lds_fft<false>(buf, m, 1, m, tw);
+  const float inv = 1.f / (float)m;
+  for (int i = threadIdx.x; i < m; i += blockDim.x) tab[m + n + i] = make_float2(buf[i].x * inv, buf[i].y * inv);
 }
 
 __global__ void twiddle_kernel(float2* tw, int n) {
@@ -406,6 +495,16 @@ static bool smooth_in_range(int n) {
   while (n % 3 == 0) n /= 3;
   return n == 1;
 }
+// Bluestein convolution length for an extent the Stockham stages do not cover directly: the power of two >= 2n - 1, at most 16384
+// (so n <= 8192: 2800 x 4976, the 4K frame with the CLI's pad 320, is 8192 / 16384); 0 = direct transform (or unsupported: check with
+// length_supported)
+static int bluestein_len(int n) {
+  if (smooth_in_range(n) || n < 16 || 2 * n - 1 > 16384) return 0;
+  int m = 64;
+  while (m < 2 * n - 1) m <<= 1;
+  return m;  // (a 2^a 3^b length in between was measured: the generic stages cost more than the shorter line saves)
+}
+static bool length_supported(int n) { return smooth_in_range(n) || bluestein_len(n) != 0; }
 // butterflies per thread per stage are capped at MAX_IT: n*nf <= 16*threads (radix 4 / 2) or 12*threads (radix 3)
 static int fft_budget(int n) { return n % 3 == 0 ? 12 : 16; }
 
@@ -413,6 +512,10 @@ static int rows_nf(int n) {
   const int cap = fft_budget(n) * 256;
   return std::max(1, std::min(64, cap / n));
 }
+// threads of a row-pass workgroup: 256, more only for lines longer than 16 butterfly inputs per thread (Bluestein lengths 8192 / 16384)
+static int rows_threads(int L) { return L <= 4096 ? 256 : (L <= 8192 ? 512 : 1024); }
+// twiddles go to LDS next to the lines when both fit
+static bool tw_fits(size_t line_bytes, int L) { return line_bytes + (size_t)L * sizeof(float2) <= 150 * 1024; }
 
 static int set_dyn_lds(const void* fn, size_t bytes) {
   if (bytes > 160 * 1024) return fail(LHG_E_ARG, "asm: LDS request %zu exceeds 160 KiB", bytes);
@@ -455,13 +558,15 @@ static int run_rows_forward(const float* in_a, const float* in_b, int in_mode, f
                             int pad_c, int cols, const float* tw_cols, float2* t1, hipStream_t st) {
   if (asm_reg_enabled() && cols == 1024) return run_rows_forward_reg<32, 8>(in_a, in_b, in_mode, phase_scale, planes * rows0, cols0, pad_c, tw_cols, t1, st);
   if (asm_reg_enabled() && cols == 256) return run_rows_forward_reg<16, 16>(in_a, in_b, in_mode, phase_scale, planes * rows0, cols0, pad_c, tw_cols, t1, st);
-  const int nf = rows_nf(cols);
-  const size_t lds = (size_t)(cols + nf * cols) * sizeof(float2);
+  const int m = bluestein_len(cols), L = m ? m : cols;
+  const int nf = rows_nf(L);
+  const int tw_lds = tw_fits((size_t)nf * L * sizeof(float2), L);
+  const size_t lds = (size_t)((tw_lds ? L : 0) + nf * L) * sizeof(float2);
   int rc = set_dyn_lds(reinterpret_cast<const void*>(rows_forward_kernel), lds);
   if (rc) return rc;
   const int total_rows = planes * rows0;
-  hipLaunchKernelGGL(rows_forward_kernel, dim3((total_rows + nf - 1) / nf), dim3(256), lds, st, in_a, in_b, in_mode, phase_scale,
-                     total_rows, cols0, pad_c, cols, nf, reinterpret_cast<const float2*>(tw_cols), t1);
+  hipLaunchKernelGGL(rows_forward_kernel, dim3((total_rows + nf - 1) / nf), dim3(rows_threads(L)), lds, st, in_a, in_b, in_mode, phase_scale,
+                     total_rows, cols0, pad_c, cols, m, nf, tw_lds, reinterpret_cast<const float2*>(tw_cols), t1);
   return check_launch("rows_forward");
 }
 
@@ -469,12 +574,14 @@ static int run_rows_inverse(const float2* t2, int planes, int rows0, int cols0, 
                             float* out_b, float* out_c, int out_mode, hipStream_t st) {
   if (asm_reg_enabled() && cols == 1024) return run_rows_inverse_reg<32, 8>(t2, planes * rows0, cols0, pad_c, tw_cols, out_a, out_b, out_c, out_mode, st);
   if (asm_reg_enabled() && cols == 256) return run_rows_inverse_reg<16, 16>(t2, planes * rows0, cols0, pad_c, tw_cols, out_a, out_b, out_c, out_mode, st);
-  const int nf = rows_nf(cols);
-  const size_t lds = (size_t)(cols + nf * cols) * sizeof(float2);
+  const int m = bluestein_len(cols), L = m ? m : cols;
+  const int nf = rows_nf(L);
+  const int tw_lds = tw_fits((size_t)nf * L * sizeof(float2), L);
+  const size_t lds = (size_t)((tw_lds ? L : 0) + nf * L) * sizeof(float2);
   int rc = set_dyn_lds(reinterpret_cast<const void*>(rows_inverse_kernel), lds);
   if (rc) return rc;
   const int total_rows = planes * rows0;
-  hipLaunchKernelGGL(rows_inverse_kernel, dim3((total_rows + nf - 1) / nf), dim3(256), lds, st, t2, total_rows, cols0, pad_c, cols, nf,
+  hipLaunchKernelGGL(rows_inverse_kernel, dim3((total_rows + nf - 1) / nf), dim3(rows_threads(L)), lds, st, t2, total_rows, cols0, pad_c, cols, m, nf, tw_lds,
                      reinterpret_cast<const float2*>(tw_cols), out_a, out_b, reinterpret_cast<float2*>(out_c), out_mode);
   return check_launch("rows_inverse");
 }
@@ -496,16 +603,20 @@ static int run_cols(ColsParams& p, hipStream_t st) {
     if (p.R == 256) return run_cols_reg<16, 16>(p, st);
   }
   // G columns per workgroup: 16 (128-byte segments) while G*R <= 16*threads keeps <= MAX_IT butterflies per thread
+  p.M = bluestein_len(p.R);
+  const int L = p.M ? p.M : p.R;  // LDS line length
   int G = 16;
-  while (G > 1 && (size_t)G * (p.R + 1) * sizeof(float2) + (size_t)p.R * sizeof(float2) > 150 * 1024) G >>= 1;
+  while (G > 1 && (size_t)G * (L + 1) * sizeof(float2) + (size_t)L * sizeof(float2) > 150 * 1024) G >>= 1;
+  p.tw_in_lds = tw_fits((size_t)G * (L + 1) * sizeof(float2), L);
   int threads = 1024;
-  const long long budget = fft_budget(p.R);
-  while (G > 1 && (long long)G * p.R > budget * threads) G >>= 1;
-  if ((long long)G * p.R > budget * threads) return fail(LHG_E_ARG, "asm: column length %d unsupported", p.R);
+  const long long budget = fft_budget(L);
+  while (G > 1 && (long long)G * L > budget * threads) G >>= 1;
+  if ((long long)G * L > budget * threads) return fail(LHG_E_ARG, "asm: column length %d unsupported", p.R);
   while (G > 1 && p.C % G != 0) G >>= 1;
-  while (threads > 64 && (long long)G * p.R <= 2ll * threads) threads >>= 1;  // small transforms: fewer idle waves
+  while (threads > 64 && (long long)G * L <= 2ll * threads) threads >>= 1;  // small transforms: fewer idle waves
   p.G = G;
-  const size_t lds = ((size_t)G * (p.R + 1) + p.R) * sizeof(float2);
+  p.tw_in_lds = tw_fits((size_t)G * (L + 1) * sizeof(float2), L);
+  const size_t lds = ((size_t)G * (L + 1) + (p.tw_in_lds ? L : 0)) * sizeof(float2);
   int rc = set_dyn_lds(reinterpret_cast<const void*>(cols_filter_kernel), lds);
   if (rc) return rc;
   hipLaunchKernelGGL(cols_filter_kernel, dim3(p.planes * (p.C / G)), dim3(threads), lds, st, p);
@@ -515,7 +626,8 @@ static int run_cols(ColsParams& p, hipStream_t st) {
 static int check_geometry(int planes, int rows0, int cols0, int pad_r, int pad_c, const char* what) {
   const int R = rows0 + 2 * pad_r, C = cols0 + 2 * pad_c;
   LHG_REQUIRE(planes > 0 && rows0 > 0 && cols0 > 0 && pad_r >= 0 && pad_c >= 0, "%s: bad extents", what);
-  LHG_REQUIRE(smooth_in_range(R) && smooth_in_range(C), "%s: padded extents %dx%d must be 2^a*3^b in [16,4096] (<=3072 with a factor 3)", what, R, C);
+  LHG_REQUIRE(length_supported(R) && length_supported(C),
+              "%s: padded extents %dx%d: each must be 2^a*3^b in [16,4096] (<=3072 with a factor 3) or any length in [16,8192] (Bluestein)", what, R, C);
   return LHG_OK;
 }
 
@@ -531,10 +643,27 @@ using namespace lhg;
 
 extern "C" {
 
+long long lhg_fft_table_floats(int n) {
+  const int m = n > 0 ? bluestein_len(n) : 0;
+  return m ? 2ll * (2 * m + n) : 2ll * std::max(n, 0);
+}
+
 int lhg_fft_twiddles(float* twiddle, int n, lhg_stream_t s) {
   LHG_REQUIRE(n > 0, "fft_twiddles: n must be positive");
-  hipLaunchKernelGGL(twiddle_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(s), reinterpret_cast<float2*>(twiddle), n);
-  return check_launch("twiddles");
+  float2* tab = reinterpret_cast<float2*>(twiddle);
+  const int m = bluestein_len(n);
+  if (!m) {
+    hipLaunchKernelGGL(twiddle_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(s), tab, n);
+    return check_launch("twiddles");
+  }
+  // Bluestein table: [m twiddles of length m][n chirp values][FFT_m(wrapped chirp) / m]
+  hipLaunchKernelGGL(twiddle_kernel, dim3((m + 255) / 256), dim3(256), 0, as_stream(s), tab, m);
+  hipLaunchKernelGGL(chirp_kernel, dim3((n + 255) / 256), dim3(256), 0, as_stream(s), tab + m, n);
+  const size_t lds = (size_t)m * sizeof(float2);
+  int rc = set_dyn_lds(reinterpret_cast<const void*>(bluestein_filter_kernel), lds);
+  if (rc) return rc;
+  hipLaunchKernelGGL(bluestein_filter_kernel, dim3(1), dim3(rows_threads(m)), lds, as_stream(s), tab, n, m);
+  return check_launch("bluestein table");
 }
 
 int lhg_asm_propagate(const float* in_a, const float* in_b, int in_mode, float phase_scale, int planes, int rows0, int cols0, int pad_r,

@@ -71,6 +71,7 @@ _SIGNATURES = {
     "lhg_asm_propagate": [_p, _p, _i, _f, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _sz, _p, _p, _p],
     "lhg_asm_to_spectrum": [_p, _p, _i, _f, _i, _i, _i, _i, _i, _p, _p, _p, _sz, _p, _p, _p],
     "lhg_asm_from_spectrum": [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _sz, _p, _p, _p],
+    "lhg_fft_table_floats": [_i],
     "lhg_fft_twiddles": [_p, _i, _p],
     "lhg_symconv_field": [_p, _i, _i, _i, _p, _p, _p, _p, _p],
     "lhg_double_phase_encode": [_p, _p, _i, _i, _i, _p, _p],
@@ -84,7 +85,7 @@ _SIGNATURES = {
     "lhg_psnr_ssim": [_p, _p, _i, _i, _i, _p, _p, _sz, _p],
     "lhg_adam_step": [_p, _p, _p, _p, _ll, _f, _f, _f, _f, _i, _p],
 }
-_RESTYPE = {"lhg_last_error": C.c_char_p, "lhg_packed_weight_floats": C.c_longlong, "lhg_conv2d_thin_wgrad_workspace": C.c_size_t, "lhg_psnr_ssim_workspace": C.c_size_t}
+_RESTYPE = {"lhg_last_error": C.c_char_p, "lhg_packed_weight_floats": C.c_longlong, "lhg_fft_table_floats": C.c_longlong, "lhg_conv2d_thin_wgrad_workspace": C.c_size_t, "lhg_psnr_ssim_workspace": C.c_size_t}
 
 _lib = None
 

@@ -429,17 +429,71 @@ def test_asm_4k_geometry_radix3():
     assert rel_err(torch.cat((ha, ta)).cpu(), a) < PARITY
 
 
-def test_non_power_of_two_extent_uses_rocfft_route():
-    """192 + 2*320 = 832 = 2^6 * 13 (the reference CLI default for 192^2 frames): served by torch.fft on the GPU."""
-    fx = _fixed(192, 192, 320, 0.45)
-    assert not fx._geom.supported()
+@pytest.mark.parametrize("r0,c0,pad", [(192, 192, 320), (100, 140, 21), (77, 90, 5), (64, 2100, 4), (64, 4848, 1)], ids=lambda v: str(v))
+def test_non_smooth_extents_run_on_the_hip_bluestein_path(r0, c0, pad):
+    """192 + 2*320 = 832 = 2^6 * 13 (the reference CLI default for 192^2 frames; torch.fft takes any extent,
+    angular_spectrum_method.py:382-392) and other lengths outside 2^a 3^b: the fused HIP operator transforms them as Bluestein
+    convolutions of power-of-two length inside the same three passes (2100 + 2*131 = 2362 columns -> length 8192, 4848 + 2*75 = 4998 ->
+    16384: the sizes a 4K frame with that pad needs).  Forward values against the oracle, gradients against the oracle's autograd."""
+    from learned_hologram_gan_amd import asm_ops
+
+    fx = _fixed(r0, c0, pad, 0.45)
+    R, C = fx.samplingRowNum, fx.samplingColNum
+    assert fx._geom.supported() and not (asm_ops.smooth_extent(R) and asm_ops.smooth_extent(C))
     g = torch.Generator().manual_seed(4)
-    amp, phs = torch.rand((1, 3, 192, 192), generator=g), torch.rand((1, 3, 192, 192), generator=g) * 6
-    o = optics.make_optics(192, 192, 320, 0.45, PITCH, WL)
+    amp, phs = torch.rand((2, 3, r0, c0), generator=g) + 0.1, torch.rand((2, 3, r0, c0), generator=g) * 6
+    o = optics.make_optics(r0, c0, pad, 0.45, PITCH, WL)
     Hf = optics.transfer_function(o.w, torch.tensor([1e-3]))[0]
     assert cplx_err(fx.propagate_AP2C_backward(amp.to(DEV), phs.to(DEV)), optics.backpropagate_to_slm(o, Hf, amp, phs)) < PARITY
     a, _ = fx.propagate_POH2AP_forward(phs.to(DEV))
     assert rel_err(a.cpu(), optics.poh_to_amp_phase(o, Hf, phs)[0]) < PARITY
+    # adjoint passes: d sum(|field|^2 weighted) / d (amp, phs)
+    wgt = torch.rand((2, 3, r0, c0), generator=g)
+    ad, pd = amp.clone().requires_grad_(True), phs.clone().requires_grad_(True)
+    f_ref = optics.backpropagate_to_slm(o, Hf, ad, pd)
+    ((f_ref.real * wgt).sum() + (f_ref.imag * wgt.flip(-1)).sum()).backward()
+    ah, ph = amp.to(DEV).requires_grad_(True), phs.to(DEV).requires_grad_(True)
+    f_hip = fx.propagate_AP2C_backward(ah, ph)
+    ((f_hip.real * wgt.to(DEV)).sum() + (f_hip.imag * wgt.flip(-1).to(DEV)).sum()).backward()
+    assert rel_err(ah.grad.cpu(), ad.grad) < 5 * PARITY and rel_err(ph.grad.cpu(), pd.grad) < 5 * PARITY
+
+
+def test_asm_4k_frame_with_the_cli_default_pad():
+    """A 2160 x 3840 frame with the reference CLI's default pad_size 320 (generatePOH.py:96): 2800 x 4976 = (2^4 5^2 7) x (2^4 311)
+    transforms, Bluestein lengths 8192 / 16384 on the HIP operator."""
+    import time
+
+    r0, c0, pad = 2160, 3840, 320
+    fx = _fixed(r0, c0, pad, 0.45)
+    assert (fx.samplingRowNum, fx.samplingColNum) == (2800, 4976) and fx._geom.supported()
+    o = optics.make_optics(r0, c0, pad, 0.45, PITCH, WL)
+    Hf = optics.transfer_function(o.w, torch.tensor([1e-3]))[0]
+    g = torch.Generator().manual_seed(21)
+    small = torch.rand((2, 1, 3, r0 // 8, c0 // 8), generator=g)
+    amp, phs = (torch.nn.functional.interpolate(t, size=(r0, c0), mode="bilinear") for t in small)
+    ref = optics.backpropagate_to_slm(o, Hf, amp + 0.1, phs * 6.28)
+    a, p = (amp + 0.1).to(DEV), (phs * 6.28).to(DEV)
+    got = fx.propagate_AP2C_backward(a, p)
+    assert cplx_err(got, ref) < PARITY
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(3):
+        fx.propagate_AP2C_backward(a, p)
+    torch.cuda.synchronize()
+    print("4K pad-320 back-propagation (3 planes): %.1f ms on the HIP Bluestein path" % ((time.perf_counter() - t0) / 3 * 1e3))
+
+
+def test_extent_beyond_the_lds_transforms_uses_rocfft_route():
+    """Lengths the LDS kernels cannot hold (non-smooth above 8192) stay on torch.fft / rocFFT on the GPU — same maths, still no CPU
+    fallback.  Checked at 8800 + 2*275 = 9350 = 2 * 5^2 * 11 * 17 columns."""
+    r0, c0, pad_r = 32, 8800, 1
+    fx = _fixed(r0, c0, pad_r, 0.45)
+    assert not fx._geom.supported()
+    g = torch.Generator().manual_seed(5)
+    amp, phs = torch.rand((1, 3, r0, c0), generator=g) + 0.1, torch.rand((1, 3, r0, c0), generator=g) * 6
+    o = optics.make_optics(r0, c0, pad_r, 0.45, PITCH, WL)
+    Hf = optics.transfer_function(o.w, torch.tensor([1e-3]))[0]
+    assert cplx_err(fx.propagate_AP2C_backward(amp.to(DEV), phs.to(DEV)), optics.backpropagate_to_slm(o, Hf, amp, phs)) < PARITY
 
 
 def test_full_size_train_step_vs_oracle(oracle_full_step):
