@@ -14,8 +14,10 @@
 // Per plane-pair of 2-D transforms this moves ~11 MB at 384^2/1024^2 instead of the 67 MB of two
 // dense fft2 calls (DESIGN.md has the accounting).  Transform lengths 256 and 1024 (the 192^2 / 384^2 frames with the
 // reference's pads) run on register-resident two-step transforms (asm_cols_reg.inc: one LDS round trip per 1-D transform);
-// every other length 2^a 3^b uses the Stockham autosort radix-4 / 2 / 3 stages below (in LDS, host-exact twiddle table
-// computed in double, in place with register staging: read-all / barrier / write-all).
+// every other product of the primes up to 13 (<= 4096: 2304 x 4096 for 4K, 832 = 2^6 13, 2800 = 2^4 5^2 7) uses the Stockham
+// autosort radix-4 / 2 / 3 / 5 / 7 / 11 / 13 stages below (in LDS, host-exact twiddle table computed in double, in place with
+// register staging: read-all / barrier / write-all); any other length up to 8192 (4976 = 2^4 311) runs as a Bluestein convolution
+// of power-of-two length on the same stages.
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
@@ -121,6 +123,60 @@ __device__ __forceinline__ void stages_pow2(float2* buf, int nf, int stride, con
   }
 }
 
+// ---- radix-R stage for the odd primes 5, 7, 11, 13 (832 = 2^6 13, 2800 = 2^4 5^2 7: the padded extents of the CLI's default pad):
+// the same Stockham step as the radix-4 / 2 / 3 stages with the R-point DFT written out (R^2 complex multiply-adds, the powers of
+// w_R taken from the twiddle table at compile-time indices).  16 / R butterflies per thread, read-all / barrier / write-all.
+template <int R, bool INV>
+__device__ void stage_prime(float2* buf, int n, int p, int nf, int stride, const float2* tw) {
+  constexpr int ITS = 16 / R;
+  const int nthreads = blockDim.x, tid = threadIdx.x;
+  const int T = n / R, total = nf * T, twstep = n / (p * R), wstep = n / R;
+  float2 w[R];
+#pragma unroll
+  for (int m = 0; m < R; ++m) {
+    w[m] = tw[m * wstep];
+    if (INV) w[m].y = -w[m].y;
+  }
+  float2 out[ITS][R];
+#pragma unroll
+  for (int it = 0; it < ITS; ++it) {
+    const int b = tid + it * nthreads;
+    if (b < total) {
+      const int f = b / T, i = b - f * T, k = i % p;
+      const float2* x = buf + f * stride + i;
+      float2 u[R];
+#pragma unroll
+      for (int j = 0; j < R; ++j) {
+        u[j] = x[j * T];
+        if (j > 0 && p > 1) {
+          float2 t = tw[j * k * twstep];
+          if (INV) t.y = -t.y;
+          u[j] = cmul(u[j], t);
+        }
+      }
+#pragma unroll
+      for (int jp = 0; jp < R; ++jp) {
+        float2 acc = u[0];
+#pragma unroll
+        for (int j = 1; j < R; ++j) acc = cadd(acc, cmul(u[j], w[(j * jp) % R]));
+        out[it][jp] = acc;
+      }
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < ITS; ++it) {
+    const int b = tid + it * nthreads;
+    if (b < total) {
+      const int f = b / T, i = b - f * T, k = i % p;
+      float2* y = buf + f * stride + (i - k) * R + k;
+#pragma unroll
+      for (int jp = 0; jp < R; ++jp) y[jp * p] = out[it][jp];
+    }
+  }
+  __syncthreads();
+}
+
 template <bool INV>
 __device__ void lds_fft(float2* buf, int n, int nf, int stride, const float2* tw) {
   switch (n) {  // wave-uniform
@@ -137,8 +193,18 @@ __device__ void lds_fft(float2* buf, int n, int nf, int stride, const float2* tw
   }
   const int nthreads = blockDim.x, tid = threadIdx.x;
   for (int p = 1; p < n;) {
-    const int rem = n / p;                                   // n = 2^a * 3^b: radix 4 while possible, then 2, then 3
-    const int R = (rem % 4 == 0) ? 4 : ((rem % 2 == 0) ? 2 : 3);
+    const int rem = n / p;                                   // radix 4 while possible, then 2, then 3, then the odd primes up to 13
+    const int R = (rem % 4 == 0) ? 4 : (rem % 2 == 0) ? 2 : (rem % 3 == 0) ? 3 : (rem % 5 == 0) ? 5 : (rem % 7 == 0) ? 7 : (rem % 11 == 0) ? 11 : 13;
+    if (R > 4) {  // wave-uniform
+      switch (R) {
+        case 5: stage_prime<5, INV>(buf, n, p, nf, stride, tw); break;
+        case 7: stage_prime<7, INV>(buf, n, p, nf, stride, tw); break;
+        case 11: stage_prime<11, INV>(buf, n, p, nf, stride, tw); break;
+        default: stage_prime<13, INV>(buf, n, p, nf, stride, tw); break;
+      }
+      p *= R;
+      continue;
+    }
     const bool p_pow2 = (p & (p - 1)) == 0;
     const int T = n / R;
     const int total = nf * T;
@@ -487,12 +553,21 @@ __global__ void twiddle_kernel(float2* tw, int n) {
 }
 
 // ---------------------------------------------------------------------------------------- host
-// supported transform lengths: 2^a * 3^b in [16, 4096] (radix 4 / 2 / 3 Stockham stages); one 256-thread
-// workgroup must hold a whole row transform, so lengths with a factor 3 stop at 3072
+// butterfly inputs per thread and stage: 16 for radix 4 / 2 (MAX_IT butterflies), 12 for radix 3, R * (16 / R) for the odd primes
+static int fft_budget(int n) {
+  int b = 16;
+  if (n % 3 == 0) b = std::min(b, 12);
+  if (n % 5 == 0) b = std::min(b, 15);
+  if (n % 7 == 0) b = std::min(b, 14);
+  if (n % 11 == 0) b = std::min(b, 11);
+  if (n % 13 == 0) b = std::min(b, 13);
+  return b;
+}
+// lengths transformed directly: products of 2, 3, 5, 7, 11, 13 in [16, 4096] that one 256-thread workgroup can hold as a row
 static bool smooth_in_range(int n) {
-  if (n < 16 || n > (n % 3 == 0 ? 3072 : 4096)) return false;
-  while (n % 2 == 0) n /= 2;
-  while (n % 3 == 0) n /= 3;
+  if (n < 16 || n > 4096 || n > fft_budget(n) * 256) return false;
+  for (int q : {2, 3, 5, 7, 11, 13})
+    while (n % q == 0) n /= q;
   return n == 1;
 }
 // Bluestein convolution length for an extent the Stockham stages do not cover directly: the power of two >= 2n - 1, at most 16384
@@ -505,8 +580,6 @@ static int bluestein_len(int n) {
   return m;  // (a 2^a 3^b length in between was measured: the generic stages cost more than the shorter line saves)
 }
 static bool length_supported(int n) { return smooth_in_range(n) || bluestein_len(n) != 0; }
-// butterflies per thread per stage are capped at MAX_IT: n*nf <= 16*threads (radix 4 / 2) or 12*threads (radix 3)
-static int fft_budget(int n) { return n % 3 == 0 ? 12 : 16; }
 
 static int rows_nf(int n) {
   const int cap = fft_budget(n) * 256;
@@ -627,7 +700,7 @@ static int check_geometry(int planes, int rows0, int cols0, int pad_r, int pad_c
   const int R = rows0 + 2 * pad_r, C = cols0 + 2 * pad_c;
   LHG_REQUIRE(planes > 0 && rows0 > 0 && cols0 > 0 && pad_r >= 0 && pad_c >= 0, "%s: bad extents", what);
   LHG_REQUIRE(length_supported(R) && length_supported(C),
-              "%s: padded extents %dx%d: each must be 2^a*3^b in [16,4096] (<=3072 with a factor 3) or any length in [16,8192] (Bluestein)", what, R, C);
+              "%s: padded extents %dx%d: each must be in [16,8192] (2^a 3^b 5^c 7^d 11^e 13^f up to 4096 directly, anything else as a Bluestein convolution)", what, R, C);
   return LHG_OK;
 }
 

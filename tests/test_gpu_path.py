@@ -430,16 +430,24 @@ def test_asm_4k_geometry_radix3():
 
 
 @pytest.mark.parametrize("r0,c0,pad", [(192, 192, 320), (100, 140, 21), (77, 90, 5), (64, 2100, 4), (64, 4848, 1)], ids=lambda v: str(v))
-def test_non_smooth_extents_run_on_the_hip_bluestein_path(r0, c0, pad):
+def test_extents_outside_2a3b_run_on_the_hip_operator(r0, c0, pad):
     """192 + 2*320 = 832 = 2^6 * 13 (the reference CLI default for 192^2 frames; torch.fft takes any extent,
-    angular_spectrum_method.py:382-392) and other lengths outside 2^a 3^b: the fused HIP operator transforms them as Bluestein
-    convolutions of power-of-two length inside the same three passes (2100 + 2*131 = 2362 columns -> length 8192, 4848 + 2*75 = 4998 ->
-    16384: the sizes a 4K frame with that pad needs).  Forward values against the oracle, gradients against the oracle's autograd."""
+    angular_spectrum_method.py:382-392) and other lengths outside 2^a 3^b stay on the fused HIP operator: products of primes up to 13
+    through radix-5 / 7 / 11 / 13 Stockham stages (832; 198 = 2 3^2 11; 100 = 2^2 5^2), everything else as a Bluestein convolution of
+    power-of-two length inside the same three passes (142 = 2 71, 87 = 3 29, 2362 columns -> length 8192, 4998 -> 16384: the sizes a 4K
+    frame with that pad needs).  Forward values against the oracle, gradients against the oracle's autograd."""
     from learned_hologram_gan_amd import asm_ops
 
     fx = _fixed(r0, c0, pad, 0.45)
     R, C = fx.samplingRowNum, fx.samplingColNum
-    assert fx._geom.supported() and not (asm_ops.smooth_extent(R) and asm_ops.smooth_extent(C))
+    def pow23(n):
+        while n % 2 == 0:
+            n //= 2
+        while n % 3 == 0:
+            n //= 3
+        return n == 1
+
+    assert fx._geom.supported() and not (pow23(R) and pow23(C))
     g = torch.Generator().manual_seed(4)
     amp, phs = torch.rand((2, 3, r0, c0), generator=g) + 0.1, torch.rand((2, 3, r0, c0), generator=g) * 6
     o = optics.make_optics(r0, c0, pad, 0.45, PITCH, WL)

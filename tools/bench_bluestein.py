@@ -19,4 +19,4 @@ for (r0, c0, pad, B) in ((192, 192, 320, 4), (2160, 3840, 320, 1)):
         roc = t(lambda: fx.propagate_AP2C_backward(a, p))
     finally:
         asm_ops.Geometry.supported = sup
-    print(f"{r0}x{c0} pad {pad} -> {fx.samplingRowNum}x{fx.samplingColNum}, {3*B} planes: HIP Bluestein {hip:.2f} ms, torch.fft route {roc:.2f} ms")
+    print(f"{r0}x{c0} pad {pad} -> {fx.samplingRowNum}x{fx.samplingColNum}, {3*B} planes: fused HIP operator {hip:.2f} ms, torch.fft route {roc:.2f} ms")
