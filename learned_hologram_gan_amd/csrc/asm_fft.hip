@@ -177,7 +177,9 @@ __device__ void stage_prime(float2* buf, int n, int p, int nf, int stride, const
   __syncthreads();
 }
 
-template <bool INV>
+// PRIMES: the length may contain the factors 5 / 7 / 11 / 13.  A separate instantiation: with the prime stages compiled into it the
+// kernel of the 2^a 3^b lengths (the 4K geometry 2304 x 4096) ran 15 % slower (register pressure of the 13-point butterfly).
+template <bool INV, bool PRIMES = false>
 __device__ void lds_fft(float2* buf, int n, int nf, int stride, const float2* tw) {
   switch (n) {  // wave-uniform
     case 64: return stages_pow2<64, 1, INV>(buf, nf, stride, tw);
@@ -194,8 +196,8 @@ __device__ void lds_fft(float2* buf, int n, int nf, int stride, const float2* tw
   const int nthreads = blockDim.x, tid = threadIdx.x;
   for (int p = 1; p < n;) {
     const int rem = n / p;                                   // radix 4 while possible, then 2, then 3, then the odd primes up to 13
-    const int R = (rem % 4 == 0) ? 4 : (rem % 2 == 0) ? 2 : (rem % 3 == 0) ? 3 : (rem % 5 == 0) ? 5 : (rem % 7 == 0) ? 7 : (rem % 11 == 0) ? 11 : 13;
-    if (R > 4) {  // wave-uniform
+    const int R = (rem % 4 == 0) ? 4 : (rem % 2 == 0) ? 2 : (!PRIMES || rem % 3 == 0) ? 3 : (rem % 5 == 0) ? 5 : (rem % 7 == 0) ? 7 : (rem % 11 == 0) ? 11 : 13;
+    if (PRIMES && R > 4) {  // wave-uniform
       switch (R) {
         case 5: stage_prime<5, INV>(buf, n, p, nf, stride, tw); break;
         case 7: stage_prime<7, INV>(buf, n, p, nf, stride, tw); break;
@@ -374,9 +376,9 @@ __device__ void bluestein_fft(float2* buf, int n, int m, int nf, int stride, con
 }
 
 // one 1-D transform per line: directly (m == 0) or through Bluestein's convolution of length m
-template <bool INV>
+template <bool INV, bool PRIMES>
 __device__ __forceinline__ void fft_line(float2* buf, int n, int m, int nf, int stride, const float2* tw, const float2* __restrict__ tab) {
-  if (m == 0) lds_fft<INV>(buf, n, nf, stride, tw);
+  if (m == 0) lds_fft<INV, PRIMES>(buf, n, nf, stride, tw);
   else bluestein_fft<INV>(buf, n, m, nf, stride, tw, tab);
 }
 
@@ -384,7 +386,9 @@ extern __shared__ __attribute__((aligned(16))) unsigned char lds_raw[];
 
 // ---------------------------------------------------------------------------------------- pass 1
 // grid.x = ceil(planes*rows0 / nf); block 256 threads; LDS: tw[n] + nf*n complex
-__global__ __launch_bounds__(1024) void rows_forward_kernel(const float* __restrict__ in_a, const float* __restrict__ in_b, int in_mode,
+// MAXT: 256 for every line up to 4096 (the register budget the Stockham stages were tuned with), 1024 for the Bluestein lines above
+template <int MAXT, bool PRIMES>
+__global__ __launch_bounds__(MAXT) void rows_forward_kernel(const float* __restrict__ in_a, const float* __restrict__ in_b, int in_mode,
                                                             float phase_scale, int total_rows, int cols0, int pad_c, int n, int m, int nf,
                                                             int tw_in_lds, const float2* __restrict__ twg, float2* __restrict__ t1) {
   const int L = m ? m : n;  // LDS line length (Bluestein: the convolution length)
@@ -416,7 +420,7 @@ __global__ __launch_bounds__(1024) void rows_forward_kernel(const float* __restr
     }
   }
   __syncthreads();
-  fft_line<false>(buf, n, m, nf, L, tw, twg);
+  fft_line<false, PRIMES>(buf, n, m, nf, L, tw, twg);
   for (int i = tid; i < nf * n; i += nth) {
     const int f = i / n;
     const int row = row0 + f;
@@ -438,6 +442,7 @@ struct ColsParams {
   const float2* tw;                           // R entries
 };
 
+template <bool PRIMES>
 __global__ __launch_bounds__(1024) void cols_filter_kernel(const ColsParams p) {
   const int L = p.M ? p.M : p.R;
   float2* twl = reinterpret_cast<float2*>(lds_raw);
@@ -459,7 +464,7 @@ __global__ __launch_bounds__(1024) void cols_filter_kernel(const ColsParams p) {
     buf[g * stride + r] = z;
   }
   __syncthreads();
-  if (p.do_fwd) fft_line<false>(buf, p.R, p.M, p.G, stride, tw, p.tw);
+  if (p.do_fwd) fft_line<false, PRIMES>(buf, p.R, p.M, p.G, stride, tw, p.tw);
   const int s1 = p.f1_op ? (p.f1_index ? p.f1_index[plane] : 0) : 0;
   const int s2 = p.f2_op ? (p.f2_index ? p.f2_index[plane] : 0) : 0;
   if (p.f1_op || p.f2_op || p.scale != 1.f) {
@@ -473,7 +478,7 @@ __global__ __launch_bounds__(1024) void cols_filter_kernel(const ColsParams p) {
     }
     __syncthreads();
   }
-  if (p.do_inv) fft_line<true>(buf, p.R, p.M, p.G, stride, tw, p.tw);
+  if (p.do_inv) fft_line<true, PRIMES>(buf, p.R, p.M, p.G, stride, tw, p.tw);
   for (int i = tid; i < p.dst_rows * p.G; i += nth) {
     const int g = i & gm, r = i >> lg;
     p.dst[((size_t)plane * p.dst_rows + r) * p.C + c0 + g] = buf[g * stride + r + p.dst_off];
@@ -483,7 +488,8 @@ __global__ __launch_bounds__(1024) void cols_filter_kernel(const ColsParams p) {
 #include "asm_cols_reg.inc"
 
 // ---------------------------------------------------------------------------------------- pass 3
-__global__ __launch_bounds__(1024) void rows_inverse_kernel(const float2* __restrict__ t2, int total_rows, int cols0, int pad_c, int n, int m, int nf,
+template <int MAXT, bool PRIMES>
+__global__ __launch_bounds__(MAXT) void rows_inverse_kernel(const float2* __restrict__ t2, int total_rows, int cols0, int pad_c, int n, int m, int nf,
                                                             int tw_in_lds, const float2* __restrict__ twg, float* __restrict__ out_a,
                                                             float* __restrict__ out_b, float2* __restrict__ out_c, int out_mode) {
   const int L = m ? m : n;
@@ -500,7 +506,7 @@ __global__ __launch_bounds__(1024) void rows_inverse_kernel(const float2* __rest
     buf[f * L + (i - f * n)] = row < total_rows ? t2[(size_t)row * n + (i - f * n)] : make_float2(0.f, 0.f);
   }
   __syncthreads();
-  fft_line<true>(buf, n, m, nf, L, tw, twg);
+  fft_line<true, PRIMES>(buf, n, m, nf, L, tw, twg);
   for (int i = tid; i < nf * cols0; i += nth) {
     const int f = i / cols0, x = i - f * cols0;
     const int row = row0 + f;
@@ -563,6 +569,7 @@ static int fft_budget(int n) {
   if (n % 13 == 0) b = std::min(b, 13);
   return b;
 }
+static bool has_prime_radix(int n) { return n % 5 == 0 || n % 7 == 0 || n % 11 == 0 || n % 13 == 0; }
 // lengths transformed directly: products of 2, 3, 5, 7, 11, 13 in [16, 4096] that one 256-thread workgroup can hold as a row
 static bool smooth_in_range(int n) {
   if (n < 16 || n > 4096 || n > fft_budget(n) * 256) return false;
@@ -635,11 +642,16 @@ static int run_rows_forward(const float* in_a, const float* in_b, int in_mode, f
   const int nf = rows_nf(L);
   const int tw_lds = tw_fits((size_t)nf * L * sizeof(float2), L);
   const size_t lds = (size_t)((tw_lds ? L : 0) + nf * L) * sizeof(float2);
-  int rc = set_dyn_lds(reinterpret_cast<const void*>(rows_forward_kernel), lds);
-  if (rc) return rc;
   const int total_rows = planes * rows0;
-  hipLaunchKernelGGL(rows_forward_kernel, dim3((total_rows + nf - 1) / nf), dim3(rows_threads(L)), lds, st, in_a, in_b, in_mode, phase_scale,
-                     total_rows, cols0, pad_c, cols, m, nf, tw_lds, reinterpret_cast<const float2*>(tw_cols), t1);
+  auto launch = [&](auto kernel) {
+    int rc = set_dyn_lds(reinterpret_cast<const void*>(kernel), lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kernel, dim3((total_rows + nf - 1) / nf), dim3(rows_threads(L)), lds, st, in_a, in_b, in_mode, phase_scale, total_rows,
+                       cols0, pad_c, cols, m, nf, tw_lds, reinterpret_cast<const float2*>(tw_cols), t1);
+    return (int)LHG_OK;
+  };
+  int rc = L > 4096 ? launch(rows_forward_kernel<1024, false>) : (has_prime_radix(L) ? launch(rows_forward_kernel<256, true>) : launch(rows_forward_kernel<256, false>));
+  if (rc) return rc;
   return check_launch("rows_forward");
 }
 
@@ -651,11 +663,16 @@ static int run_rows_inverse(const float2* t2, int planes, int rows0, int cols0, 
   const int nf = rows_nf(L);
   const int tw_lds = tw_fits((size_t)nf * L * sizeof(float2), L);
   const size_t lds = (size_t)((tw_lds ? L : 0) + nf * L) * sizeof(float2);
-  int rc = set_dyn_lds(reinterpret_cast<const void*>(rows_inverse_kernel), lds);
-  if (rc) return rc;
   const int total_rows = planes * rows0;
-  hipLaunchKernelGGL(rows_inverse_kernel, dim3((total_rows + nf - 1) / nf), dim3(rows_threads(L)), lds, st, t2, total_rows, cols0, pad_c, cols, m, nf, tw_lds,
-                     reinterpret_cast<const float2*>(tw_cols), out_a, out_b, reinterpret_cast<float2*>(out_c), out_mode);
+  auto launch = [&](auto kernel) {
+    int rc = set_dyn_lds(reinterpret_cast<const void*>(kernel), lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kernel, dim3((total_rows + nf - 1) / nf), dim3(rows_threads(L)), lds, st, t2, total_rows, cols0, pad_c, cols, m, nf, tw_lds,
+                       reinterpret_cast<const float2*>(tw_cols), out_a, out_b, reinterpret_cast<float2*>(out_c), out_mode);
+    return (int)LHG_OK;
+  };
+  int rc = L > 4096 ? launch(rows_inverse_kernel<1024, false>) : (has_prime_radix(L) ? launch(rows_inverse_kernel<256, true>) : launch(rows_inverse_kernel<256, false>));
+  if (rc) return rc;
   return check_launch("rows_inverse");
 }
 
@@ -690,9 +707,14 @@ static int run_cols(ColsParams& p, hipStream_t st) {
   p.G = G;
   p.tw_in_lds = tw_fits((size_t)G * (L + 1) * sizeof(float2), L);
   const size_t lds = ((size_t)G * (L + 1) + (p.tw_in_lds ? L : 0)) * sizeof(float2);
-  int rc = set_dyn_lds(reinterpret_cast<const void*>(cols_filter_kernel), lds);
+  auto launch = [&](auto kernel) {
+    int rc = set_dyn_lds(reinterpret_cast<const void*>(kernel), lds);
+    if (rc) return rc;
+    hipLaunchKernelGGL(kernel, dim3(p.planes * (p.C / G)), dim3(threads), lds, st, p);
+    return (int)LHG_OK;
+  };
+  int rc = has_prime_radix(L) ? launch(cols_filter_kernel<true>) : launch(cols_filter_kernel<false>);
   if (rc) return rc;
-  hipLaunchKernelGGL(cols_filter_kernel, dim3(p.planes * (p.C / G)), dim3(threads), lds, st, p);
   return check_launch("cols_filter");
 }
 
