@@ -123,6 +123,71 @@ __device__ __forceinline__ void stages_pow2(float2* buf, int nf, int stride, con
   }
 }
 
+// ---- compile-time stages for a length that is not a power of two (2304 = 4^4 3^2, the row count of the 4K geometry): the same
+// butterflies as the generic loop below with every stage parameter a constant, so transform / index / twiddle position come from
+// multiply-shift divisions by constants instead of runtime integer divisions (the column pass of a 4K frame is bound by exactly that).
+template <int N, int P, int R, bool INV>
+__device__ __forceinline__ void stage_c(float2* buf, int nf, int stride, const float2* tw) {
+  static_assert(R == 4 || R == 3, "radix");
+  constexpr int T = N / R, TWSTEP = N / (P * R);
+  const int nthreads = blockDim.x, tid = threadIdx.x;
+  const int total = nf * T;
+  float2 u[MAX_IT][R];
+  int off[MAX_IT];
+#pragma unroll
+  for (int it = 0; it < MAX_IT; ++it) {
+    const int b = tid + it * nthreads;
+    if (b < total) {
+      const int f = b / T, i = b - f * T, k = i % P;
+      const float2* x = buf + f * stride + i;
+      float2 v[R];
+#pragma unroll
+      for (int j = 0; j < R; ++j) v[j] = x[j * T];
+      if (P > 1) {
+#pragma unroll
+        for (int j = 1; j < R; ++j) {
+          float2 w = tw[j * k * TWSTEP];
+          if (INV) w.y = -w.y;
+          v[j] = cmul(v[j], w);
+        }
+      }
+      if constexpr (R == 4) {
+        const float2 v0 = cadd(v[0], v[2]), v1 = csub(v[0], v[2]), v2 = cadd(v[1], v[3]), d = csub(v[1], v[3]);
+        const float2 v3 = INV ? make_float2(-d.y, d.x) : make_float2(d.y, -d.x);
+        u[it][0] = cadd(v0, v2); u[it][1] = cadd(v1, v3); u[it][2] = csub(v0, v2); u[it][3] = csub(v1, v3);
+      } else {
+        const float c3 = 0.8660254037844386f;
+        const float2 t1 = cadd(v[1], v[2]);
+        const float2 t2 = make_float2(v[0].x - 0.5f * t1.x, v[0].y - 0.5f * t1.y);
+        const float2 d = csub(v[1], v[2]);
+        const float2 t3 = INV ? make_float2(-c3 * d.y, c3 * d.x) : make_float2(c3 * d.y, -c3 * d.x);
+        u[it][0] = cadd(v[0], t1); u[it][1] = cadd(t2, t3); u[it][2] = csub(t2, t3);
+      }
+      off[it] = f * stride + (i - k) * R + k;
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int it = 0; it < MAX_IT; ++it) {
+    if (tid + it * nthreads < total) {
+      float2* y = buf + off[it];
+#pragma unroll
+      for (int j = 0; j < R; ++j) y[j * P] = u[it][j];
+    }
+  }
+  __syncthreads();
+}
+
+template <bool INV>
+__device__ __forceinline__ void stages_2304(float2* buf, int nf, int stride, const float2* tw) {
+  stage_c<2304, 1, 4, INV>(buf, nf, stride, tw);
+  stage_c<2304, 4, 4, INV>(buf, nf, stride, tw);
+  stage_c<2304, 16, 4, INV>(buf, nf, stride, tw);
+  stage_c<2304, 64, 4, INV>(buf, nf, stride, tw);
+  stage_c<2304, 256, 3, INV>(buf, nf, stride, tw);
+  stage_c<2304, 768, 3, INV>(buf, nf, stride, tw);
+}
+
 // ---- radix-R stage for the odd primes 5, 7, 11, 13 (832 = 2^6 13, 2800 = 2^4 5^2 7: the padded extents of the CLI's default pad):
 // the same Stockham step as the radix-4 / 2 / 3 stages with the R-point DFT written out (R^2 complex multiply-adds, the powers of
 // w_R taken from the twiddle table at compile-time indices).  16 / R butterflies per thread, read-all / barrier / write-all.
@@ -189,6 +254,7 @@ __device__ void lds_fft(float2* buf, int n, int nf, int stride, const float2* tw
     case 1024: return stages_pow2<1024, 1, INV>(buf, nf, stride, tw);
     case 2048: return stages_pow2<2048, 1, INV>(buf, nf, stride, tw);
     case 4096: return stages_pow2<4096, 1, INV>(buf, nf, stride, tw);
+    case 2304: return stages_2304<INV>(buf, nf, stride, tw);
     case 8192: return stages_pow2<8192, 1, INV>(buf, nf, stride, tw);    // Bluestein convolution lengths of the large non-smooth extents
     case 16384: return stages_pow2<16384, 1, INV>(buf, nf, stride, tw);  // (512 / 1024 threads, twiddles read from global memory)
     default: break;
