@@ -568,3 +568,75 @@ def test_bf16_storage_batch_norm_pool_and_layout(bf16_storage):
     # max pool: exact on bf16 values, gradient routed to the first maximum
     p = ops.MaxPool2x2Fn.apply(xg.detach())
     assert torch.equal(to_nchw(p.float()), F.max_pool2d(x, 2))
+
+
+# --------------------------------------------------------------------------- tensor scales of the fp16-split GEMM mode
+def test_absmax_kernel_and_fused_measurements(ops):
+    """lhg_absmax max-accumulates max|x| over an NHWC slice (vector and scalar paths, non-finite values order above finite ones); the
+    BN kernels measure the same quantity for the tensor they write (y_absmax / gx_absmax) and tag it on the tensor object."""
+    if ops.conv_precision() != "fp32_split_f16":
+        pytest.skip("tensor scales belong to the fp32_split_f16 mode")
+    g = torch.Generator().manual_seed(3)
+    t = (torch.randn((2, 9, 7, 96), generator=g) * 3).to(DEV)
+    assert float(ops.operand_absmax(t)[0]) == float(t.abs().max())
+    sl = t[..., 32:64]                                  # channel slice: ld 96, C 32
+    assert float(ops.operand_absmax(sl)[0]) == float(sl.abs().max())
+    odd = torch.randn((1, 5, 3, 6), generator=g).to(DEV)  # C % 4 != 0: scalar path
+    assert float(ops.operand_absmax(odd)[0]) == float(odd.abs().max())
+    z = torch.zeros((1, 4, 4, 32), device=DEV)
+    assert float(ops.operand_absmax(z)[0]) == 0.0
+    bad = t.clone()
+    bad[1, 2, 3, 4] = float("inf")
+    assert torch.isinf(ops.operand_absmax(bad)).all()
+    bad[0, 0, 0, 0] = float("nan")
+    assert torch.isnan(ops.operand_absmax(bad)).all()
+    # the slot is remembered on the tensor together with its version counter ...
+    a1 = ops.operand_absmax(t)
+    assert ops.operand_absmax(t).data_ptr() == a1.data_ptr()
+    t.mul_(2.0)                                         # ... and an in-place update invalidates it
+    a2 = ops.operand_absmax(t)
+    assert a2.data_ptr() != a1.data_ptr() and float(a2[0]) == float(t.abs().max())
+    # fused measurements: BatchNormTrainFn output and its input-gradient
+    x = (torch.randn((3, 10, 14, 64), generator=g) * 2 + 0.7).to(DEV).requires_grad_(True)
+    gam, bet = torch.rand(64, generator=g).to(DEV) + 0.5, torch.randn(64, generator=g).to(DEV)
+    rm, rv = torch.zeros(64, device=DEV), torch.ones(64, device=DEV)
+    y = ops.BatchNormTrainFn.apply(x, gam.requires_grad_(True), bet.requires_grad_(True), rm, rv, None, 1, 0.0, None)
+    tag = y.__dict__.get("_lhg_amax")
+    assert tag is not None and float(tag[1][0]) == float(y.detach().abs().max())
+    pooled = ops.MaxPool2x2Fn.apply(y)
+    assert pooled.__dict__["_lhg_amax"][1].data_ptr() == tag[1].data_ptr()  # inherits the input's bound
+    gy = torch.randn(y.shape, generator=g).to(DEV)
+    gx, _ = ops.bn_backward_raw(gy, x.detach(), y.detach(), gam.detach(), *_bn_stats(ops, x.detach()), 1, 0.0, False, None, None, False)
+    assert float(gx.__dict__["_lhg_amax"][1][0]) == float(gx.abs().max())
+
+
+def _bn_stats(ops, x):
+    from learned_hologram_gan_amd.native import call, ptr, stream_ptr
+
+    px, N, H, W, Cc, ld = ops.nhwc(x)
+    stats = torch.empty((2 * Cc,), dtype=torch.float32, device=x.device)
+    ws = torch.empty((4104 * Cc,), dtype=torch.float32, device=x.device)
+    call("lhg_bn_stats", px, N * H * W, Cc, ld, ptr(stats), None, None, 0.1, 1e-5, ptr(ws), stream_ptr())
+    return (stats,)
+
+
+def test_autotune_choices_persist_in_the_cache_file(tmp_path):
+    """LHG_TUNE_CACHE=<file>: a process appends its tiling choices, a later process reads them back (and times nothing it finds there)."""
+    import os
+    import subprocess
+    import sys
+
+    cache = tmp_path / "tune.txt"
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import torch; from learned_hologram_gan_amd import hip_ops as ops\n"
+            "torch.manual_seed(0)\n"
+            "x = torch.randn(2, 24, 24, 64, device='cuda'); w = torch.randn(64, 64, 3, 3, device='cuda')\n"
+            "y = ops.conv2d_forward_raw(x, w, None, 1); torch.cuda.synchronize(); print(float(y.abs().sum()))")
+    env = dict(os.environ, LHG_TUNE_CACHE=str(cache))
+    a = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True)
+    assert a.returncode == 0, a.stderr[-800:]
+    lines = cache.read_text().strip().splitlines()
+    assert lines and all(ln.startswith("lhg-tune-") for ln in lines)
+    b = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True)
+    assert b.returncode == 0 and b.stdout.strip().splitlines()[-1] == a.stdout.strip().splitlines()[-1]
+    assert cache.read_text().strip().splitlines() == lines  # nothing new was tuned

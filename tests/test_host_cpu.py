@@ -28,6 +28,35 @@ def test_library_exports_declared_abi():
     assert lib.lhg_abi_version() == 3
 
 
+def test_host_side_size_functions_and_supported_lengths():
+    """Pure host functions of the ABI (no kernel launch): FFT table sizes follow the transform route (direct: 2n floats; Bluestein:
+    m twiddles + n chirp values + m filter values, m the power of two >= 2n - 1) and agree with the Python mirror of the supported
+    lengths; packed-weight sizes follow the precision mode (the fp16-split panels carry max|w| in 16 bytes behind them)."""
+    from learned_hologram_gan_amd import asm_ops, native
+
+    lib = native.load()
+    for n, direct in ((1024, True), (2304, True), (4096, True), (832, True), (2800, True), (198, True), (100, True),
+                      (4976, False), (142, False), (87, False), (2362, False), (8000, False)):
+        assert asm_ops.smooth_extent(n) == direct and asm_ops.supported_extent(n)
+        floats = int(lib.lhg_fft_table_floats(n))
+        if direct:
+            assert floats == 2 * n
+        else:
+            m = 64
+            while m < 2 * n - 1:
+                m *= 2
+            assert floats == 2 * (2 * m + n)
+    assert not asm_ops.supported_extent(9350) and not asm_ops.supported_extent(8)
+    assert lib.lhg_default_conv_precision() == 4 or "LHG_CONV_PRECISION" in __import__("os").environ
+    mode = lib.lhg_get_conv_precision()
+    try:
+        elems = 9 * 128 * 64
+        for prec, floats in ((0, elems), (1, elems), (2, elems * 3 // 2), (3, elems), (4, elems + 4)):
+            assert lib.lhg_set_conv_precision(prec) == 0 and int(lib.lhg_packed_weight_floats(9, 128, 64)) == floats
+    finally:
+        lib.lhg_set_conv_precision(mode)
+
+
 def test_library_is_gfx950_code_object():
     from learned_hologram_gan_amd import native
 
