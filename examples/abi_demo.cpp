@@ -71,7 +71,7 @@ int main() {
   HIP_OK(hipMemsetAsync(dxmax, 0, LHG_ABSMAX_WORDS * 4, stream));  // lhg_absmax max-accumulates into its slot
   LHG_OK_OR_DIE(lhg_absmax(dx, (long long)N * H * W, Ci, Ci, dxmax, stream));  // the tensor scale of the fp16-split GEMM mode (ignored by the others)
   LHG_OK_OR_DIE(lhg_conv2d_forward(dx, N, H, W, Ci, Ci, dwp, rows_pad, K, K, /*stride=*/1, dy, Co, Co, db, nullptr, nullptr, nullptr, 0,
-                                   LHG_ACT_RELU, 0.f, /*planar_out=*/0, dxmax, stream));
+                                   LHG_ACT_RELU, 0.f, /*planar_out=*/0, dxmax, /*y_absmax=*/nullptr, stream));
   HIP_OK(hipMemcpyAsync(y.data(), dy, y.size() * 4, hipMemcpyDeviceToHost, stream));
   HIP_OK(hipStreamSynchronize(stream));
   double err = 0, mag = 0;

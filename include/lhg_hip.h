@@ -136,7 +136,9 @@ int lhg_pack_weight(const float* w, int D0, int D1, int KH, int KW, int rows_fro
  *   v = acc + bias[c];  v = v*scale[c] + shift[c];  v += res[pixel][c];  v = act(v)
  * (each pointer may be NULL).  planar_out != 0 stores NCHW instead of NHWC.
  * `x_absmax` / `gy_absmax`: device pointer to max|.| of that operand (lhg_absmax), required in the
- * LHG_PRECISION_F32_SPLIT_F16 mode, ignored (may be NULL) in every other.                          */
+ * LHG_PRECISION_F32_SPLIT_F16 mode, ignored (may be NULL) in every other.  `y_absmax` (forward calls, may be NULL):
+ * the fp16-split kernels max-accumulate max|y| of an NHWC output into it — lhg_absmax for the next GEMM's operand
+ * without a pass of its own (several launches may share one slot: the halves of a concatenation buffer).          */
 
 /* y = conv2d(x, W, stride, padding=KH/2).  ref: neural_network_components.py:27-30
  * (3x3 s1, 1x1), discriminator.py:34-38 (3x3 s1/s2), :25 (1024->1 head). */
@@ -145,7 +147,7 @@ int lhg_conv2d_forward(const float* x, int N, int H, int W, int Ci, int ldx,
                        float* y, int Co, int ldy,
                        const float* bias, const float* scale, const float* shift,
                        const float* res, int ldres, int act, float slope, int planar_out,
-                       const float* x_absmax, lhg_stream_t s);
+                       const float* x_absmax, float* y_absmax, lhg_stream_t s);
 
 /* gx = conv2d_backward_input(gy, W).  (H, W) are the INPUT extents of the forward conv.
  * `wp` packed with rows_from_d0 = 0.  Replaces the autograd node of the call sites above;
@@ -184,7 +186,7 @@ int lhg_conv2d_thin_backward_weight(const float* x, int N, int H, int W, int Ci,
 /* y = conv_transpose2d(x, W, kernel 2, stride 2).  ref: neural_network_components.py:270-286. */
 int lhg_conv_transpose2x2_forward(const float* x, int N, int H, int W, int Ci, int ldx,
                                   const float* wp, int rows_pad, float* y, int Co, int ldy,
-                                  const float* bias, const float* x_absmax, lhg_stream_t s);
+                                  const float* bias, const float* x_absmax, float* y_absmax, lhg_stream_t s);
 int lhg_conv_transpose2x2_backward_input(const float* gy, int N, int H, int W, int Co, int ldgy,
                                          const float* wp, int rows_pad, float* gx, int Ci, int ldgx,
                                          const float* gy_absmax, lhg_stream_t s);

@@ -60,6 +60,7 @@ struct GGParams {
   int xcd;  // 1: XCD-contiguous tile order (xcd_contiguous)
   const float* a_amax;  // fp16-split mode: max|in| over the gathered tensor (device, lhg_absmax) and max|w| (behind the weight panels)
   const float* w_amax;
+  float* out_amax;      // fp16-split mode, optional: max-accumulates max|out| (NHWC outputs)
   int prio; // gg3s_kernel: 0 no s_setprio, 1 consumers (MFMA waves) raised, 2 producers (load / split waves) raised
 };
 
@@ -1070,11 +1071,12 @@ long long lhg_packed_weight_floats(int taps, int rows_pad, int k_pad) {
 
 int lhg_conv2d_forward(const float* x, int N, int H, int W, int Ci, int ldx, const float* wp, int rows_pad, int KH, int KW, int stride,
                        float* y, int Co, int ldy, const float* bias, const float* scale, const float* shift,
-                       const float* res, int ldres, int act, float slope, int planar_out, const float* x_absmax, lhg_stream_t s) {
+                       const float* res, int ldres, int act, float slope, int planar_out, const float* x_absmax, float* y_absmax,
+                       lhg_stream_t s) {
   LHG_REQUIRE(conv_args_ok(KH, KW, stride), "conv2d_forward: unsupported kernel %dx%d stride %d", KH, KW, stride);
   GGParams p{};
   conv_fwd_geom(p.g, N, H, W, Ci, ldx, Co, ldy, KH, KW, stride);
-  p.a_amax = x_absmax; p.w_amax = weight_amax(wp, KH * KW, rows_pad, Ci);
+  p.a_amax = x_absmax; p.w_amax = weight_amax(wp, KH * KW, rows_pad, Ci); p.out_amax = y_absmax;
   p.in = x; p.wp = wp; p.out = y; p.bias = bias; p.scale = scale; p.shift = shift; p.res = res; p.ldres = ldres;
   p.rows_pad = rows_pad; p.act = act; p.slope = slope; p.planar_out = planar_out;
   return launch_gg(p, as_stream(s));
@@ -1179,12 +1181,12 @@ static void convt_geom(Geom& g, int N, int H, int W, int Ci, int ldx, int Co, in
 }
 
 int lhg_conv_transpose2x2_forward(const float* x, int N, int H, int W, int Ci, int ldx, const float* wp, int rows_pad,
-                                  float* y, int Co, int ldy, const float* bias, const float* x_absmax, lhg_stream_t s) {
+                                  float* y, int Co, int ldy, const float* bias, const float* x_absmax, float* y_absmax, lhg_stream_t s) {
   for (int py = 0; py < 2; ++py)
     for (int px = 0; px < 2; ++px) {
       GGParams p{};
       convt_geom(p.g, N, H, W, Ci, ldx, Co, ldy, py, px);
-      p.a_amax = x_absmax; p.w_amax = weight_amax(wp, 4, rows_pad, Ci);
+      p.a_amax = x_absmax; p.w_amax = weight_amax(wp, 4, rows_pad, Ci); p.out_amax = y_absmax;
       p.in = x; p.wp = wp; p.out = y; p.bias = bias; p.rows_pad = rows_pad; p.act = LHG_ACT_NONE;
       int rc = launch_gg(p, as_stream(s));
       if (rc) return rc;

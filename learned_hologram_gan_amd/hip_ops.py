@@ -88,10 +88,41 @@ class OutSlot:
     the op writes through the raw pointer and returns a detached alias of the view, which
     autograd then owns like any freshly allocated output."""
 
-    __slots__ = ("t",)
+    __slots__ = ("t", "share")
 
-    def __init__(self, t):
+    def __init__(self, t, share=None):
         self.t = t
+        self.share = share  # AmaxShare of the buffer this view belongs to, or None
+
+
+class AmaxShare:
+    """One max|.| slot for a buffer that several producers fill (the two halves of a skip-concatenation buffer): every producer that
+    measures its output max-accumulates into ``slot`` and counts itself in; the buffer may be tagged with the slot only when all of
+    its ``parts`` producers did (a producer that cannot measure — thin convolution, another GEMM mode — simply does not count)."""
+
+    __slots__ = ("slot", "parts", "writers")
+
+    def __init__(self, device, parts=2):
+        self.slot = fused_absmax_slot(device)
+        self.parts, self.writers = parts, 0
+
+    def writer(self):
+        """The slot for a producer about to measure into it (None when the mode has no use for it)."""
+        if self.slot is not None:
+            self.writers += 1
+        return self.slot
+
+    def tag(self, buf):
+        if self.slot is not None and self.writers >= self.parts:
+            tag_absmax(buf, self.slot)
+        return buf
+
+
+def _out_amax(out, device, fresh_ok=True):
+    """(slot, tag_target_is_fresh): where a producer with destination ``out`` (None, or an OutSlot) accumulates max|output|."""
+    if isinstance(out, OutSlot):
+        return out.share.writer() if out.share is not None else None
+    return fused_absmax_slot(device) if fresh_ok else None
 
 
 def _resolve_out(out, shape, device, dtype=None):
@@ -111,7 +142,8 @@ class CatViewsFn(Function):
     @staticmethod
     def forward(ctx, a, b, buf_slot):
         ctx.ca = a.shape[-1]
-        return buf_slot.t.detach()
+        out = buf_slot.t.detach()
+        return buf_slot.share.tag(out) if buf_slot.share is not None else out
 
     @staticmethod
     def backward(ctx, g):
@@ -370,7 +402,7 @@ def operand_absmax(t):
     if _mode() != _F16_SPLIT:
         return None
     known = t.__dict__.get("_lhg_amax")
-    if known is not None and known[0] == t._version:
+    if known is not None and known[0] == t._version and _slot_alive(known[1]):
         return known[1]
     p, N, H, W, Cc, ld = nhwc(t)
     out = _amax_slot(t.device)
@@ -390,7 +422,7 @@ def fused_absmax_slot(device):
 def _inherit_absmax(dst, src):
     """dst's elements are a subset of src's (or zeros): src's known max|.| bounds dst's."""
     known = src.__dict__.get("_lhg_amax")
-    if known is not None and known[0] == src._version:
+    if known is not None and known[0] == src._version and _slot_alive(known[1]):
         tag_absmax(dst, known[1])
     return dst
 
@@ -405,20 +437,53 @@ def tag_absmax(t, slot):
 
 _FUSED_ABSMAX = os.environ.get("LHG_FUSED_ABSMAX", "1") != "0"  # 0: every operand is measured by lhg_absmax (A/B measurements)
 ABSMAX_WORDS = 1  # LHG_ABSMAX_WORDS: an operand's max|x| is the maximum of this many floats (include/lhg_hip.h)
-_AMAX_POOL = {}  # (device, stream, capturing) -> [zero-filled tensor, next free index]; a slot is handed out once
+_AMAX_POOL = {}  # (device, stream, capturing) -> _SlotRing
+_RING_POOLS, _POOL_SLOTS = 64, 1024
+
+
+class _SlotRing:
+    """Zero-filled one-float slots for lhg_absmax (it max-accumulates), handed out once each.  One fill launch prepares 1024 slots.
+    The pools form a ring of 64 that is never freed: a slot's memory is reused only 65536 measurements later (re-zeroed on the
+    stream that owns the ring), so a kernel of ANOTHER stream that still reads a slot — the weight-gradient GEMMs run on the side
+    stream — can never see its pool handed to a different tensor by the caching allocator.  Every pool carries a generation counter;
+    a tag on a long-lived tensor (tag_absmax) is honoured only while its pool has not been recycled."""
+
+    __slots__ = ("pools", "gens", "cur", "nxt", "device")
+
+    def __init__(self, device):
+        self.device, self.pools, self.gens, self.cur, self.nxt = device, [], [], -1, _POOL_SLOTS
+
+    def take(self):
+        if self.nxt >= _POOL_SLOTS:
+            self.cur = (self.cur + 1) % _RING_POOLS
+            if self.cur == len(self.pools):
+                self.pools.append(torch.zeros((_POOL_SLOTS * ABSMAX_WORDS,), dtype=torch.float32, device=self.device))
+                self.gens.append([0])
+            else:
+                self.pools[self.cur].zero_()
+                self.gens[self.cur][0] += 1
+            self.nxt = 0
+        i = self.nxt
+        self.nxt = i + 1
+        slot = self.pools[self.cur][i * ABSMAX_WORDS:(i + 1) * ABSMAX_WORDS]
+        slot.__dict__["_lhg_gen"] = (self.gens[self.cur], self.gens[self.cur][0])
+        return slot
+
+
+def _slot_alive(slot) -> bool:
+    g = slot.__dict__.get("_lhg_gen")
+    return g is None or g[0][0] == g[1]
 
 
 def _amax_slot(device):
-    """A zeroed one-float slot for lhg_absmax (it max-accumulates).  One fill launch prepares 1024 slots.  Pools are per stream — the fill
-    and the measurement are ordered by the stream they both run on — and a pool filled outside a graph capture is not used inside one
-    (the fill has to be part of the graph for the replays to start from zero)."""
+    """A zeroed slot on the ring of the current stream — fill and measurement are ordered by the stream they both run on — and of the
+    current capture state (a pool filled outside a graph capture is not used inside one: the fill has to be part of the graph for
+    the replays to start from zero)."""
     key = (device, stream_ptr(), torch.cuda.is_current_stream_capturing())
-    pool = _AMAX_POOL.get(key)
-    if pool is None or pool[1] >= pool[0].numel():
-        pool = _AMAX_POOL[key] = [torch.zeros((1024 * ABSMAX_WORDS,), dtype=torch.float32, device=device), 0]
-    i = pool[1]
-    pool[1] = i + ABSMAX_WORDS
-    return pool[0][i:i + ABSMAX_WORDS]
+    ring = _AMAX_POOL.get(key)
+    if ring is None:
+        ring = _AMAX_POOL[key] = _SlotRing(device)
+    return ring.take()
 
 
 def apply_env_precision() -> None:
@@ -522,7 +587,8 @@ def _raw_weight(w):
     return wd if wd.is_contiguous() else wd.contiguous()
 
 
-def conv2d_forward_raw(x, w, bias, stride, act=ACT_NONE, slope=0.0, scale=None, shift=None, res=None, out=None, planar=False, x_amax=None):
+def conv2d_forward_raw(x, w, bias, stride, act=ACT_NONE, slope=0.0, scale=None, shift=None, res=None, out=None, planar=False, x_amax=None,
+                       measure_out=False):
     """y = act((conv(x, w) + bias) * scale + shift + res); no autograd."""
     px, N, H, W, Ci, ldx = nhwc(x)
     Co, Ciw, KH, KW = w.shape
@@ -553,8 +619,12 @@ def conv2d_forward_raw(x, w, bias, stride, act=ACT_NONE, slope=0.0, scale=None, 
     native.count_flops(0, 2.0 * N * Ho * Wo * Co * (w.shape[1] * w.shape[2] * w.shape[3]))
     if x_amax is None:
         x_amax = operand_absmax(x)
+    # measure_out: the output feeds another GEMM directly (eval-mode chains, conv + activation blocks): the epilogue measures max|y|
+    y_amax = _out_amax(out, x.device) if measure_out and not planar else None
     call("lhg_conv2d_forward", px, N, H, W, Ci, ldx, ptr(wp), wp.shape[1], KH, KW, stride, py, Co, ldy,
-         ptr(bias), ptr(scale), ptr(shift), pres, ldres, act, float(slope), int(planar), ptr(x_amax), stream_ptr())
+         ptr(bias), ptr(scale), ptr(shift), pres, ldres, act, float(slope), int(planar), ptr(x_amax), ptr(y_amax), stream_ptr())
+    if y_amax is not None:
+        tag_absmax(y, y_amax)  # (a view into a shared buffer: the slot bounds the whole buffer, hence the view)
     return y
 
 
@@ -755,7 +825,11 @@ class ConvTranspose2x2Fn(TrackedFunction):
         py, _, _, _, _, ldy = nhwc(y)
         native.count_flops(0, 2.0 * N * H * W * 4 * Ci * Co)
         ctx.x_amax = operand_absmax(x)
-        call("lhg_conv_transpose2x2_forward", px, N, H, W, Ci, ldx, ptr(wp), wp.shape[1], py, Co, ldy, ptr(bias), ptr(ctx.x_amax), stream_ptr())
+        y_amax = _out_amax(out, x.device)  # the output is a conv input (through the concatenation buffer)
+        call("lhg_conv_transpose2x2_forward", px, N, H, W, Ci, ldx, ptr(wp), wp.shape[1], py, Co, ldy, ptr(bias), ptr(ctx.x_amax), ptr(y_amax),
+             stream_ptr())
+        if y_amax is not None:
+            tag_absmax(y, y_amax)
         return y
 
     @staticmethod
@@ -850,7 +924,7 @@ class ConvBiasActFn(TrackedFunction):
 
     @staticmethod
     def forward(ctx, x, w, bias, stride, act, slope):
-        y = conv2d_forward_raw(x, w, bias, stride, act=act, slope=slope)
+        y = conv2d_forward_raw(x, w, bias, stride, act=act, slope=slope, measure_out=True)
         ctx.save_for_backward(x, w, y)
         ctx.stride, ctx.act, ctx.slope, ctx.has_bias = stride, act, slope, bias is not None
         note_use(w, ctx.needs_input_grad[1])
@@ -896,7 +970,7 @@ class BatchNormTrainFn(TrackedFunction):
         pres, ldres = (None, 0)
         if res is not None:
             pres, _, _, _, _, ldres = nhwc(res)
-        y_amax = fused_absmax_slot(x.device)  # max|y| measured by the kernel that writes y: the next conv's GEMMs need no pass of their own
+        y_amax = _out_amax(out, x.device)  # max|y| measured by the kernel that writes y: the next conv's GEMMs need no pass of their own
         call("lhg_bn_apply", px, ldx, pixels, Cc, ptr(stats), ptr(gamma), ptr(beta), pres, ldres, act, float(slope), py, ldy, ptr(y_amax),
              stream_ptr())
         tag_absmax(y, y_amax)

@@ -45,7 +45,7 @@ _SIGNATURES = {
     "lhg_default_conv_precision": [],
     "lhg_packed_weight_floats": [C.c_int, C.c_int, C.c_int],
     "lhg_pack_weight": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _p],
-    "lhg_conv2d_forward": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _i, _i, _f, _i, _p, _p],
+    "lhg_conv2d_forward": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _i, _i, _f, _i, _p, _p, _p],
     "lhg_conv2d_backward_input": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p, _p],
     "lhg_conv2d_wgrad_splits": [_i, _i, _i, _i, _i, _i, _i, _i],
     "lhg_conv2d_backward_weight": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _p, _p, _p],
@@ -54,7 +54,7 @@ _SIGNATURES = {
     "lhg_conv2d_thin_backward_input": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _i, _p],
     "lhg_conv2d_thin_wgrad_workspace": [_i, _i, _i, _i, _i, _i],
     "lhg_conv2d_thin_backward_weight": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _p, _p, _sz, _p],
-    "lhg_conv_transpose2x2_forward": [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _i, _p, _p, _p],
+    "lhg_conv_transpose2x2_forward": [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _i, _p, _p, _p, _p],
     "lhg_conv_transpose2x2_backward_input": [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _i, _p, _p],
     "lhg_conv_transpose2x2_wgrad_splits": [_i, _i, _i, _i, _i],
     "lhg_conv_transpose2x2_backward_weight": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _i, _i, _i, _p, _p, _p],

@@ -74,9 +74,9 @@ class ResidualBlock(nn.Module):
         with torch.no_grad():
             s1, t1 = _bn_eval_affine(b1)
             s2, t2 = _bn_eval_affine(b2)
-            y = ops.conv2d_forward_raw(x, c1.weight, c1.bias, self.strides, act=ACT_RELU, scale=s1, shift=t1)
+            y = ops.conv2d_forward_raw(x, c1.weight, c1.bias, self.strides, act=ACT_RELU, scale=s1, shift=t1, measure_out=True)
             skip = ops.conv2d_forward_raw(x, c3.weight, c3.bias, self.strides) if c3 is not None else x
-            return ops.conv2d_forward_raw(y, c2.weight, c2.bias, 1, act=ACT_RELU, scale=s2, shift=t2, res=skip, out=out)
+            return ops.conv2d_forward_raw(y, c2.weight, c2.bias, 1, act=ACT_RELU, scale=s2, shift=t2, res=skip, out=out, measure_out=True)
 
     def forward(self, X):
         x = ops.ToNHWC.apply(X, ops.pad_to(X.shape[1], 32))
@@ -167,10 +167,10 @@ class UNet(nn.Module):
         with torch.no_grad():
             return ops.ConvTranspose2x2Fn.apply(x, convt.weight, convt.bias, out)
 
-    def _cat(self, skip, up, buf):
+    def _cat(self, skip, up, buf, share):
         if self.training:
-            return ops.CatViewsFn.apply(skip, up, OutSlot(buf))
-        return buf
+            return ops.CatViewsFn.apply(skip, up, OutSlot(buf, share))
+        return share.tag(buf)
 
     def forward(self, X):
         if X.shape[1] != self.in_channels or X.shape[2] % 16 or X.shape[3] % 16:
@@ -181,20 +181,22 @@ class UNet(nn.Module):
         new = lambda h, w, c: ops.new_nhwc(N, h, w, c, dev)  # noqa: E731  (fp32, or bf16 in the bf16 storage mode)
         buf4, buf3, buf2, buf1 = new(H, W, 128), new(H // 2, W // 2, 256), new(H // 4, W // 4, 512), new(H // 8, W // 8, 1024)
         pool = ops.MaxPool2x2Fn.apply
+        # one max|.| slot per concatenation buffer: the encoder block and the transposed conv that fill its halves both measure into it
+        sh4, sh3, sh2, sh1 = (ops.AmaxShare(dev) for _ in range(4))
 
-        e1 = self._block(self.encoder1[0]).forward_nhwc(x, OutSlot(buf4[..., :64]))
-        e2 = self._block(self.encoder2[1]).forward_nhwc(pool(e1), OutSlot(buf3[..., :128]))
-        e3 = self._block(self.encoder3[1]).forward_nhwc(pool(e2), OutSlot(buf2[..., :256]))
-        e4 = self._block(self.encoder4[1]).forward_nhwc(pool(e3), OutSlot(buf1[..., :512]))
+        e1 = self._block(self.encoder1[0]).forward_nhwc(x, OutSlot(buf4[..., :64], sh4))
+        e2 = self._block(self.encoder2[1]).forward_nhwc(pool(e1), OutSlot(buf3[..., :128], sh3))
+        e3 = self._block(self.encoder3[1]).forward_nhwc(pool(e2), OutSlot(buf2[..., :256], sh2))
+        e4 = self._block(self.encoder4[1]).forward_nhwc(pool(e3), OutSlot(buf1[..., :512], sh1))
         b = self._block(self.bottleneck[1]).forward_nhwc(pool(e4))
-        u = self._up(self.bottleneck[2], b, OutSlot(buf1[..., 512:]))
-        d = self._block(self.decoder1[0]).forward_nhwc(self._cat(e4, u, buf1))
-        u = self._up(self.decoder1[1], d, OutSlot(buf2[..., 256:]))
-        d = self._block(self.decoder2[0]).forward_nhwc(self._cat(e3, u, buf2))
-        u = self._up(self.decoder2[1], d, OutSlot(buf3[..., 128:]))
-        d = self._block(self.decoder3[0]).forward_nhwc(self._cat(e2, u, buf3))
-        u = self._up(self.decoder3[1], d, OutSlot(buf4[..., 64:]))
-        d = self._block(self.decoder4).forward_nhwc(self._cat(e1, u, buf4))
+        u = self._up(self.bottleneck[2], b, OutSlot(buf1[..., 512:], sh1))
+        d = self._block(self.decoder1[0]).forward_nhwc(self._cat(e4, u, buf1, sh1))
+        u = self._up(self.decoder1[1], d, OutSlot(buf2[..., 256:], sh2))
+        d = self._block(self.decoder2[0]).forward_nhwc(self._cat(e3, u, buf2, sh2))
+        u = self._up(self.decoder2[1], d, OutSlot(buf3[..., 128:], sh3))
+        d = self._block(self.decoder3[0]).forward_nhwc(self._cat(e2, u, buf3, sh3))
+        u = self._up(self.decoder3[1], d, OutSlot(buf4[..., 64:], sh4))
+        d = self._block(self.decoder4).forward_nhwc(self._cat(e1, u, buf4, sh4))
         head = self.final_layer[0]
         flush_batch_counters()
         if self.training:

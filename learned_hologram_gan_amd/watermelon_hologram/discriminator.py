@@ -49,11 +49,12 @@ class WGANGPDiscriminator192(nn.Module):
             s = ops.Conv2dFn.apply(h, self.conv.weight, self.conv.bias, 1, None)
         else:
             with torch.no_grad():
-                h = ops.conv2d_forward_raw(h, c1.weight, c1.bias, 1, act=ACT_LEAKY, slope=0.2)
+                h = ops.conv2d_forward_raw(h, c1.weight, c1.bias, 1, act=ACT_LEAKY, slope=0.2, measure_out=True)
                 for blk in (self.block2, self.block3, self.block4, self.block5, self.block6):
                     conv, bn = blk[0], blk[1]
                     sc, sh = ops.batch_norm_eval_affine(bn.weight, bn.bias, bn.running_mean, bn.running_var)
-                    h = ops.conv2d_forward_raw(h, conv.weight, conv.bias, conv.stride[0], act=ACT_LEAKY, slope=0.2, scale=sc, shift=sh)
+                    h = ops.conv2d_forward_raw(h, conv.weight, conv.bias, conv.stride[0], act=ACT_LEAKY, slope=0.2, scale=sc, shift=sh,
+                                               measure_out=True)
                 s = ops.conv2d_forward_raw(h, self.conv.weight, self.conv.bias, 1)
         return s.reshape(s.shape[0], -1).float()  # (N, H/8, W/8, 1) -> (N, H*W/64), same order as Flatten on NCHW; scores are fp32
 

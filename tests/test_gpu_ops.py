@@ -610,6 +610,27 @@ def test_absmax_kernel_and_fused_measurements(ops):
     assert float(gx.__dict__["_lhg_amax"][1][0]) == float(gx.abs().max())
 
 
+def test_absmax_slot_ring_recycles_and_invalidates_tags(ops, monkeypatch):
+    """The slot pools form a ring that is never freed (a weight-gradient GEMM on the side stream may still read a slot after Python let
+    go of it); a recycled pool starts from zero again and the tags that pointed into it are not honoured any more."""
+    if ops.conv_precision() != "fp32_split_f16":
+        pytest.skip("tensor scales belong to the fp32_split_f16 mode")
+    monkeypatch.setattr(ops, "_RING_POOLS", 2)
+    monkeypatch.setattr(ops, "_POOL_SLOTS", 4)
+    monkeypatch.setattr(ops, "_AMAX_POOL", {})
+    t = torch.full((1, 2, 2, 32), 3.0, device=DEV)
+    first = ops.operand_absmax(t)
+    assert float(first[0]) == 3.0 and ops.operand_absmax(t).data_ptr() == first.data_ptr()
+    ptrs = {first.data_ptr()}
+    for i in range(8):                                  # two full turns of the ring
+        o = ops.operand_absmax(torch.full((1, 2, 2, 32), float(i + 10), device=DEV))
+        assert float(o[0]) == float(i + 10)             # a recycled slot starts from zero again
+        ptrs.add(o.data_ptr())
+    again = ops.operand_absmax(t)                       # the old tag points into a recycled pool: measured afresh
+    assert float(again[0]) == 3.0 and not ops._slot_alive(first)
+    assert len(ptrs | {again.data_ptr()}) <= 8          # 2 pools x 4 slots, reused in place
+
+
 def _bn_stats(ops, x):
     from learned_hologram_gan_amd.native import call, ptr, stream_ptr
 
