@@ -62,15 +62,30 @@ def overlap():
     sync = W._sync_G
     assert sync.enabled and len(sync.ranges) >= 3
     x = (rgbd.to(dev), tamp.to(dev), tphs.to(dev), idx)
+    fwd = []  # (G loss, checksum of the hologram) of every pass: tells a forward difference from a backward one
+
+    notes = []
+
+    def one_pass():
+        out = W.train_step(*x)
+        fwd.append((float(out["G_loss"]), float(out["POH"].double().sum()), float(out["hat_amps"].double().sum())))
+        with torch.no_grad():  # the reconstruction of the step against fresh evaluations from the same hologram
+            for k in range(3):
+                again = W.propagator.reconstruct_planes(W.generator.part2.propagator, out["POH"], x[1], x[2], idx)[0]
+                if not torch.equal(again, out["hat_amps"]):
+                    d = (again - out["hat_amps"]).abs()
+                    notes.append({"pass": len(fwd) - 1, "recompute": k, "elements": int((d > 0).sum()), "max_abs": float(d.max()),
+                                  "where": torch.nonzero(d > 0)[:4].tolist()})
+
     sync.enabled = False
-    W.train_step(*x)           # pass 0: local, first sight of every geometry (the GEMM launcher times its tilings here)
+    one_pass()                 # pass 0: local, first sight of every geometry (the GEMM launcher times its tilings here)
     sync.enabled = True
     before = hip_ops.CONTRIBUTIONS
-    W.train_step(*x)           # pass 1: reduced across the two ranks, buckets launched from inside backward
+    one_pass()                 # pass 1: reduced across the two ranks, buckets launched from inside backward
     total = hip_ops.CONTRIBUTIONS - before
     log = [(b, c - before, ff) for b, c, ff in sync.launch_log]
     sync.enabled = False
-    W.train_step(*x)           # pass 2: local again
+    one_pass()                 # pass 2: local again
     local0, reduced, local = grabbed
     gathered = [torch.empty_like(local) for _ in range(world)]
     dist.all_gather(gathered, local)
@@ -78,8 +93,22 @@ def overlap():
     err = ((reduced - mean).norm() / mean.norm()).item()
     both = [torch.empty_like(reduced) for _ in range(world)]
     dist.all_gather(both, reduced)
+
+    def offenders(a, b):  # parameters whose slots differ, worst first: what to look at when a stream race shows
+        flat = W._opt_G.flat
+        names = {id(p): n for n, p in W.generator.named_parameters()}
+        out = []
+        for p_, o in zip(flat.params, flat.offsets):
+            da, db = a[o:o + p_.numel()], b[o:o + p_.numel()]
+            if not torch.equal(da, db):
+                out.append((names.get(id(p_), "?"), float((da - db).norm() / (db.norm() + 1e-30))))
+        return sorted(out, key=lambda t: -t[1])[:6]
+
     print(json.dumps({"rank": rank, "err": err, "launch_log": log, "contributions": total, "buckets": len(sync.ranges),
-                      "local_repeatable": bool(torch.equal(local0, local)), "ranks_agree": bool(torch.equal(both[0], both[1]))}), flush=True)
+                      "local_repeatable": bool(torch.equal(local0, local)), "ranks_agree": bool(torch.equal(both[0], both[1])),
+                      "forward_repeats": fwd[0] == fwd[1] == fwd[2], "forward": fwd, "recompute_notes": notes,
+                      "diff_pass0_vs_pass2": offenders(local0, local), "diff_reduced_vs_mean": offenders(reduced, mean) if err > 1e-6 else []}),
+          flush=True)
     dist.barrier()
     dist.destroy_process_group()
 
