@@ -103,9 +103,12 @@ __device__ __forceinline__ f32x4 act_grad4(f32x4 yy, int act, float slope) {
 // Running max|v| of what a streaming kernel writes — the tensor scale the fp16-split GEMMs need of their operands (lhg_absmax):
 // folded into the producer it costs no pass of its own.  Magnitude bits compare as unsigned (NaN > inf > finite).
 __device__ __forceinline__ unsigned amax4(unsigned m, f32x4 v) {
+  // v_max_f32 with |.| source modifiers: one instruction per element.  (A NaN element does not raise the maximum here — it still turns
+  // into a NaN fp16 term in the GEMM that reads it, so the result is NaN either way; an infinity does and leaves the tensor unscaled.)
+  float f = __uint_as_float(m);
 #pragma unroll
-  for (int e = 0; e < 4; ++e) m = max(m, __float_as_uint(v[e]) & 0x7fffffffu);
-  return m;
+  for (int e = 0; e < 4; ++e) f = fmaxf(f, fabsf(v[e]));
+  return __float_as_uint(f);
 }
 // `seen`: the slot's value loaded when the workgroup started (its latency hides behind the streaming loop); only a workgroup that beat
 // it goes back to memory at all, and then re-reads before the atomic: a few dozen atomics per launch instead of one per workgroup.

@@ -661,3 +661,37 @@ def test_autotune_choices_persist_in_the_cache_file(tmp_path):
     b = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True)
     assert b.returncode == 0 and b.stdout.strip().splitlines()[-1] == a.stdout.strip().splitlines()[-1]
     assert cache.read_text().strip().splitlines() == lines  # nothing new was tuned
+
+
+@pytest.mark.parametrize("scale", [1e-4, 1.0, 3e4], ids=lambda s: f"x{s:g}")
+def test_f16_split_tracks_exact_fp32_over_operand_scales(ops, scale):
+    """A conv -> conv -> conv-transpose chain (no normalisation in between, so the operand magnitudes really differ by `scale`^k from
+    layer to layer) and its gradients in the default two-term fp16 mode against the exact fp32 MFMA kernels on the same data: the
+    per-tensor power-of-two scales must keep the result at fp32 accuracy whether the activations are ~1e-8 or ~1e9."""
+    if ops.conv_precision() != "fp32_split_f16":
+        pytest.skip("the default mode was overridden")
+    g = torch.Generator().manual_seed(17)
+    x0 = (torch.randn((2, 20, 24, 64), generator=g) * scale).to(DEV)
+    w1 = (torch.randn((128, 64, 3, 3), generator=g) * (64 * 9) ** -0.5 * scale).to(DEV)
+    w2 = (torch.randn((128, 128, 3, 3), generator=g) * (128 * 9) ** -0.5).to(DEV)
+    wt = (torch.randn((128, 64, 2, 2), generator=g) * 128 ** -0.5 * scale).to(DEV)
+    proj = torch.randn((2, 40, 48, 64), generator=g).to(DEV)
+
+    def run(mode):
+        ops.set_conv_precision(mode)
+        try:
+            x = x0.clone().requires_grad_(True)
+            ws = [w.clone().requires_grad_(True) for w in (w1, w2, wt)]
+            h = ops.Conv2dFn.apply(x, ws[0], None, 1, None)
+            h = ops.Conv2dFn.apply(h, ws[1], None, 1, None)
+            y = ops.ConvTranspose2x2Fn.apply(h, ws[2], None, None)
+            (y * proj).sum().backward()
+            torch.cuda.synchronize()
+            ops.join_side_stream()
+            return [y.detach().clone(), x.grad.clone()] + [w.grad.clone() for w in ws]
+        finally:
+            ops.set_conv_precision("default")
+
+    got, want = run("fp32_split_f16"), run("fp32")
+    for a, b in zip(got, want):
+        assert torch.isfinite(a).all() and rel_err(a.cpu().double(), b.cpu().double()) < 3e-6, scale
