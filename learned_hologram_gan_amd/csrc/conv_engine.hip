@@ -61,6 +61,7 @@ struct GGParams {
   const float* a_amax;  // fp16-split mode: max|in| over the gathered tensor (device, lhg_absmax) and max|w| (behind the weight panels)
   const float* w_amax;
   float* out_amax;      // fp16-split mode, optional: max-accumulates max|out| (NHWC outputs)
+  int tap_of[9];        // gg4s_kernel: tap index of the 3x3 offset (dy + 1) * 3 + (dx + 1)
   int prio; // gg3s_kernel: 0 no s_setprio, 1 consumers (MFMA waves) raised, 2 producers (load / split waves) raised
 };
 
@@ -245,6 +246,7 @@ __global__ __launch_bounds__(256, 2) void gg_kernel(const GGParams p) {
 #include "gg2_kernel.inc"
 #include "gg2b_kernel.inc"
 #include "gg3s_kernel.inc"
+#include "gg4s_kernel.inc"
 
 // ------------------------------------------------------------------------------------ wg_kernel
 constexpr int WG_TILE = 64;
@@ -781,10 +783,23 @@ static int launch_gg_split(GGParams& p, hipStream_t st) {
   const unsigned wb = (unsigned)wp_bytes;
   auto blocks = [&](int bm, int bn) { return (unsigned)(((g.M + bm - 1) / bm) * (p.rows_pad / bn)); };
   const bool n128 = p.rows_pad % 128 == 0;
-  constexpr int NV = 5;  // 3, 4: eight consumer waves (two per SIMD) on the 128x128 / 128x64 tiles
+  constexpr int NV = 7;  // 3, 4: eight consumer waves (two per SIMD) on the 128x128 / 128x64 tiles; 5, 6: strip-staged 3x3 kernel (gg4s)
+  // gg4s_kernel: fp16 planes, full 3x3 tap set, stride 1 both ways, same extents in and out
+  bool strips = split_f16() && g.T == 9 && g.istep == 1 && g.ostep == 1 && g.oy0 == 0 && g.ox0 == 0 && g.gh == g.Hi && g.gw == g.Wi && g.Ho == g.Hi &&
+                g.Wo == g.Wi && (long long)g.N * g.Hi * (g.Wi + 2) < (1ll << 31);
+  if (strips) {
+    int seen = 0;
+    for (int t = 0; t < 9; ++t) {
+      const int dyi = g.dy[t] + 1, dxi = g.dx[t] + 1;
+      if ((unsigned)dyi < 3u && (unsigned)dxi < 3u) { p.tap_of[dyi * 3 + dxi] = t; seen |= 1 << (dyi * 3 + dxi); }
+    }
+    strips = seen == 0x1ff;
+  }
+  auto blocks_strip = [&](int bn) { return (unsigned)((((long long)g.N * g.Hi * (g.Wi + 2) + 63) / 64) * (p.rows_pad / bn)); };
   const bool f16 = split_f16();
   if (f16) LHG_REQUIRE(p.a_amax != nullptr && p.w_amax != nullptr, "gather-GEMM (fp32_split_f16 mode): the operand's absmax pointer is missing (lhg_absmax)");
   auto valid = [&](int v) {
+    if (v >= 5) return strips && (v == 5 || n128);
     return (v == 0 || v == 3) ? n128 : (NP == 3 || f16 || v < 3);
   };
   auto run = [&](int v) {
@@ -804,6 +819,8 @@ static int launch_gg_split(GGParams& p, hipStream_t st) {
         case 0: hipLaunchKernelGGL((gg3s_kernel<128, 128, 2, 2, 32, float, 4, _Float16>), dim3(blocks(128, 128)), dim3(512), 0, st, p, ib, wb); break;
         case 1: hipLaunchKernelGGL((gg3s_kernel<128, 64, 2, 2, 32, float, 4, _Float16>), dim3(blocks(128, 64)), dim3(512), 0, st, p, ib, wb); break;
         case 2: hipLaunchKernelGGL((gg3s_kernel<64, 64, 2, 2, 32, float, 4, _Float16>), dim3(blocks(64, 64)), dim3(512), 0, st, p, ib, wb); break;
+        case 5: hipLaunchKernelGGL((gg4s_kernel<64>), dim3(blocks_strip(64)), dim3(512), 0, st, p, ib, wb); break;
+        case 6: hipLaunchKernelGGL((gg4s_kernel<128>), dim3(blocks_strip(128)), dim3(512), 0, st, p, ib, wb); break;
         default: break;
       }
     } else {
