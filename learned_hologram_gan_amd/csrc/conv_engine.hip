@@ -783,7 +783,7 @@ static int launch_gg_split(GGParams& p, hipStream_t st) {
   const unsigned wb = (unsigned)wp_bytes;
   auto blocks = [&](int bm, int bn) { return (unsigned)(((g.M + bm - 1) / bm) * (p.rows_pad / bn)); };
   const bool n128 = p.rows_pad % 128 == 0;
-  constexpr int NV = 7;  // 3, 4: eight consumer waves (two per SIMD) on the 128x128 / 128x64 tiles; 5, 6: strip-staged 3x3 kernel (gg4s)
+  constexpr int NV = 9;  // 3, 4: eight consumer waves (two per SIMD) on the 128x128 / 128x64 tiles; 5..8: strip-staged 3x3 kernel (gg4s)
   // gg4s_kernel: fp16 planes, full 3x3 tap set, stride 1 both ways, same extents in and out
   bool strips = split_f16() && g.T == 9 && g.istep == 1 && g.ostep == 1 && g.oy0 == 0 && g.ox0 == 0 && g.gh == g.Hi && g.gw == g.Wi && g.Ho == g.Hi &&
                 g.Wo == g.Wi && (long long)g.N * g.Hi * (g.Wi + 2) < (1ll << 31);
@@ -795,11 +795,11 @@ static int launch_gg_split(GGParams& p, hipStream_t st) {
     }
     strips = seen == 0x1ff;
   }
-  auto blocks_strip = [&](int bn) { return (unsigned)((((long long)g.N * g.Hi * (g.Wi + 2) + 63) / 64) * (p.rows_pad / bn)); };
+  auto blocks_strip = [&](int bm, int bn) { return (unsigned)((((long long)g.N * g.Hi * (g.Wi + 2) + bm - 1) / bm) * (p.rows_pad / bn)); };
   const bool f16 = split_f16();
   if (f16) LHG_REQUIRE(p.a_amax != nullptr && p.w_amax != nullptr, "gather-GEMM (fp32_split_f16 mode): the operand's absmax pointer is missing (lhg_absmax)");
   auto valid = [&](int v) {
-    if (v >= 5) return strips && (v == 5 || n128);
+    if (v >= 5) return strips && (v == 5 || v == 7 || n128);
     return (v == 0 || v == 3) ? n128 : (NP == 3 || f16 || v < 3);
   };
   auto run = [&](int v) {
@@ -819,8 +819,10 @@ static int launch_gg_split(GGParams& p, hipStream_t st) {
         case 0: hipLaunchKernelGGL((gg3s_kernel<128, 128, 2, 2, 32, float, 4, _Float16>), dim3(blocks(128, 128)), dim3(512), 0, st, p, ib, wb); break;
         case 1: hipLaunchKernelGGL((gg3s_kernel<128, 64, 2, 2, 32, float, 4, _Float16>), dim3(blocks(128, 64)), dim3(512), 0, st, p, ib, wb); break;
         case 2: hipLaunchKernelGGL((gg3s_kernel<64, 64, 2, 2, 32, float, 4, _Float16>), dim3(blocks(64, 64)), dim3(512), 0, st, p, ib, wb); break;
-        case 5: hipLaunchKernelGGL((gg4s_kernel<64>), dim3(blocks_strip(64)), dim3(512), 0, st, p, ib, wb); break;
-        case 6: hipLaunchKernelGGL((gg4s_kernel<128>), dim3(blocks_strip(128)), dim3(512), 0, st, p, ib, wb); break;
+        case 5: hipLaunchKernelGGL((gg4s_kernel<64, 64>), dim3(blocks_strip(64, 64)), dim3(512), 0, st, p, ib, wb); break;
+        case 6: hipLaunchKernelGGL((gg4s_kernel<64, 128>), dim3(blocks_strip(64, 128)), dim3(512), 0, st, p, ib, wb); break;
+        case 7: hipLaunchKernelGGL((gg4s_kernel<128, 64>), dim3(blocks_strip(128, 64)), dim3(512), 0, st, p, ib, wb); break;
+        case 8: hipLaunchKernelGGL((gg4s_kernel<128, 128>), dim3(blocks_strip(128, 128)), dim3(512), 0, st, p, ib, wb); break;
         default: break;
       }
     } else {
