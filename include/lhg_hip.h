@@ -222,11 +222,15 @@ int lhg_bn_apply(const float* x, int ldx, long long pixels, int C, const float* 
 /* Backward of y = act(bn(x) + res) given gy:  g = gy * act'(y);  gres = g (if non-NULL);
  * gx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); ggamma (+)= sum g*xhat; gbeta (+)= sum g  (accumulate != 0 adds).
  * `y` is the forward OUTPUT (sign gives the activation mask).  ws: >= 8192*C floats.
- * gx_absmax (may be NULL): max-accumulates max|gx|, as y_absmax above (gx is the gy operand of the preceding conv's backward GEMMs). */
+ * gx_absmax (may be NULL): max-accumulates max|gx|, as y_absmax above (gx is the gy operand of the preceding conv's backward GEMMs).
+ * y may be NULL when the forward had no residual and a ReLU / LeakyReLU: the kernels then recompute the pre-activation from x, gamma
+ * and `beta` exactly as lhg_bn_apply rounded it (one fma per element) and take the mask from its sign — one tensor read less in each
+ * of the two passes; `beta` is only read in that case. */
 int lhg_bn_backward(const float* gy, int ldgy, const float* x, int ldx, const float* y, int ldy,
                     long long pixels, int C, const float* stats, const float* gamma,
                     int act, float slope, float* gx, int ldgx, float* gres, int ldgres,
-                    float* ggamma, float* gbeta, int accumulate, float* ws, float* gx_absmax, lhg_stream_t s);
+                    float* ggamma, float* gbeta, int accumulate, float* ws, float* gx_absmax,
+                    const float* beta, lhg_stream_t s);
 /* Double backward of the gx output above (WGAN-GP, ref: watermelon.py:466-473):
  * given ggx (cotangent of gx) returns ggy (cotangent of gy), gx2 (cotangent of x) and
  * ggamma2 (cotangent of gamma).  ws: >= 5*4096*C floats. */

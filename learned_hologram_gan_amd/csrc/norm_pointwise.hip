@@ -160,6 +160,16 @@ __global__ void bn_stats_final(const float* __restrict__ sums /* [2][C] shifted 
   }
 }
 
+// v = x * a + b with ONE rounding per element (fma), a = invstd * gamma, b = beta - mean * a: the pre-activation of bn_apply.  The backward
+// kernels evaluate the same expression when they derive the activation mask from x instead of reading the forward output y
+// (no residual, ReLU / LeakyReLU: sign(y) == sign(v) exactly, one tensor read less per pass).
+__device__ __forceinline__ f32x4 bn_affine(f32x4 x, f32x4 a, f32x4 b) {
+  f32x4 v;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) v[e] = __builtin_fmaf(x[e], a[e], b[e]);
+  return v;
+}
+
 // ------------------------------------------------------------------ BN apply (+residual, +activation)
 template <class T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, int ldx, long long pixels, int C,
@@ -183,7 +193,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
           return v;
         },
         [&](long long q, const V2& l) {
-          f32x4 v = l.a * a + b;
+          f32x4 v = bn_affine(l.a, a, b);
           if (res) v += l.b;
 #pragma unroll
           for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act, slope);
@@ -195,23 +205,36 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
 }
 
 // ------------------------------------------------------------------ BN backward
+// y == nullptr: the activation mask is recomputed from x (gamma / beta non-null; forward had no residual and a ReLU / LeakyReLU)
 template <class T>
 __global__ __launch_bounds__(256) void bn_bwd_partial(const T* __restrict__ gy, int ldgy, const T* __restrict__ x, int ldx,
                                                       const T* __restrict__ y, int ldy, long long pixels, int C,
-                                                      const float* __restrict__ stats, int act, float slope, int lanes_c, int rows,
+                                                      const float* __restrict__ stats, const float* __restrict__ gamma,
+                                                      const float* __restrict__ beta, int act, float slope, int lanes_c, int rows,
                                                       float* __restrict__ partial) {
+  const bool recompute = y == nullptr && act != LHG_ACT_NONE;
   column_reduce<2>(
-      pixels, C, lanes_c, rows, partial, [&](int cb) { return V2{ld4(stats + cb), ld4(stats + C + cb)}; },
+      pixels, C, lanes_c, rows, partial,
+      [&](int cb) {
+        V4 c;
+        c.a = ld4(stats + cb);
+        c.b = ld4(stats + C + cb);
+        if (recompute) {
+          c.c = c.b * ld4(gamma + cb);           // a = invstd * gamma     (as bn_apply_kernel)
+          c.d = ld4(beta + cb) - c.a * c.c;      // b = beta - mean * a
+        }
+        return c;
+      },
       [&](long long q, int cb) {
         V3 v;
         v.a = ld4(gy + (size_t)q * ldgy + cb);
         v.b = ld4(x + (size_t)q * ldx + cb);
-        if (act != LHG_ACT_NONE) v.c = ld4(y + (size_t)q * ldy + cb);
+        if (act != LHG_ACT_NONE && !recompute) v.c = ld4(y + (size_t)q * ldy + cb);
         return v;
       },
-      [&](const V3& v, const V2& st, f32x4* acc) {
+      [&](const V3& v, const V4& st, f32x4* acc) {
         f32x4 g = v.a;
-        if (act != LHG_ACT_NONE) g *= act_grad4(v.c, act, slope);
+        if (act != LHG_ACT_NONE) g *= act_grad4(recompute ? bn_affine(v.b, st.c, st.d) : v.c, act, slope);
         const f32x4 xh = (v.b - st.a) * st.b;
         acc[0] += g;
         acc[1] += g * xh;
@@ -258,7 +281,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const T* __restrict__ gy, in
                                                     const float* __restrict__ sums, int act, float slope,
                                                     T* __restrict__ gx, int ldgx, T* __restrict__ gres, int ldgres,
                                                     float* __restrict__ ggamma, float* __restrict__ gbeta, int accumulate, int lanes_c,
-                                                    int rows, float* __restrict__ gx_amax) {
+                                                    int rows, float* __restrict__ gx_amax, const float* __restrict__ beta) {
   const int tx = threadIdx.x % lanes_c, ty = threadIdx.x / lanes_c;
   const float invn = 1.f / (float)pixels;
   unsigned am = 0;
@@ -271,18 +294,24 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const T* __restrict__ gy, in
       if (gbeta) st4(gbeta + cb, accumulate ? ld4(gbeta + cb) + sg : sg);
     }
     const f32x4 k = gam * inv, mg = sg * invn, mgx = sgx * invn;
+    const bool recompute = y == nullptr && act != LHG_ACT_NONE;  // mask from x: v = x * a + b as bn_apply_kernel evaluated it
+    f32x4 fa = inv, fb = inv;
+    if (recompute) {
+      fa = inv * gam;
+      fb = ld4(beta + cb) - mean * fa;
+    }
     pixel_loop(
         (long long)blockIdx.x * rows + ty, pixels, (long long)gridDim.x * rows,
         [&](long long q) {
           V3 v;
           v.a = ld4(gy + (size_t)q * ldgy + cb);
           v.b = ld4(x + (size_t)q * ldx + cb);
-          if (act != LHG_ACT_NONE) v.c = ld4(y + (size_t)q * ldy + cb);
+          if (act != LHG_ACT_NONE && !recompute) v.c = ld4(y + (size_t)q * ldy + cb);
           return v;
         },
         [&](long long q, const V3& v) {
           f32x4 g = v.a;
-          if (act != LHG_ACT_NONE) g *= act_grad4(v.c, act, slope);
+          if (act != LHG_ACT_NONE) g *= act_grad4(recompute ? bn_affine(v.b, fa, fb) : v.c, act, slope);
           if (gres) st4(gres + (size_t)q * ldgres + cb, g);
           const f32x4 xh = (v.b - mean) * inv;
           const f32x4 o = k * (g - mg - xh * mgx);
@@ -582,21 +611,24 @@ static int bn_apply_impl(const float* x, int ldx, long long pixels, int C, const
 template <class T>
 static int bn_backward_impl(const float* gy, int ldgy, const float* x, int ldx, const float* y, int ldy, long long pixels, int C,
                             const float* stats, const float* gamma, int act, float slope, float* gx, int ldgx, float* gres, int ldgres,
-                            float* ggamma, float* gbeta, int accumulate, float* ws, float* gx_absmax, lhg_stream_t s) {
+                            float* ggamma, float* gbeta, int accumulate, float* ws, float* gx_absmax, const float* beta, lhg_stream_t s) {
   LHG_NHWC_OK(gy, C, ldgy, "bn_backward(gy)");
   LHG_NHWC_OK(x, C, ldx, "bn_backward(x)");
   LHG_NHWC_OK(gx, C, ldgx, "bn_backward(gx)");
-  if (act != LHG_ACT_NONE) LHG_NHWC_OK(y, C, ldy, "bn_backward(y)");
+  if (act != LHG_ACT_NONE && y) LHG_NHWC_OK(y, C, ldy, "bn_backward(y)");
+  if (act != LHG_ACT_NONE && !y)
+    LHG_REQUIRE(beta != nullptr && gres == nullptr && (act == LHG_ACT_RELU || act == LHG_ACT_LEAKY),
+                "bn_backward: without y the mask is recomputed from x: needs beta, no residual, ReLU / LeakyReLU");
   if (gres) LHG_NHWC_OK(gres, C, ldgres, "bn_backward(gres)");
   const ColMap cm = col_map(C);
   const int nblk = partial_blocks(pixels, cm.gy);
   float* sums = ws + (size_t)nblk * 2 * C;
   hipLaunchKernelGGL((bn_bwd_partial<T>), dim3(nblk, cm.gy), dim3(256), 0, as_stream(s), as_act<T>(gy), ldgy, as_act<T>(x), ldx, as_act<T>(y), ldy, pixels, C,
-                     stats, act, slope, cm.lanes_c, cm.rows, ws);
+                     stats, gamma, beta, act, slope, cm.lanes_c, cm.rows, ws);
   hipLaunchKernelGGL(reduce_partials<2>, dim3((C + 31) / 32, 2), dim3(1024), 0, as_stream(s), ws, nblk, C, sums, 0);
   const int nb2 = grid_for((size_t)pixels, cm.rows * 4, std::max(1, 2048 / cm.gy));
   hipLaunchKernelGGL((bn_bwd_apply<T>), dim3(nb2, cm.gy), dim3(256), 0, as_stream(s), as_act<T>(gy), ldgy, as_act<T>(x), ldx, as_act<T>(y), ldy, pixels, C, stats,
-                     gamma, sums, act, slope, as_act<T>(gx), ldgx, as_act<T>(gres), ldgres, ggamma, gbeta, accumulate, cm.lanes_c, cm.rows, gx_absmax);
+                     gamma, sums, act, slope, as_act<T>(gx), ldgx, as_act<T>(gres), ldgres, ggamma, gbeta, accumulate, cm.lanes_c, cm.rows, gx_absmax, beta);
   return check_launch("bn_backward");
 }
 
@@ -679,9 +711,9 @@ int lhg_bn_apply(const float* x, int ldx, long long pixels, int C, const float* 
 }
 int lhg_bn_backward(const float* gy, int ldgy, const float* x, int ldx, const float* y, int ldy, long long pixels, int C,
                     const float* stats, const float* gamma, int act, float slope, float* gx, int ldgx, float* gres, int ldgres,
-                    float* ggamma, float* gbeta, int accumulate, float* ws, float* gx_absmax, lhg_stream_t s) {
+                    float* ggamma, float* gbeta, int accumulate, float* ws, float* gx_absmax, const float* beta, lhg_stream_t s) {
   return LHG_ACT_CALL(bn_backward_impl, gy, ldgy, x, ldx, y, ldy, pixels, C, stats, gamma, act, slope, gx, ldgx, gres, ldgres, ggamma, gbeta,
-                      accumulate, ws, gx_absmax, s);
+                      accumulate, ws, gx_absmax, beta, s);
 }
 int lhg_bn_backward_backward(const float* ggx, const float* gy, const float* x, const float* y, long long pixels, int C,
                              const float* stats, const float* gamma, int act, float slope, float* ggy, float* gx2, float* ggamma2,

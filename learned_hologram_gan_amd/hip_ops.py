@@ -977,6 +977,7 @@ class BatchNormTrainFn(TrackedFunction):
         ctx.save_for_backward(x, y, gamma, stats)
         ctx.act, ctx.slope, ctx.has_res = act, slope, res is not None
         ctx.beta = beta if ctx.needs_input_grad[2] else None
+        ctx.beta_value = beta  # the backward kernels recompute the activation mask from x (no residual: one tensor read less per pass)
         note_use(gamma, ctx.needs_input_grad[1])
         note_use(ctx.beta)
         return y
@@ -989,7 +990,7 @@ class BatchNormTrainFn(TrackedFunction):
         s_beta = _small_grad_slot(ctx.beta)
         if s_gamma is not None and s_beta is not None and param_grads_wanted():
             # plain backward into the flat gradient buffer: the kernel adds d gamma / d beta to their slots itself
-            gx, gres = bn_backward_raw(gy, x, y, gamma, stats, ctx.act, ctx.slope, ctx.has_res, s_gamma, s_beta, True)
+            gx, gres = bn_backward_raw(gy, x, y, gamma, stats, ctx.act, ctx.slope, ctx.has_res, s_gamma, s_beta, True, ctx.beta_value)
             note_contribution(gamma)
             note_contribution(ctx.beta)
             return gx, None, None, None, None, (gres if ctx.has_res else None), None, None, None
@@ -997,16 +998,20 @@ class BatchNormTrainFn(TrackedFunction):
         return gx, ggamma, gbeta, None, None, (gres if ctx.has_res else None), None, None, None
 
 
-def bn_backward_raw(gy, x, y, gamma, stats, act, slope, want_res, ggamma, gbeta, accumulate):
-    """lhg_bn_backward; ggamma / gbeta are written (or, with ``accumulate``, added to).  Returns (gx, gres)."""
+def bn_backward_raw(gy, x, y, gamma, stats, act, slope, want_res, ggamma, gbeta, accumulate, beta=None):
+    """lhg_bn_backward; ggamma / gbeta are written (or, with ``accumulate``, added to).  Returns (gx, gres).  With ``beta`` (and no
+    residual, ReLU / LeakyReLU) the kernels recompute the activation mask from x instead of reading y."""
     pg, N, H, W, Cc, ldg = nhwc(gy)
     px, _, _, _, _, ldx = nhwc(x)
     py, _, _, _, _, ldy = nhwc(y)
+    if beta is not None and not want_res and act in (ACT_RELU, ACT_LEAKY) and _ACT_DTYPE == torch.float32:
+        py = None
     gx = new_nhwc(N, H, W, Cc, gy.device)
     gres = new_nhwc(N, H, W, Cc, gy.device) if want_res else None
     gx_amax = fused_absmax_slot(gy.device)  # gx is the gy of the preceding conv's two backward GEMMs
     call("lhg_bn_backward", pg, ldg, px, ldx, py, ldy, N * H * W, Cc, ptr(stats), ptr(gamma), act, float(slope),
-         ptr(gx), Cc, ptr(gres), Cc, ptr(ggamma), ptr(gbeta), int(accumulate), ptr(_bn_ws(Cc, gy.device)), ptr(gx_amax), stream_ptr())
+         ptr(gx), Cc, ptr(gres), Cc, ptr(ggamma), ptr(gbeta), int(accumulate), ptr(_bn_ws(Cc, gy.device)), ptr(gx_amax), ptr(beta),
+         stream_ptr())
     tag_absmax(gx, gx_amax)
     return gx, gres
 
