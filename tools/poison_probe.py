@@ -4,19 +4,19 @@ bit.  usage: poison_probe.py [rows=64] [pad=32]"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
+torch.manual_seed(122731)  # random-init weights: the probe compares the step with itself
 from learned_hologram_gan_amd import hip_ops
 from learned_hologram_gan_amd.watermelon_hologram.watermelon import watermelon
-from oracle import seeded  # seeded weights / inputs only
 
 rows = int(sys.argv[1]) if len(sys.argv) > 1 else 64
 pad = int(sys.argv[2]) if len(sys.argv) > 2 else 32
 dev = "cuda:0"
 stack = torch.linspace(-4e-4, 0.0, 21)[:-1][:8]
 W = watermelon(filter_radius_coefficient=0.45, pad_size=pad, distance_stack=stack, input_shape=(1, 4, rows, rows))
-W.generator.load_state_dict(seeded.generator_state_dict()); W.discriminator.load_state_dict(seeded.critic_state_dict())
 W.generator.to(dev).train(); W.discriminator.to(dev).train()
 W.configure(1, 0.0, 1, 1e-3, 0.1, 1e-3, 1e-3, 1, 10)
-rgbd, tamp, tphs = seeded.smooth_batch(2, rows, rows, seed=200)
+g = torch.Generator().manual_seed(200)
+rgbd, tamp, tphs = (torch.rand((2, c, rows, rows), generator=g) for c in (4, 3, 3))
 idx = torch.tensor([5, 2]); alphas = [torch.tensor([0.3, 0.8]).view(2, 1, 1, 1).to(dev)]
 x = (rgbd.to(dev), tamp.to(dev), tphs.to(dev), idx, alphas)
 grabbed = {}
