@@ -695,3 +695,20 @@ def test_f16_split_tracks_exact_fp32_over_operand_scales(ops, scale):
     got, want = run("fp32_split_f16"), run("fp32")
     for a, b in zip(got, want):
         assert torch.isfinite(a).all() and rel_err(a.cpu().double(), b.cpu().double()) < 3e-6, scale
+
+
+@pytest.mark.parametrize("variant", [5, 8], ids=lambda v: f"gg4s_variant{v}")
+def test_strip_kernel_is_exercised_when_forced(variant):
+    """The autotuner decides per geometry whether a 3x3 stride-1 launch runs on the strip kernel (gg4s) — on the small shapes of this
+    file it may never win.  Force it (64 x 64 and 128 x 128 tiles; LHG_GGS_VARIANT is read once per process, hence the child process)
+    and run the convolution parity tests, ragged extents and the fp64 comparison included."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, LHG_AUTOTUNE="0", LHG_GGS_VARIANT=str(variant))
+    out = subprocess.run([sys.executable, "-m", "pytest", os.path.join(root, "tests", "test_gpu_ops.py"), "-m", "gpu", "-x", "-q", "-p", "no:cacheprovider",
+                          "-k", "conv2d_forward_and_gradients or split_gemm or randomised_shape_sweep or fused_epilogue"],
+                         cwd=root, env=env, capture_output=True, text=True)
+    assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-500:]
