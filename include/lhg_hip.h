@@ -129,6 +129,17 @@ int lhg_absmax(const float* x, long long pixels, int C, int ld, float* out, lhg_
  *      nn.LazyConvTranspose2d weights (IOHW) :270-286. */
 int lhg_pack_weight(const float* w, int D0, int D1, int KH, int KW, int rows_from_d0,
                     float* dst, int rows_pad, int k_pad, lhg_stream_t s);
+/* The same for `n` weights at once (a HOST array of descriptors, read before the call returns): what a model needs after every
+ * optimiser step (ref: the Adam steps of watermelon.py:137-138 touch every conv weight of the stepped network).  In
+ * LHG_PRECISION_F32_SPLIT_F16 the fill of the max|w| words, the max|w| passes and the packs of up to 64 weights share three launches
+ * instead of three per weight; the other modes pack one weight per launch.  Each `dst` holds lhg_packed_weight_floats() floats;
+ * results are identical to n lhg_pack_weight calls. */
+typedef struct lhg_pack_item {
+  const float* w;
+  float* dst;
+  int D0, D1, KH, KW, rows_from_d0, rows_pad, k_pad;
+} lhg_pack_item;
+int lhg_pack_weights(const lhg_pack_item* items, int n, lhg_stream_t s);
 
 /* ------------------------------------------------------------------ convolution family
  * One implicit-GEMM engine (MFMA v_mfma_f32_32x32x2_f32, LDS-tiled, no im2col buffer).

@@ -454,6 +454,79 @@ static int launch_absmax(const float* x, long long pixels, int C, int ld, float*
   return check_launch("absmax");
 }
 
+// ------------------------------------------------------------------ batched weight packing (fp16-split mode)
+// After an optimiser step every conv weight of the model needs its panels again: per weight that is a fill of the max|w| word, the
+// max|w| pass and the pack — three small launches, ~200 per train step.  lhg_pack_weights does the same work for up to PACK_BATCH
+// weights in three launches: the descriptors travel in the kernel arguments, `blk0` / `ablk0` are running block counts and a
+// workgroup finds its weight with a (wave-uniform) scan over them.
+constexpr int PACK_BATCH = 64;
+struct PackItem {
+  const float* w;
+  _Float16* dst;
+  unsigned* amax;
+  int D0, D1, T, rows_from_d0, rows_pad, k_pad;
+  unsigned blk0, ablk0;  // first workgroup of this weight in the pack / max|w| launches
+};
+struct PackBatch {
+  int n;
+  unsigned blocks, ablocks;
+  PackItem it[PACK_BATCH];
+};
+
+__global__ void pack_batch_zero_kernel(const PackBatch b) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < b.n) *b.it[i].amax = 0u;
+}
+
+__device__ __forceinline__ int pack_batch_find(const PackBatch& b, unsigned blk, bool amax_pass) {
+  int i = 0;
+  while (i + 1 < b.n && (amax_pass ? b.it[i + 1].ablk0 : b.it[i + 1].blk0) <= blk) ++i;
+  return i;
+}
+
+__global__ __launch_bounds__(256) void pack_batch_absmax_kernel(const PackBatch b) {
+  const int i = pack_batch_find(b, blockIdx.x, true);
+  const PackItem& it = b.it[i];
+  const unsigned nblk = (i + 1 < b.n ? b.it[i + 1].ablk0 : b.ablocks) - it.ablk0;
+  const size_t total = (size_t)it.D0 * it.D1 * it.T;
+  unsigned m = 0;
+  for (size_t e = (size_t)(blockIdx.x - it.ablk0) * 256 + threadIdx.x; e < total; e += (size_t)nblk * 256)
+    m = max(m, __float_as_uint(it.w[e]) & 0x7fffffffu);
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
+  __shared__ unsigned red[4];
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = m;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    m = max(max(red[0], red[1]), max(red[2], red[3]));
+    if (m > *reinterpret_cast<volatile unsigned*>(it.amax)) atomicMax(it.amax, m);
+  }
+}
+
+__global__ __launch_bounds__(256) void pack_batch_kernel(const PackBatch b) {  // pack_weight_split_kernel<2, _Float16> per weight
+  const int i = pack_batch_find(b, blockIdx.x, false);
+  const PackItem& it = b.it[i];
+  const unsigned nblk = (i + 1 < b.n ? b.it[i + 1].blk0 : b.blocks) - it.blk0;
+  const size_t total = (size_t)it.T * it.rows_pad * it.k_pad;
+  const int kch = it.k_pad / 32;
+  const float sc = split_scale(__uint_as_float(*it.amax));
+  const int rows = it.rows_from_d0 ? it.D0 : it.D1, K = it.rows_from_d0 ? it.D1 : it.D0;
+  for (size_t e = (size_t)(blockIdx.x - it.blk0) * 256 + threadIdx.x; e < total; e += (size_t)nblk * 256) {
+    const int k = (int)(e % it.k_pad);
+    const int row = (int)((e / it.k_pad) % it.rows_pad);
+    const int t = (int)(e / ((size_t)it.k_pad * it.rows_pad));
+    float v = 0.f;
+    if (row < rows && k < K) {
+      const int d0 = it.rows_from_d0 ? row : k, d1 = it.rows_from_d0 ? k : row;
+      v = it.w[((size_t)d0 * it.D1 + d1) * it.T + t] * sc;
+    }
+    _Float16* out = it.dst + ((((size_t)t * it.rows_pad + row) * kch + k / 32) * 2) * 32 + (k & 31);
+    const _Float16 h0 = (_Float16)v;
+    out[0] = h0;
+    out[32] = (_Float16)(v - (float)h0);
+  }
+}
+
 // grad[d0][d1][t] = sum_s slabs[s][t][m][n].  Block = 64 consecutive outputs (n fastest: coalesced slab reads) x 4 slab
 // slices; each thread sums every 4th slab, then the slices are combined through LDS.
 template <int LANES>  // outputs per block; 256 / LANES slab slices
@@ -1067,6 +1140,46 @@ int lhg_pack_weight(const float* w, int D0, int D1, int KH, int KW, int rows_fro
   else
     hipLaunchKernelGGL(pack_weight_kernel, dim3(blocks), dim3(256), 0, as_stream(s), w, D0, D1, KH * KW, rows_from_d0, dst, rows_pad, k_pad);
   return check_launch("pack_weight");
+}
+
+int lhg_pack_weights(const lhg_pack_item* items, int n, lhg_stream_t s) {
+  LHG_REQUIRE(n >= 0 && (n == 0 || items != nullptr), "pack_weights: bad item list");
+  if (g_precision != LHG_PRECISION_F32_SPLIT_F16) {  // the other modes have no max|w| pass to share: one pack launch per weight
+    for (int i = 0; i < n; ++i) {
+      const lhg_pack_item& q = items[i];
+      const int rc = lhg_pack_weight(q.w, q.D0, q.D1, q.KH, q.KW, q.rows_from_d0, q.dst, q.rows_pad, q.k_pad, s);
+      if (rc) return rc;
+    }
+    return LHG_OK;
+  }
+  for (int first = 0; first < n; first += PACK_BATCH) {
+    PackBatch b;
+    b.n = std::min(PACK_BATCH, n - first);
+    unsigned blk = 0, ablk = 0;
+    for (int i = 0; i < b.n; ++i) {
+      const lhg_pack_item& q = items[first + i];
+      const int rows = q.rows_from_d0 ? q.D0 : q.D1, K = q.rows_from_d0 ? q.D1 : q.D0;
+      LHG_REQUIRE(q.w && q.dst && q.D0 > 0 && q.D1 > 0 && q.KH > 0 && q.KW > 0, "pack_weights: item %d is empty", first + i);
+      LHG_REQUIRE(q.rows_pad >= rows && q.k_pad >= K && q.rows_pad % 64 == 0 && q.k_pad % 32 == 0, "pack_weights: bad padding of item %d (%d>=%d, %d>=%d)",
+                  first + i, q.rows_pad, rows, q.k_pad, K);
+      const size_t total = (size_t)q.KH * q.KW * q.rows_pad * q.k_pad, elems = (size_t)q.D0 * q.D1 * q.KH * q.KW;
+      PackItem& it = b.it[i];
+      it.w = q.w;
+      it.dst = reinterpret_cast<_Float16*>(q.dst);
+      it.amax = reinterpret_cast<unsigned*>(q.dst + total);
+      it.D0 = q.D0; it.D1 = q.D1; it.T = q.KH * q.KW; it.rows_from_d0 = q.rows_from_d0; it.rows_pad = q.rows_pad; it.k_pad = q.k_pad;
+      it.blk0 = blk;
+      it.ablk0 = ablk;
+      blk += (unsigned)std::min<size_t>((total + 1023) / 1024, 1024);   // >= 4 elements per thread
+      ablk += (unsigned)std::min<size_t>((elems + 4095) / 4096, 64);
+    }
+    b.blocks = blk;
+    b.ablocks = ablk;
+    hipLaunchKernelGGL(pack_batch_zero_kernel, dim3(1), dim3(PACK_BATCH), 0, as_stream(s), b);
+    hipLaunchKernelGGL(pack_batch_absmax_kernel, dim3(ablk), dim3(256), 0, as_stream(s), b);
+    hipLaunchKernelGGL(pack_batch_kernel, dim3(blk), dim3(256), 0, as_stream(s), b);
+  }
+  return check_launch("pack_weights");
 }
 
 int lhg_set_conv_precision(int precision) {

@@ -141,25 +141,6 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const T* __restrict__ x,
       });
 }
 
-template <class T>
-__global__ void bn_stats_final(const float* __restrict__ sums /* [2][C] shifted sums */, const T* __restrict__ x, long long pixels, int C,
-                               float* __restrict__ stats, float* running_mean, float* running_var, float momentum, float eps) {
-  const int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  const double n = (double)pixels;
-  const double dm = (double)sums[c] / n;
-  const double mean = (double)ld1(x + c) + dm;
-  double var = (double)sums[C + c] / n - dm * dm;
-  if (var < 0) var = 0;
-  stats[c] = (float)mean;
-  stats[C + c] = (float)(1.0 / sqrt(var + (double)eps));
-  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-  if (running_var) {
-    const double unbiased = n > 1 ? var * n / (n - 1) : var;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
-  }
-}
-
 // v = x * a + b with ONE rounding per element (fma), a = invstd * gamma, b = beta - mean * a: the pre-activation of bn_apply.  The backward
 // kernels evaluate the same expression when they derive the activation mask from x instead of reading the forward output y
 // (no residual, ReLU / LeakyReLU: sign(y) == sign(v) exactly, one tensor read less per pass).
@@ -271,6 +252,56 @@ __global__ __launch_bounds__(1024) void reduce_partials(const float* __restrict_
     for (int i = 0; i < RP_SLICES; ++i) s += red[i][lane_c];
     float* dst = sums + (size_t)k * C + c;
     *dst = accumulate ? *dst + (float)s : (float)s;
+  }
+}
+
+// reduce_partials<2> and bn_stats_final in one launch: the 32 channels of a block sum their two shifted-sum columns over the partial
+// rows (same order and roundings as the two kernels) and slice 0 writes mean / invstd and the running statistics.
+template <class T>
+__global__ __launch_bounds__(1024) void bn_stats_reduce_final(const float* __restrict__ partial, int nblk, const T* __restrict__ x,
+                                                              long long pixels, int C, float* __restrict__ stats, float* running_mean,
+                                                              float* running_var, float momentum, float eps) {
+  __shared__ double red[2][RP_SLICES][32];
+  const int lane_c = threadIdx.x & 31, slice = threadIdx.x >> 5;
+  const int c = blockIdx.x * 32 + lane_c;
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
+    if (c < C) {
+      const float* src = partial + (size_t)k * C + c;
+      const size_t stride = (size_t)2 * C;
+      int b = slice;
+      for (; b + 3 * RP_SLICES < nblk; b += 4 * RP_SLICES) {
+        s0 += src[(size_t)b * stride];
+        s1 += src[(size_t)(b + RP_SLICES) * stride];
+        s2 += src[(size_t)(b + 2 * RP_SLICES) * stride];
+        s3 += src[(size_t)(b + 3 * RP_SLICES) * stride];
+      }
+      for (; b < nblk; b += RP_SLICES) s0 += src[(size_t)b * stride];
+    }
+    red[k][slice][lane_c] = (s0 + s1) + (s2 + s3);
+  }
+  __syncthreads();
+  if (slice != 0 || c >= C) return;
+  double sum[2];
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    double s = 0;
+#pragma unroll
+    for (int i = 0; i < RP_SLICES; ++i) s += red[k][i][lane_c];
+    sum[k] = (double)(float)s;
+  }
+  const double n = (double)pixels;
+  const double dm = sum[0] / n;
+  const double mean = (double)ld1(x + c) + dm;
+  double var = sum[1] / n - dm * dm;
+  if (var < 0) var = 0;
+  stats[c] = (float)mean;
+  stats[C + c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+  if (running_var) {
+    const double unbiased = n > 1 ? var * n / (n - 1) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
   }
 }
 
@@ -588,10 +619,8 @@ static int bn_stats_impl(const float* x, long long pixels, int C, int ld, float*
   const ColMap cm = col_map(C);
   const int nblk = partial_blocks(pixels, cm.gy);
   hipLaunchKernelGGL((bn_stats_partial<T>), dim3(nblk, cm.gy), dim3(256), 0, as_stream(s), as_act<T>(x), pixels, C, ld, cm.lanes_c, cm.rows, ws);
-  float* sums = ws + (size_t)nblk * 2 * C;
-  hipLaunchKernelGGL(reduce_partials<2>, dim3((C + 31) / 32, 2), dim3(1024), 0, as_stream(s), ws, nblk, C, sums, 0);
-  hipLaunchKernelGGL((bn_stats_final<T>), dim3((C + 255) / 256), dim3(256), 0, as_stream(s), sums, as_act<T>(x), pixels, C, stats, running_mean,
-                     running_var, momentum, eps);
+  hipLaunchKernelGGL((bn_stats_reduce_final<T>), dim3((C + 31) / 32), dim3(1024), 0, as_stream(s), ws, nblk, as_act<T>(x), pixels, C, stats,
+                     running_mean, running_var, momentum, eps);
   return check_launch("bn_stats");
 }
 

@@ -512,13 +512,44 @@ def pack_weight(w: torch.Tensor, rows_from_d0: bool, k_pad_to: int = 32) -> torc
     wd = w.detach()
     if not wd.is_contiguous():
         wd = wd.contiguous()
-    floats = int(native.load().lhg_packed_weight_floats(KH * KW, rows_pad, k_pad))
-    panel_rows = KH * KW * rows_pad
-    buf = torch.empty((floats,), dtype=torch.float32, device=w.device)  # panels (+ 16 bytes behind them in the fp16-split mode: max|w|)
-    out = buf[: panel_rows * (floats // panel_rows)].view(KH * KW, rows_pad, floats // panel_rows)
+    out = _packed_buffer(KH, KW, rows_pad, k_pad, w.device)
     call("lhg_pack_weight", ptr(wd), D0, D1, KH, KW, int(rows_from_d0), ptr(out), rows_pad, k_pad, stream_ptr())
     cache[(rows_from_d0, k_pad, _mode())] = (stamp, out)
     return out
+
+
+def _packed_buffer(KH, KW, rows_pad, k_pad, device):
+    floats = int(native.load().lhg_packed_weight_floats(KH * KW, rows_pad, k_pad))
+    panel_rows = KH * KW * rows_pad
+    buf = torch.empty((floats,), dtype=torch.float32, device=device)  # panels (+ 16 bytes behind them in the fp16-split mode: max|w|)
+    return buf[: panel_rows * (floats // panel_rows)].view(KH * KW, rows_pad, floats // panel_rows)
+
+
+def repack_weights(params) -> int:
+    """Refresh, in one batched call (lhg_pack_weights), every packed form the ops hold of weights that changed since they were
+    packed — what an optimiser step leaves behind (ref: watermelon.py:137-138).  Without it each conv re-packs its weight on its
+    next use: the same values from ~200 small launches per train step.  Returns the number of panels written."""
+    mode, items, fresh = _mode(), [], []
+    for w in params:
+        cache = w.__dict__.get("_lhg_packed")
+        if not cache or w.dim() != 4 or not w.is_cuda or not w.is_contiguous():
+            continue
+        stamp = (w.data_ptr(), w._version, tuple(w.shape))
+        D0, D1, KH, KW = w.shape
+        for key, (old, _) in list(cache.items()):
+            rows_from_d0, k_pad, m = key
+            if m != mode or old == stamp or old[0] != stamp[0] or old[2] != stamp[2]:
+                continue
+            rows_pad = pad_to(D0 if rows_from_d0 else D1, 64)
+            out = _packed_buffer(KH, KW, rows_pad, k_pad, w.device)
+            items.append(native.PackItem(w.data_ptr(), out.data_ptr(), D0, D1, KH, KW, int(rows_from_d0), rows_pad, k_pad))
+            fresh.append((cache, key, stamp, out))
+    if items:
+        arr = (native.PackItem * len(items))(*items)
+        call("lhg_pack_weights", arr, len(items), stream_ptr())
+        for cache, key, stamp, out in fresh:
+            cache[key] = (stamp, out)
+    return len(items)
 
 
 def bump_version(t: torch.Tensor):

@@ -29,6 +29,12 @@ class AsmFilter(C.Structure):
     _fields_ = [("f1", _p), ("f1_index", _p), ("f1_op", _i), ("f2", _p), ("f2_index", _p), ("f2_op", _i)]
 
 
+class PackItem(C.Structure):
+    """lhg_pack_item (include/lhg_hip.h)."""
+    _fields_ = [("w", C.c_void_p), ("dst", C.c_void_p), ("D0", C.c_int), ("D1", C.c_int), ("KH", C.c_int), ("KW", C.c_int),
+                ("rows_from_d0", C.c_int), ("rows_pad", C.c_int), ("k_pad", C.c_int)]
+
+
 # name -> argtypes (restype is int unless listed in _RESTYPE)
 _SIGNATURES = {
     "lhg_abi_version": [],
@@ -45,6 +51,7 @@ _SIGNATURES = {
     "lhg_default_conv_precision": [],
     "lhg_packed_weight_floats": [C.c_int, C.c_int, C.c_int],
     "lhg_pack_weight": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _p],
+    "lhg_pack_weights": [_p, _i, _p],
     "lhg_conv2d_forward": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _i, _i, _f, _i, _p, _p, _p],
     "lhg_conv2d_backward_input": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p, _p],
     "lhg_conv2d_wgrad_splits": [_i, _i, _i, _i, _i, _i, _i, _i],

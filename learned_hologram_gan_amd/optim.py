@@ -73,6 +73,8 @@ class FusedAdam:
                            self.eps, self.step_count)
         for p in self.flat.params:
             hip_ops.bump_version(p)
+        if self.flat.data.is_cuda:
+            hip_ops.repack_weights(self.flat.params)  # every packed form the convs hold, in one batched call
 
     def state_dict(self):
         return dict(step=self.step_count, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, lr=self.lr, betas=self.betas, eps=self.eps)

@@ -712,3 +712,66 @@ def test_strip_kernel_is_exercised_when_forced(variant):
                           "-k", "conv2d_forward_and_gradients or split_gemm or randomised_shape_sweep or fused_epilogue"],
                          cwd=root, env=env, capture_output=True, text=True)
     assert out.returncode == 0, out.stdout[-1500:] + out.stderr[-500:]
+
+
+@pytest.mark.parametrize("mode", ["fp32_split_f16", "fp32_split", "fp32"])
+def test_batched_weight_pack_equals_per_weight_packs(ops, mode):
+    """lhg_pack_weights (one call after an optimiser step) writes bit-for-bit what the lazy per-weight lhg_pack_weight writes, for both
+    panel orientations and more weights than one batch of kernel arguments holds; forms that are still current are left alone."""
+    prev = ops.conv_precision()
+    ops.set_conv_precision(mode)
+    try:
+        torch.manual_seed(21)
+        code = ops._mode()
+        shapes = [(64, 32, 3, 3), (128, 64, 3, 3), (32, 64, 2, 2), (70, 33, 1, 1), (1024, 512, 3, 3)] + [(64, 64, 3, 3)] * 34
+        ws = [torch.randn(s, device=DEV) * (10.0 ** (i % 5 - 2)) for i, s in enumerate(shapes)]
+        for w in ws:  # first use: the lazy path
+            ops.pack_weight(w, True)
+            ops.pack_weight(w, False)
+        assert ops.repack_weights(ws) == 0  # nothing is stale
+        for w in ws[:-1]:
+            w.mul_(1.5).add_(0.01)  # what an optimiser step does: new values, new version, same storage
+        stale = [w.__dict__["_lhg_packed"][(True, ops.pad_to(w.shape[1], 32), code)][1] for w in ws]
+        assert ops.repack_weights(ws) == 2 * (len(ws) - 1)  # two batches of kernel arguments
+        got = [(ops.pack_weight(w, True), ops.pack_weight(w, False)) for w in ws]  # cache hits now
+        assert got[-1][0] is stale[-1] and all(g[0] is not s for g, s in zip(got[:-1], stale[:-1]))
+        for w, (a, b) in zip(ws, got):
+            fresh = w.clone()  # no cache on the clone: packed by lhg_pack_weight
+            fa, fb = ops.pack_weight(fresh, True), ops.pack_weight(fresh, False)
+            assert torch.equal(a.view(torch.int32), fa.view(torch.int32)) and torch.equal(b.view(torch.int32), fb.view(torch.int32))
+            if mode == "fp32_split_f16":  # max|w| behind the panels
+                tail = lambda t: torch.as_strided(t, (1,), (1,), t.numel())  # noqa: E731
+                assert float(tail(a)) == float(w.abs().max()) == float(tail(fa))
+        assert ops.repack_weights(ws) == 0
+    finally:
+        ops.set_conv_precision(prev)
+
+
+def test_optimizer_step_leaves_every_packed_form_current(ops):
+    """FusedAdam.step re-packs, in its batched call, the forms the convs hold: the next forward / backward find them in the cache."""
+    from learned_hologram_gan_amd import optim
+
+    torch.manual_seed(3)
+    net = torch.nn.Sequential(torch.nn.Conv2d(32, 64, 3, padding=1), torch.nn.Conv2d(64, 32, 3, padding=1)).to(DEV)
+    opt = optim.FusedAdam(optim.FlatParams(net), lr=1e-2)
+    x = torch.randn(2, 12, 12, 32, device=DEV, requires_grad=True)
+
+    def run():
+        h = ops.Conv2dFn.apply(x, net[0].weight, net[0].bias, 1, None)
+        y = ops.Conv2dFn.apply(h, net[1].weight, net[1].bias, 1, None)
+        opt.zero_grad()
+        y.square().mean().backward()
+        return y
+
+    run()
+    opt.step()
+    for conv in net:
+        w = conv.weight
+        stamp = (w.data_ptr(), w._version, tuple(w.shape))
+        forms = w.__dict__["_lhg_packed"]
+        assert len(forms) == 2 and all(s == stamp for s, _ in forms.values())
+    before = {id(v[1]) for conv in net for v in conv.weight.__dict__["_lhg_packed"].values()}
+    y1 = run()
+    assert before == {id(v[1]) for conv in net for v in conv.weight.__dict__["_lhg_packed"].values()}  # no re-pack on use
+    ref = F.conv2d(F.conv2d(x.detach().permute(0, 3, 1, 2), net[0].weight, net[0].bias, padding=1), net[1].weight, net[1].bias, padding=1)
+    assert rel_err(y1.detach().permute(0, 3, 1, 2).cpu(), ref.cpu()) < TOL
