@@ -490,8 +490,14 @@ __global__ __launch_bounds__(256) void pack_batch_absmax_kernel(const PackBatch 
   const unsigned nblk = (i + 1 < b.n ? b.it[i + 1].ablk0 : b.ablocks) - it.ablk0;
   const size_t total = (size_t)it.D0 * it.D1 * it.T;
   unsigned m = 0;
-  for (size_t e = (size_t)(blockIdx.x - it.ablk0) * 256 + threadIdx.x; e < total; e += (size_t)nblk * 256)
-    m = max(m, __float_as_uint(it.w[e]) & 0x7fffffffu);
+  const unsigned* w = reinterpret_cast<const unsigned*>(it.w);
+  const size_t stride = (size_t)nblk * 256;
+  size_t e = (size_t)(blockIdx.x - it.ablk0) * 256 + threadIdx.x;
+  for (; e + 3 * stride < total; e += 4 * stride) {  // four loads in flight
+    const unsigned a = w[e], b2 = w[e + stride], c = w[e + 2 * stride], d = w[e + 3 * stride];
+    m = max(max(m, a & 0x7fffffffu), max(b2 & 0x7fffffffu, max(c & 0x7fffffffu, d & 0x7fffffffu)));
+  }
+  for (; e < total; e += stride) m = max(m, w[e] & 0x7fffffffu);
 #pragma unroll
   for (int o = 32; o > 0; o >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o, 64));
   __shared__ unsigned red[4];
@@ -1170,8 +1176,8 @@ int lhg_pack_weights(const lhg_pack_item* items, int n, lhg_stream_t s) {
       it.D0 = q.D0; it.D1 = q.D1; it.T = q.KH * q.KW; it.rows_from_d0 = q.rows_from_d0; it.rows_pad = q.rows_pad; it.k_pad = q.k_pad;
       it.blk0 = blk;
       it.ablk0 = ablk;
-      blk += (unsigned)std::min<size_t>((total + 1023) / 1024, 1024);   // >= 4 elements per thread
-      ablk += (unsigned)std::min<size_t>((elems + 4095) / 4096, 64);
+      blk += (unsigned)std::min<size_t>((total + 1023) / 1024, 16384);  // 4 elements per thread (the largest weight sets the launch's duration)
+      ablk += (unsigned)std::min<size_t>((elems + 2047) / 2048, 2048);
     }
     b.blocks = blk;
     b.ablocks = ablk;

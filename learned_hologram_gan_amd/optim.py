@@ -10,9 +10,14 @@ they copy through the views.
 
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import hip_ops
+
+
+_BATCHED_REPACK = os.environ.get("LHG_BATCHED_REPACK", "1") != "0"  # 0: every conv re-packs its weight on its next use (for A/B timing)
 
 
 class FlatParams:
@@ -73,7 +78,7 @@ class FusedAdam:
                            self.eps, self.step_count)
         for p in self.flat.params:
             hip_ops.bump_version(p)
-        if self.flat.data.is_cuda:
+        if self.flat.data.is_cuda and _BATCHED_REPACK:
             hip_ops.repack_weights(self.flat.params)  # every packed form the convs hold, in one batched call
 
     def state_dict(self):
@@ -126,10 +131,11 @@ def run_pretraining(model, batch_loss, train_loader, val_loader, epochs, lr, gam
         model.train()
         total, n = torch.zeros((), device=model.optimizer.flat.data.device), 0
         for batch in train_loader:
-            loss, samples = batch_loss(batch)
-            model.optimizer.zero_grad()
-            loss.backward()
-            model.optimizer.step()
+            with hip_ops.deferred_gc():  # no collector pauses while the host thread is feeding the GPU
+                loss, samples = batch_loss(batch)
+                model.optimizer.zero_grad()
+                loss.backward()
+                model.optimizer.step()
             total, n = total + loss.detach(), n + samples
         train_loss = total.item() / n
         model.eval()

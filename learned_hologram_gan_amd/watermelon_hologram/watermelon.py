@@ -184,6 +184,10 @@ class watermelon:
         """One batch of the reference loop (watermelon.py:207-277).  Returns detached tensors for logging."""
         if self._opt_G is None:
             raise RuntimeError("call configure(...) (or train(...)) before train_step")
+        with hip_ops.deferred_gc():  # no collector pauses while the host thread is feeding the GPU
+            return self._train_step(RGBD, target_amp, target_phs, plane_indices, gp_alphas)
+
+    def _train_step(self, RGBD, target_amp, target_phs, plane_indices, gp_alphas):
         ratio = self.discriminator_train_ratio if self._opt_D is not None else 0
         POH, hat_amps, target_amps, hat_phases, target_phases = self.reconstruct(RGBD, target_amp, target_phs, plane_indices)
         fake = hat_amps.detach()

@@ -731,10 +731,11 @@ def test_batched_weight_pack_equals_per_weight_packs(ops, mode):
         assert ops.repack_weights(ws) == 0  # nothing is stale
         for w in ws[:-1]:
             w.mul_(1.5).add_(0.01)  # what an optimiser step does: new values, new version, same storage
-        stale = [w.__dict__["_lhg_packed"][(True, ops.pad_to(w.shape[1], 32), code)][1] for w in ws]
+        held = [w.__dict__["_lhg_packed"][(True, ops.pad_to(w.shape[1], 32), code)][1] for w in ws]
+        untouched = held[-1].clone()
         assert ops.repack_weights(ws) == 2 * (len(ws) - 1)  # two batches of kernel arguments
-        got = [(ops.pack_weight(w, True), ops.pack_weight(w, False)) for w in ws]  # cache hits now
-        assert got[-1][0] is stale[-1] and all(g[0] is not s for g, s in zip(got[:-1], stale[:-1]))
+        got = [(ops.pack_weight(w, True), ops.pack_weight(w, False)) for w in ws]  # cache hits now: the same buffers, rewritten in place
+        assert all(g[0] is h for g, h in zip(got, held)) and torch.equal(held[-1], untouched)
         for w, (a, b) in zip(ws, got):
             fresh = w.clone()  # no cache on the clone: packed by lhg_pack_weight
             fa, fb = ops.pack_weight(fresh, True), ops.pack_weight(fresh, False)
