@@ -166,6 +166,14 @@ int lhg_conv2d_forward(const float* x, int N, int H, int W, int Ci, int ldx,
 int lhg_conv2d_backward_input(const float* gy, int N, int H, int W, int Co, int ldgy,
                               const float* wp, int rows_pad, int KH, int KW, int stride,
                               float* gx, int Ci, int ldgx, const float* gy_absmax, lhg_stream_t s);
+/* gx = conv2d_backward_input(gy, W) + res: the sum autograd forms when the conv's input has a second consumer (the skip path of
+ * ResidualBlock, ref: neural_network_components.py:22-31: `X` feeds convolution_layer_1 and convolution_layer_3 / the identity),
+ * taken in the GEMM epilogue instead of by a separate pass over both gradients.  `res` (gx's pixels, ldres floats apart, >= Ci
+ * channels) may be NULL. */
+int lhg_conv2d_backward_input_add(const float* gy, int N, int H, int W, int Co, int ldgy,
+                                  const float* wp, int rows_pad, int KH, int KW, int stride,
+                                  float* gx, int Ci, int ldgx, const float* res, int ldres,
+                                  const float* gy_absmax, lhg_stream_t s);
 
 /* Partial weight gradients: slabs[S][KH*KW][ci_pad][co_pad] (S = split count chosen by
  * lhg_conv2d_wgrad_splits), to be summed by lhg_wgrad_reduce. */

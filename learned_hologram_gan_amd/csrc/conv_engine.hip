@@ -1222,7 +1222,13 @@ int lhg_conv2d_forward(const float* x, int N, int H, int W, int Ci, int ldx, con
 
 int lhg_conv2d_backward_input(const float* gy, int N, int H, int W, int Co, int ldgy, const float* wp, int rows_pad, int KH, int KW, int stride,
                               float* gx, int Ci, int ldgx, const float* gy_absmax, lhg_stream_t s) {
+  return lhg_conv2d_backward_input_add(gy, N, H, W, Co, ldgy, wp, rows_pad, KH, KW, stride, gx, Ci, ldgx, nullptr, 0, gy_absmax, s);
+}
+
+int lhg_conv2d_backward_input_add(const float* gy, int N, int H, int W, int Co, int ldgy, const float* wp, int rows_pad, int KH, int KW, int stride,
+                                  float* gx, int Ci, int ldgx, const float* res, int ldres, const float* gy_absmax, lhg_stream_t s) {
   LHG_REQUIRE(conv_args_ok(KH, KW, stride), "conv2d_backward_input: unsupported kernel %dx%d stride %d", KH, KW, stride);
+  LHG_REQUIRE(res == nullptr || ldres >= Ci, "conv2d_backward_input: the added gradient has %d floats per pixel, gx has %d channels", ldres, Ci);
   const int ph = KH / 2, pw = KW / 2;
   const int Ho = (H + 2 * ph - KH) / stride + 1, Wo = (W + 2 * pw - KW) / stride + 1;
   GGParams p{};
@@ -1230,6 +1236,7 @@ int lhg_conv2d_backward_input(const float* gy, int N, int H, int W, int Co, int 
   g.N = N; g.Hi = Ho; g.Wi = Wo; g.Ci = Co; g.ldi = ldgy;  // gathered tensor = gy
   g.Ho = H; g.Wo = W; g.Co = Ci; g.ldo = ldgx;             // scattered tensor = gx
   p.in = gy; p.wp = wp; p.out = gx; p.rows_pad = rows_pad; p.act = LHG_ACT_NONE;
+  p.res = res; p.ldres = ldres;  // indexed by the gx pixel in every parity class
   p.a_amax = gy_absmax; p.w_amax = weight_amax(wp, KH * KW, rows_pad, Co);
   if (stride == 1) {
     g.gh = H; g.gw = W; g.oy0 = g.ox0 = 0; g.ostep = 1; g.istep = 1; g.T = KH * KW;

@@ -720,13 +720,20 @@ class Conv2dFn(TrackedFunction):
 
     @staticmethod
     def backward(ctx, gy):
+        return Conv2dFn._backward(ctx, gy, None)
+
+    @staticmethod
+    def _backward(ctx, gy, g_shared):
+        """``g_shared``: the gradient that reached x through its other consumer (Conv2dSharedInputFn), added in the GEMM epilogue."""
         x, w = ctx.saved_tensors
-        gy = _as_nhwc_view(gy)  # autograd may hand out an expanded (zero-stride) gradient, e.g. from .sum()
         gx = gw = gb = None
+        if gy is None:  # only the alias of x was used downstream
+            return g_shared, None, None, None, None
+        gy = _as_nhwc_view(gy)  # autograd may hand out an expanded (zero-stride) gradient, e.g. from .sum()
         gemm = not (w.shape[2] == w.shape[3] and thin_mode(w.shape[1], w.shape[0], w.shape[2], ctx.stride))
         gy_amax = operand_absmax(gy) if gemm and gy.shape[-1] % 32 == 0 else None  # one measurement for both backward GEMMs
         if ctx.needs_input_grad[0]:
-            gx = Conv2dInputGradFn.apply(gy, w, ctx.stride, x.shape[1], x.shape[2], x.shape[3], gy_amax)
+            gx = Conv2dInputGradFn.apply(gy, w, ctx.stride, x.shape[1], x.shape[2], x.shape[3], gy_amax, g_shared)
         if not param_grads_wanted():  # inside only_input_gradients(): the caller differentiates with respect to activations only
             return gx, None, None, None, None
         if ctx.needs_input_grad[1]:
@@ -737,15 +744,47 @@ class Conv2dFn(TrackedFunction):
         return gx, gw, gb, None, None
 
 
+class Conv2dSharedInputFn(TrackedFunction):
+    """(conv2d(x, w) + bias, x): Conv2dFn for an input that has a second consumer — ``X`` of the reference's ResidualBlock feeds
+    convolution_layer_1 and the skip path (ref: neural_network_components.py:22-31).  The second output is x itself; whatever
+    gradient arrives through it is added to this conv's input gradient inside the GEMM epilogue (lhg_conv2d_backward_input_add)
+    instead of by autograd's accumulation pass over the two full-size gradients.  LHG_FUSE_SKIP_GRAD=0: callers use Conv2dFn."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, stride, out):
+        ctx.set_materialize_grads(False)  # an unused output must not cost a zero-filled gradient
+        return Conv2dFn.forward(ctx, x, w, bias, stride, out), x
+
+    @staticmethod
+    def backward(ctx, gy, g_shared):
+        return Conv2dFn._backward(ctx, gy, g_shared)
+
+
+FUSE_SKIP_GRAD = os.environ.get("LHG_FUSE_SKIP_GRAD", "1") != "0"
+
+
+def conv2d_shared_input(x, w, bias, stride, out):
+    """(y, x') with x' an alias of x for its other consumer — see Conv2dSharedInputFn."""
+    if not FUSE_SKIP_GRAD or not (torch.is_grad_enabled() and x.requires_grad):
+        return Conv2dFn.apply(x, w, bias, stride, out), x
+    y, xs = Conv2dSharedInputFn.apply(x, w, bias, stride, out)
+    return y, _inherit_absmax(xs, x)
+
+
 class Conv2dInputGradFn(TrackedFunction):
     """gx = d conv2d / d x contracted with gy.  Returns (N, H, W, pad32(Ci))."""
 
     @staticmethod
-    def forward(ctx, gy, w, stride, H, W, Cx, gy_amax=None):
+    def forward(ctx, gy, w, stride, H, W, Cx, gy_amax=None, res=None):
+        """``res``: a second gradient of the same tensor (N, H, W, >= Ci channels), added to the result in the GEMM epilogue."""
         ctx.save_for_backward(gy, w)
         ctx.stride = stride
         note_use(w, ctx.needs_input_grad[1])
         Co, Ci, KH, KW = w.shape
+        if res is not None:
+            res = _as_nhwc_view(res)
+            if tuple(res.shape[:3]) != (gy.shape[0], H, W) or res.shape[3] < Ci:
+                raise ValueError(f"conv2d input-grad: added gradient of shape {tuple(res.shape)} does not cover ({gy.shape[0]}, {H}, {W}, {Ci})")
         if KH == KW and gy.shape[-1] >= Co and thin_mode(Ci, Co, KH, stride):
             gyv = _as_nhwc_view(gy)  # keep the (possibly temporary) dense copy alive until the launch
             pg, N, _, _, _, ldg = nhwc(gyv)
@@ -753,6 +792,8 @@ class Conv2dInputGradFn(TrackedFunction):
             if Cx > Ci:
                 gx[..., Ci:].zero_()
             call("lhg_conv2d_thin_backward_input", pg, N, H, W, Co, ldg, ptr(_raw_weight(w)), Ci, KH, ptr(gx), Cx, stream_ptr())
+            if res is not None:
+                gx[..., :Ci] += res[..., :Ci]
             return gx
         gyp = _padded_gy(gy)
         pg, N, Ho, Wo, Cg, ldg = nhwc(gyp)
@@ -767,7 +808,9 @@ class Conv2dInputGradFn(TrackedFunction):
         native.count_flops(0, 2.0 * N * Ho * Wo * Co * (w.shape[1] * w.shape[2] * w.shape[3]))
         if gy_amax is None or gyp is not gy:
             gy_amax = operand_absmax(gyp)
-        call("lhg_conv2d_backward_input", pg, N, H, W, Cg, ldg, ptr(wp), wp.shape[1], KH, KW, stride, pgx, Ci, ldgx, ptr(gy_amax), stream_ptr())
+        pres, ldres = (nhwc(res)[0], nhwc(res)[5]) if res is not None else (None, 0)
+        call("lhg_conv2d_backward_input_add", pg, N, H, W, Cg, ldg, ptr(wp), wp.shape[1], KH, KW, stride, pgx, Ci, ldgx, pres, ldres,
+             ptr(gy_amax), stream_ptr())
         return gx
 
     @staticmethod
@@ -778,7 +821,7 @@ class Conv2dInputGradFn(TrackedFunction):
             g_gy = Conv2dFn.apply(ggx, w, None, ctx.stride, None)
         if ctx.needs_input_grad[1] and param_grads_wanted():
             g_w = _weight_grad(w, (ggx, gy), lambda slot: conv2d_weight_grad(ggx, gy, w.shape, ctx.stride, slot))
-        return g_gy, g_w, None, None, None, None, None
+        return g_gy, g_w, None, None, None, None, None, (ggx if ctx.needs_input_grad[7] else None)
 
 
 def conv2d_weight_grad_raw(x, gy, wshape, stride, slot=None, x_amax=None, gy_amax=None):

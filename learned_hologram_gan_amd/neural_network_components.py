@@ -63,10 +63,11 @@ class ResidualBlock(nn.Module):
         b1, b2 = self.batch_norm_layer_1, self.batch_norm_layer_2
         if self.training:
             # (the RGBD first layer, 4 -> 64, is routed to the direct thin-convolution kernels inside the op)
-            y = ops.Conv2dFn.apply(x, c1.weight, c1.bias, self.strides, "feeds_bn")
+            # X has two consumers; the gradient of the skip path is added inside the first conv's input-gradient GEMM
+            y, xs = ops.conv2d_shared_input(x, c1.weight, c1.bias, self.strides, "feeds_bn")
             y = ops.BatchNormTrainFn.apply(y, b1.weight, b1.bias, b1.running_mean, b1.running_var, None, ACT_RELU, 0.0, None)
             y = ops.Conv2dFn.apply(y, c2.weight, c2.bias, 1, "feeds_bn")
-            skip = ops.Conv2dFn.apply(x, c3.weight, c3.bias, self.strides, None) if c3 is not None else x
+            skip = ops.Conv2dFn.apply(xs, c3.weight, c3.bias, self.strides, None) if c3 is not None else xs
             _count_batch(b1, b2)
             return ops.BatchNormTrainFn.apply(y, b2.weight, b2.bias, b2.running_mean, b2.running_var, skip, ACT_RELU, 0.0, out)
         if torch.is_grad_enabled() and (x.requires_grad or c1.weight.requires_grad):

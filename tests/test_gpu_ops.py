@@ -776,3 +776,31 @@ def test_optimizer_step_leaves_every_packed_form_current(ops):
     assert before == {id(v[1]) for conv in net for v in conv.weight.__dict__["_lhg_packed"].values()}  # no re-pack on use
     ref = F.conv2d(F.conv2d(x.detach().permute(0, 3, 1, 2), net[0].weight, net[0].bias, padding=1), net[1].weight, net[1].bias, padding=1)
     assert rel_err(y1.detach().permute(0, 3, 1, 2).cpu(), ref.cpu()) < TOL
+
+
+@pytest.mark.parametrize("stride,with_1x1", [(1, True), (2, True), (1, False)])
+def test_shared_input_conv_adds_the_skip_gradient_in_the_epilogue(ops, stride, with_1x1):
+    """Conv2dSharedInputFn: d/dx of conv3x3(x) and of the skip path (conv1x1(x) or x itself) summed inside the input-gradient GEMM —
+    the same gradient as the two-consumer graph gives with autograd's own accumulation (ResidualBlock, ref neural_network_components.py:22-31)."""
+    torch.manual_seed(17)
+    N, C, H, W, Co = 2, 64, 20, 24, 64 if not with_1x1 else 96
+    x0 = torch.randn(N, C, H, W)
+    w1, b1 = torch.randn(Co, C, 3, 3) * 0.05, torch.randn(Co) * 0.1
+    w3, b3 = torch.randn(Co, C, 1, 1) * 0.1, torch.randn(Co) * 0.1
+    gy = torch.randn(N, Co, (H + stride - 1) // stride, (W + stride - 1) // stride)
+    gs = torch.randn_like(gy) if with_1x1 else torch.randn(N, C, H, W)
+
+    xr = x0.clone().requires_grad_(True)
+    yr = F.conv2d(xr, w1, b1, stride=stride, padding=1)
+    sr = F.conv2d(xr, w3, b3, stride=stride) if with_1x1 else xr
+    ((yr * gy).sum() + (sr * gs).sum()).backward()
+
+    x = to_nhwc(x0).requires_grad_(True)
+    W1, B1, W3, B3 = (t.to(DEV).requires_grad_(True) for t in (w1, b1, w3, b3))
+    y, xs = ops.conv2d_shared_input(x, W1, B1, stride, None)
+    assert xs is not x and xs.data_ptr() == x.data_ptr()
+    s = ops.Conv2dFn.apply(xs, W3, B3, stride, None) if with_1x1 else xs
+    ((y * to_nhwc(gy)).sum() + (s * to_nhwc(gs)).sum()).backward()
+    assert rel_err(to_nchw(y), yr.detach()) < TOL
+    assert rel_err(to_nchw(x.grad), xr.grad) < TOL
+    assert rel_err(W1.grad.cpu(), torch.autograd.grad(F.conv2d(x0, w1.requires_grad_(True), b1, stride=stride, padding=1), w1, gy)[0]) < TOL
