@@ -821,7 +821,9 @@ class Conv2dInputGradFn(TrackedFunction):
             g_gy = Conv2dFn.apply(ggx, w, None, ctx.stride, None)
         if ctx.needs_input_grad[1] and param_grads_wanted():
             g_w = _weight_grad(w, (ggx, gy), lambda slot: conv2d_weight_grad(ggx, gy, w.shape, ctx.stride, slot))
-        return g_gy, g_w, None, None, None, None, None, (ggx if ctx.needs_input_grad[7] else None)
+        n = len(ctx.needs_input_grad)  # 6 to 8 arguments were passed
+        grads = (g_gy, g_w, None, None, None, None, None, ggx if n > 7 and ctx.needs_input_grad[7] else None)
+        return grads[:n]
 
 
 def conv2d_weight_grad_raw(x, gy, wshape, stride, slot=None, x_amax=None, gy_amax=None):
