@@ -786,13 +786,14 @@ def test_shared_input_conv_adds_the_skip_gradient_in_the_epilogue(ops, stride, w
     N, C, H, W, Co = 2, 64, 20, 24, 64 if not with_1x1 else 96
     x0 = torch.randn(N, C, H, W)
     w1, b1 = torch.randn(Co, C, 3, 3) * 0.05, torch.randn(Co) * 0.1
-    w3, b3 = torch.randn(Co, C, 1, 1) * 0.1, torch.randn(Co) * 0.1
+    k3 = 1 if stride == 1 else 3  # (a strided 1x1 input-gradient leaves pixels without taps: not part of the model, not supported)
+    w3, b3 = torch.randn(Co, C, k3, k3) * 0.1, torch.randn(Co) * 0.1
     gy = torch.randn(N, Co, (H + stride - 1) // stride, (W + stride - 1) // stride)
     gs = torch.randn_like(gy) if with_1x1 else torch.randn(N, C, H, W)
 
     xr = x0.clone().requires_grad_(True)
     yr = F.conv2d(xr, w1, b1, stride=stride, padding=1)
-    sr = F.conv2d(xr, w3, b3, stride=stride) if with_1x1 else xr
+    sr = F.conv2d(xr, w3, b3, stride=stride, padding=k3 // 2) if with_1x1 else xr
     ((yr * gy).sum() + (sr * gs).sum()).backward()
 
     x = to_nhwc(x0).requires_grad_(True)
