@@ -598,7 +598,7 @@ static std::map<std::array<int, 12>, int> g_gg_choice, g_wg_choice;
 // LHG_TUNE_CACHE=<file>: choices are appended to that file and read back by later processes (one line per geometry, tagged with
 // TUNE_SCHEMA so that a build with a different variant numbering ignores stale lines).
 constexpr int TUNE_RUNS = 5;
-constexpr const char* TUNE_SCHEMA = "lhg-tune-4";
+constexpr const char* TUNE_SCHEMA = "lhg-tune-5";
 static void tune_cache_load() {
   static bool done = false;
   if (done) return;
@@ -862,7 +862,8 @@ static int launch_gg_split(GGParams& p, hipStream_t st) {
   const unsigned wb = (unsigned)wp_bytes;
   auto blocks = [&](int bm, int bn) { return (unsigned)(((g.M + bm - 1) / bm) * (p.rows_pad / bn)); };
   const bool n128 = p.rows_pad % 128 == 0;
-  constexpr int NV = 9;  // 3, 4: eight consumer waves (two per SIMD) on the 128x128 / 128x64 tiles; 5..8: strip-staged 3x3 kernel (gg4s)
+  constexpr int NV = 10;  // 3, 4: eight consumer waves (two per SIMD) on the 128x128 / 128x64 tiles; 5..8: strip-staged 3x3 kernel (gg4s);
+                          // 9: 64 pixels x 128 output channels (half the activation splits of the 64x64 tile, same pixel granularity)
   // gg4s_kernel: fp16 planes, full 3x3 tap set, stride 1 both ways, same extents in and out
   bool strips = split_f16() && g.T == 9 && g.istep == 1 && g.ostep == 1 && g.oy0 == 0 && g.ox0 == 0 && g.gh == g.Hi && g.gw == g.Wi && g.Ho == g.Hi &&
                 g.Wo == g.Wi && (long long)g.N * g.Hi * (g.Wi + 2) < (1ll << 31);
@@ -878,6 +879,7 @@ static int launch_gg_split(GGParams& p, hipStream_t st) {
   const bool f16 = split_f16();
   if (f16) LHG_REQUIRE(p.a_amax != nullptr && p.w_amax != nullptr, "gather-GEMM (fp32_split_f16 mode): the operand's absmax pointer is missing (lhg_absmax)");
   auto valid = [&](int v) {
+    if (v == 9) return f16 && n128;
     if (v >= 5) return strips && (v == 5 || v == 7 || n128);
     return (v == 0 || v == 3) ? n128 : (NP == 3 || f16 || v < 3);
   };
@@ -902,6 +904,7 @@ static int launch_gg_split(GGParams& p, hipStream_t st) {
         case 6: hipLaunchKernelGGL((gg4s_kernel<64, 128>), dim3(blocks_strip(64, 128)), dim3(512), 0, st, p, ib, wb); break;
         case 7: hipLaunchKernelGGL((gg4s_kernel<128, 64>), dim3(blocks_strip(128, 64)), dim3(512), 0, st, p, ib, wb); break;
         case 8: hipLaunchKernelGGL((gg4s_kernel<128, 128>), dim3(blocks_strip(128, 128)), dim3(512), 0, st, p, ib, wb); break;
+        case 9: hipLaunchKernelGGL((gg3s_kernel<64, 128, 2, 2, 32, float, 4, _Float16>), dim3(blocks(64, 128)), dim3(512), 0, st, p, ib, wb); break;
         default: break;
       }
     } else {
