@@ -63,6 +63,11 @@ struct GGParams {
   float* out_amax;      // fp16-split mode, optional: max-accumulates max|out| (NHWC outputs)
   int tap_of[9];        // gg4s_kernel: tap index of the 3x3 offset (dy + 1) * 3 + (dx + 1)
   int prio; // gg3s_kernel: 0 no s_setprio, 1 consumers (MFMA waves) raised, 2 producers (load / split waves) raised
+  // gg3s_kernel, merged launch of the output-parity classes of a stride-2 input gradient / a 2x2 transposed conv (same tensors,
+  // different sub-grids and tap sets): class c > 0 has geometry gc[c - 1] and owns workgroups cblk[c] .. cblk[c + 1] - 1 (cblk[0] = 0).
+  int ncls;             // 0 / 1: `g` only
+  unsigned cblk[5];
+  Geom gc[3];
 };
 
 struct WGParams {
@@ -723,6 +728,32 @@ static int launch_gg_split(GGParams& p, hipStream_t st);
 static inline bool split_f16() { return g_precision == LHG_PRECISION_F32_SPLIT_F16; }
 static inline bool split_mode() { return g_precision == LHG_PRECISION_F32_SPLIT || g_precision == LHG_PRECISION_F32_SPLIT2 || split_f16(); }
 static inline int split_planes() { return g_precision == LHG_PRECISION_F32_SPLIT ? 3 : 2; }
+static int launch_gg(GGParams& p, hipStream_t st);
+static bool merge_classes() {
+  static const bool on = [] { const char* e = getenv("LHG_MERGE_CLASSES"); return !e || atoi(e) != 0; }();
+  return on;
+}
+// The output-parity classes of one operator (same tensors and weights; sub-grid, tap set and pixel count differ): one merged launch
+// in the fp16-split mode — the short K loops of the one- and two-tap classes leave the chip two thirds empty between the launches'
+// last and first workgroups otherwise — one launch per class in the other modes.  Heaviest classes first.
+static int launch_gg_classes(GGParams& p, Geom* cls, int n, hipStream_t st) {
+  if (n <= 0) return LHG_OK;
+  std::stable_sort(cls, cls + n, [](const Geom& a, const Geom& b) { return (long long)a.M * a.T > (long long)b.M * b.T; });
+  if (n > 1 && n <= 4 && merge_classes() && g_precision == LHG_PRECISION_F32_SPLIT_F16 && !act_is_bf16()) {
+    p.g = cls[0];
+    for (int c = 1; c < n; ++c) p.gc[c - 1] = cls[c];
+    p.ncls = n;
+    return launch_gg(p, st);
+  }
+  for (int c = 0; c < n; ++c) {
+    p.g = cls[c];
+    p.ncls = 0;
+    const int rc = launch_gg(p, st);
+    if (rc) return rc;
+  }
+  return LHG_OK;
+}
+
 // fp16-split mode: max|w| sits in the 16 bytes behind the panels of a packed weight (lhg_pack_weight put it there)
 static inline const float* weight_amax(const float* wp, int taps, int rows_pad, int k_pad) {
   return split_f16() ? wp + (size_t)taps * rows_pad * k_pad : nullptr;
@@ -855,17 +886,33 @@ static int launch_gg_split(GGParams& p, hipStream_t st) {
   LHG_REQUIRE(p.rows_pad % 64 == 0 && p.rows_pad >= g.Co, "gather-GEMM: rows_pad %d must be a multiple of 64 covering Co=%d", p.rows_pad, g.Co);
   LHG_REQUIRE((long long)g.N * g.Ho * g.Wo < (1ll << 31) && (long long)g.N * g.Hi * g.Wi < (1ll << 31), "gather-GEMM: more than 2^31 pixels");
   int max_ws = 0;
-  for (int t = 0; t < g.T; ++t) max_ws = std::max(max_ws, g.ws[t]);
+  const int ncls = std::max(1, p.ncls);
+  auto cls_geom = [&](int c) -> const Geom& { return c == 0 ? p.g : p.gc[c - 1]; };
+  for (int c = 0; c < ncls; ++c)
+    for (int t = 0; t < cls_geom(c).T; ++t) max_ws = std::max(max_ws, cls_geom(c).ws[t]);
   const unsigned long long ib = (((unsigned long long)g.N * g.Hi * g.Wi - 1) * g.ldi + g.Ci) * 4ull;
   const unsigned long long wp_bytes = (unsigned long long)(max_ws + 1) * p.rows_pad * g.Ci * 2ull * NP;
   LHG_REQUIRE(wp_bytes < (1ull << 32) - 64, "gather-GEMM (split mode): weight panels of 4 GiB and more are not supported");
   const unsigned wb = (unsigned)wp_bytes;
-  auto blocks = [&](int bm, int bn) { return (unsigned)(((g.M + bm - 1) / bm) * (p.rows_pad / bn)); };
+  // workgroups of a bm x bn tiling; for a merged launch also the classes' first workgroups (written into p before it is copied)
+  auto blocks = [&](int bm, int bn) {
+    unsigned total = 0;
+    for (int c = 0; c < ncls; ++c) {
+      p.cblk[c] = total;
+      total += (unsigned)(((cls_geom(c).M + bm - 1) / bm) * (p.rows_pad / bn));
+    }
+    p.cblk[ncls] = total;
+    return total;
+  };
+  auto launch3 = [&](auto kern, int bm, int bn, int threads) {
+    const unsigned nb = blocks(bm, bn);
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(threads), 0, st, p, ib, wb);
+  };
   const bool n128 = p.rows_pad % 128 == 0;
   constexpr int NV = 10;  // 3, 4: eight consumer waves (two per SIMD) on the 128x128 / 128x64 tiles; 5..8: strip-staged 3x3 kernel (gg4s);
                           // 9: 64 pixels x 128 output channels (half the activation splits of the 64x64 tile, same pixel granularity)
   // gg4s_kernel: fp16 planes, full 3x3 tap set, stride 1 both ways, same extents in and out
-  bool strips = split_f16() && g.T == 9 && g.istep == 1 && g.ostep == 1 && g.oy0 == 0 && g.ox0 == 0 && g.gh == g.Hi && g.gw == g.Wi && g.Ho == g.Hi &&
+  bool strips = split_f16() && ncls == 1 && g.T == 9 && g.istep == 1 && g.ostep == 1 && g.oy0 == 0 && g.ox0 == 0 && g.gh == g.Hi && g.gw == g.Wi && g.Ho == g.Hi &&
                 g.Wo == g.Wi && (long long)g.N * g.Hi * (g.Wi + 2) < (1ll << 31);
   if (strips) {
     int seen = 0;
@@ -886,44 +933,53 @@ static int launch_gg_split(GGParams& p, hipStream_t st) {
   auto run = [&](int v) {
     if (NP == 3) {
       switch (v) {
-        case 3: hipLaunchKernelGGL((gg3s_kernel<128, 128, 3, 1, 32, float, 8>), dim3(blocks(128, 128)), dim3(768), 0, st, p, ib, wb); break;
-        case 4: hipLaunchKernelGGL((gg3s_kernel<128, 64, 3, 1, 32, float, 8>), dim3(blocks(128, 64)), dim3(768), 0, st, p, ib, wb); break;
-        case 0: hipLaunchKernelGGL((gg3s_kernel<128, 128, 3, 2>), dim3(blocks(128, 128)), dim3(512), 0, st, p, ib, wb); break;
-        case 1: hipLaunchKernelGGL((gg3s_kernel<128, 64, 3, 2>), dim3(blocks(128, 64)), dim3(512), 0, st, p, ib, wb); break;
-        case 2: hipLaunchKernelGGL((gg3s_kernel<64, 64, 3, 2>), dim3(blocks(64, 64)), dim3(512), 0, st, p, ib, wb); break;
+        case 3: launch3(gg3s_kernel<128, 128, 3, 1, 32, float, 8>, 128, 128, 768); break;
+        case 4: launch3(gg3s_kernel<128, 64, 3, 1, 32, float, 8>, 128, 64, 768); break;
+        case 0: launch3(gg3s_kernel<128, 128, 3, 2>, 128, 128, 512); break;
+        case 1: launch3(gg3s_kernel<128, 64, 3, 2>, 128, 64, 512); break;
+        case 2: launch3(gg3s_kernel<64, 64, 3, 2>, 64, 64, 512); break;
         default: break;
       }
     } else if (f16) {
       switch (v) {
-        case 3: hipLaunchKernelGGL((gg3s_kernel<128, 128, 2, 1, 32, float, 8, _Float16>), dim3(blocks(128, 128)), dim3(768), 0, st, p, ib, wb); break;
-        case 4: hipLaunchKernelGGL((gg3s_kernel<128, 64, 2, 1, 32, float, 8, _Float16>), dim3(blocks(128, 64)), dim3(768), 0, st, p, ib, wb); break;
-        case 0: hipLaunchKernelGGL((gg3s_kernel<128, 128, 2, 2, 32, float, 4, _Float16>), dim3(blocks(128, 128)), dim3(512), 0, st, p, ib, wb); break;
-        case 1: hipLaunchKernelGGL((gg3s_kernel<128, 64, 2, 2, 32, float, 4, _Float16>), dim3(blocks(128, 64)), dim3(512), 0, st, p, ib, wb); break;
-        case 2: hipLaunchKernelGGL((gg3s_kernel<64, 64, 2, 2, 32, float, 4, _Float16>), dim3(blocks(64, 64)), dim3(512), 0, st, p, ib, wb); break;
+        case 3: launch3(gg3s_kernel<128, 128, 2, 1, 32, float, 8, _Float16>, 128, 128, 768); break;
+        case 4: launch3(gg3s_kernel<128, 64, 2, 1, 32, float, 8, _Float16>, 128, 64, 768); break;
+        case 0: launch3(gg3s_kernel<128, 128, 2, 2, 32, float, 4, _Float16>, 128, 128, 512); break;
+        case 1: launch3(gg3s_kernel<128, 64, 2, 2, 32, float, 4, _Float16>, 128, 64, 512); break;
+        case 2: launch3(gg3s_kernel<64, 64, 2, 2, 32, float, 4, _Float16>, 64, 64, 512); break;
         case 5: hipLaunchKernelGGL((gg4s_kernel<64, 64>), dim3(blocks_strip(64, 64)), dim3(512), 0, st, p, ib, wb); break;
         case 6: hipLaunchKernelGGL((gg4s_kernel<64, 128>), dim3(blocks_strip(64, 128)), dim3(512), 0, st, p, ib, wb); break;
         case 7: hipLaunchKernelGGL((gg4s_kernel<128, 64>), dim3(blocks_strip(128, 64)), dim3(512), 0, st, p, ib, wb); break;
         case 8: hipLaunchKernelGGL((gg4s_kernel<128, 128>), dim3(blocks_strip(128, 128)), dim3(512), 0, st, p, ib, wb); break;
-        case 9: hipLaunchKernelGGL((gg3s_kernel<64, 128, 2, 2, 32, float, 4, _Float16>), dim3(blocks(64, 128)), dim3(512), 0, st, p, ib, wb); break;
+        case 9: launch3(gg3s_kernel<64, 128, 2, 2, 32, float, 4, _Float16>, 64, 128, 512); break;
         default: break;
       }
     } else {
       switch (v) {
-        case 0: hipLaunchKernelGGL((gg3s_kernel<128, 128, 2, 2>), dim3(blocks(128, 128)), dim3(512), 0, st, p, ib, wb); break;
-        case 1: hipLaunchKernelGGL((gg3s_kernel<128, 64, 2, 2>), dim3(blocks(128, 64)), dim3(512), 0, st, p, ib, wb); break;
-        default: hipLaunchKernelGGL((gg3s_kernel<64, 64, 2, 2>), dim3(blocks(64, 64)), dim3(512), 0, st, p, ib, wb); break;
+        case 0: launch3(gg3s_kernel<128, 128, 2, 2>, 128, 128, 512); break;
+        case 1: launch3(gg3s_kernel<128, 64, 2, 2>, 128, 64, 512); break;
+        default: launch3(gg3s_kernel<64, 64, 2, 2>, 64, 64, 512); break;
       }
     }
   };
   static const int forced = [] { const char* e = getenv("LHG_GGS_VARIANT"); return e ? atoi(e) : -1; }();
   int choice = (forced >= 0 && forced < NV && valid(forced)) ? forced : -1;
   if (choice < 0 && g_autotune_enabled) {
-    const std::array<int, 12> key = {g.M, p.rows_pad, g.Ci, g.Co, g.T, g.istep, g.ostep, g.Hi, g.Wi, g.ldi, g.ldo, p.planar_out + 4 * g_precision};
+    const std::array<int, 12> key = {g.M, p.rows_pad, g.Ci, g.Co, g.T, g.istep, g.ostep, g.Hi, g.Wi, g.ldi, g.ldo,
+                                     p.planar_out + 4 * g_precision + 64 * ncls};
     choice = autotuned_variant(g_gg_choice, key, NV, valid, run, st);
   }
   if (choice < 0) choice = n128 && blocks(128, 128) >= 200 ? 0 : (blocks(128, 64) >= 256 ? 1 : 2);
-  ScopedKernelTime timed(0, st, 2.0 * g.M * (double)p.rows_pad * g.Ci * g.T);
-  timed.tag(g, p.rows_pad, g.Ci, choice, 2.0 * g.M * (double)p.rows_pad * g.Ci * g.T);
+  double mt_sum = 0;  // sum over the classes of pixels x taps
+  for (int c = 0; c < ncls; ++c) mt_sum += (double)cls_geom(c).M * cls_geom(c).T;
+  ScopedKernelTime timed(0, st, 2.0 * mt_sum * (double)p.rows_pad * g.Ci);
+  if (ncls == 1) timed.tag(g, p.rows_pad, g.Ci, choice, 2.0 * mt_sum * (double)p.rows_pad * g.Ci);
+  else {
+    Geom all = g;  // logged as one launch: total pixels, total taps
+    all.M = 0; all.T = 0;
+    for (int c = 0; c < ncls; ++c) { all.M += cls_geom(c).M; all.T += cls_geom(c).T; }
+    timed.tag(all, p.rows_pad, g.Ci, choice, 2.0 * mt_sum * (double)p.rows_pad * g.Ci);
+  }
   run(choice);
   return check_launch("gg3s_kernel");
 }
@@ -1253,6 +1309,8 @@ int lhg_conv2d_backward_input_add(const float* gy, int N, int H, int W, int Co, 
   }
   // stride 2: one launch per output parity class; input row y receives kernel rows kh with
   // (y + ph - kh) even, from gy row (y + ph - kh)/2.
+  Geom cls[4];
+  int n = 0;
   for (int py = 0; py < 2; ++py)
     for (int px = 0; px < 2; ++px) {
       g.gh = (H - py + 1) / 2; g.gw = (W - px + 1) / 2;
@@ -1270,10 +1328,9 @@ int lhg_conv2d_backward_input_add(const float* gy, int N, int H, int W, int Co, 
       g.T = T;
       g.M = N * g.gh * g.gw;
       if (T == 0) return fail(LHG_E_ARG, "conv2d_backward_input: empty tap set");
-      int rc = launch_gg(p, as_stream(s));
-      if (rc) return rc;
+      cls[n++] = g;
     }
-  return LHG_OK;
+  return launch_gg_classes(p, cls, n, as_stream(s));
 }
 
 // 3x3 stride-1: S = strips (image x 32-pixel column segments) x chunks per strip, so that the fused nine-tap kernel
@@ -1330,16 +1387,13 @@ static void convt_geom(Geom& g, int N, int H, int W, int Ci, int ldx, int Co, in
 
 int lhg_conv_transpose2x2_forward(const float* x, int N, int H, int W, int Ci, int ldx, const float* wp, int rows_pad,
                                   float* y, int Co, int ldy, const float* bias, const float* x_absmax, float* y_absmax, lhg_stream_t s) {
+  GGParams p{};
+  p.a_amax = x_absmax; p.w_amax = weight_amax(wp, 4, rows_pad, Ci); p.out_amax = y_absmax;
+  p.in = x; p.wp = wp; p.out = y; p.bias = bias; p.rows_pad = rows_pad; p.act = LHG_ACT_NONE;
+  Geom cls[4];
   for (int py = 0; py < 2; ++py)
-    for (int px = 0; px < 2; ++px) {
-      GGParams p{};
-      convt_geom(p.g, N, H, W, Ci, ldx, Co, ldy, py, px);
-      p.a_amax = x_absmax; p.w_amax = weight_amax(wp, 4, rows_pad, Ci); p.out_amax = y_absmax;
-      p.in = x; p.wp = wp; p.out = y; p.bias = bias; p.rows_pad = rows_pad; p.act = LHG_ACT_NONE;
-      int rc = launch_gg(p, as_stream(s));
-      if (rc) return rc;
-    }
-  return LHG_OK;
+    for (int px = 0; px < 2; ++px) convt_geom(cls[py * 2 + px], N, H, W, Ci, ldx, Co, ldy, py, px);
+  return launch_gg_classes(p, cls, 4, as_stream(s));
 }
 
 int lhg_conv_transpose2x2_backward_input(const float* gy, int N, int H, int W, int Co, int ldgy, const float* wp, int rows_pad,
