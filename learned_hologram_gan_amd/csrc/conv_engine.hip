@@ -895,21 +895,25 @@ static int launch_gg_split(GGParams& p, hipStream_t st) {
   LHG_REQUIRE(wp_bytes < (1ull << 32) - 64, "gather-GEMM (split mode): weight panels of 4 GiB and more are not supported");
   const unsigned wb = (unsigned)wp_bytes;
   // workgroups of a bm x bn tiling; for a merged launch also the classes' first workgroups (written into p before it is copied)
+  GGParams* q = &p;  // the parameter block being launched: p, or (variants 10..19) a copy of it holding one class
   auto blocks = [&](int bm, int bn) {
+    const int nq = std::max(1, q->ncls);
     unsigned total = 0;
-    for (int c = 0; c < ncls; ++c) {
-      p.cblk[c] = total;
-      total += (unsigned)(((cls_geom(c).M + bm - 1) / bm) * (p.rows_pad / bn));
+    for (int c = 0; c < nq; ++c) {
+      q->cblk[c] = total;
+      total += (unsigned)((((c == 0 ? q->g : q->gc[c - 1]).M + bm - 1) / bm) * (q->rows_pad / bn));
     }
-    p.cblk[ncls] = total;
+    q->cblk[nq] = total;
     return total;
   };
   auto launch3 = [&](auto kern, int bm, int bn, int threads) {
     const unsigned nb = blocks(bm, bn);
-    hipLaunchKernelGGL(kern, dim3(nb), dim3(threads), 0, st, p, ib, wb);
+    hipLaunchKernelGGL(kern, dim3(nb), dim3(threads), 0, st, *q, ib, wb);
   };
   const bool n128 = p.rows_pad % 128 == 0;
-  constexpr int NV = 10;  // 3, 4: eight consumer waves (two per SIMD) on the 128x128 / 128x64 tiles; 5..8: strip-staged 3x3 kernel (gg4s);
+  // 10..19 (merged parity classes only): variant v - 10 in one launch per class — what wins on the layers whose classes are long
+  // enough by themselves (512 -> 1024 @ 48^2: 493 us against 572 merged; 128 -> 256 @ 96^2: 267 against 206)
+  const int NV = ncls > 1 ? 20 : 10;  // 3, 4: eight consumer waves (two per SIMD) on the 128x128 / 128x64 tiles; 5..8: strip-staged 3x3 kernel (gg4s);
                           // 9: 64 pixels x 128 output channels (half the activation splits of the 64x64 tile, same pixel granularity)
   // gg4s_kernel: fp16 planes, full 3x3 tap set, stride 1 both ways, same extents in and out
   bool strips = split_f16() && ncls == 1 && g.T == 9 && g.istep == 1 && g.ostep == 1 && g.oy0 == 0 && g.ox0 == 0 && g.gh == g.Hi && g.gw == g.Wi && g.Ho == g.Hi &&
@@ -926,11 +930,12 @@ static int launch_gg_split(GGParams& p, hipStream_t st) {
   const bool f16 = split_f16();
   if (f16) LHG_REQUIRE(p.a_amax != nullptr && p.w_amax != nullptr, "gather-GEMM (fp32_split_f16 mode): the operand's absmax pointer is missing (lhg_absmax)");
   auto valid = [&](int v) {
+    if (v >= 10) v -= 10;
     if (v == 9) return f16 && n128;
     if (v >= 5) return strips && (v == 5 || v == 7 || n128);
     return (v == 0 || v == 3) ? n128 : (NP == 3 || f16 || v < 3);
   };
-  auto run = [&](int v) {
+  auto run_one = [&](int v) {
     if (NP == 3) {
       switch (v) {
         case 3: launch3(gg3s_kernel<128, 128, 3, 1, 32, float, 8>, 128, 128, 768); break;
@@ -961,6 +966,17 @@ static int launch_gg_split(GGParams& p, hipStream_t st) {
         default: launch3(gg3s_kernel<64, 64, 2, 2>, 64, 64, 512); break;
       }
     }
+  };
+  auto run = [&](int v) {
+    if (v < 10) { run_one(v); return; }
+    for (int c = 0; c < ncls; ++c) {
+      GGParams one = p;
+      one.g = cls_geom(c);
+      one.ncls = 0;
+      q = &one;
+      run_one(v - 10);
+    }
+    q = &p;
   };
   static const int forced = [] { const char* e = getenv("LHG_GGS_VARIANT"); return e ? atoi(e) : -1; }();
   int choice = (forced >= 0 && forced < NV && valid(forced)) ? forced : -1;
