@@ -62,13 +62,14 @@ def overlap():
     sync = W._sync_G
     assert sync.enabled and len(sync.ranges) >= 3
     x = (rgbd.to(dev), tamp.to(dev), tphs.to(dev), idx)
-    fwd = []  # (G loss, checksum of the hologram) of every pass: tells a forward difference from a backward one
+    fwd = []  # (G loss, checksums of the hologram, the reconstruction and the propagated target) of every pass: tells a forward difference from a backward one
 
     notes = []
 
     def one_pass():
         out = W.train_step(*x)
-        fwd.append((float(out["G_loss"]), float(out["POH"].double().sum()), float(out["hat_amps"].double().sum())))
+        fwd.append((float(out["G_loss"]), float(out["POH"].double().sum()), float(out["hat_amps"].double().sum()),
+                    float(out["target_amps"].double().sum())))
         with torch.no_grad():  # the reconstruction of the step against fresh evaluations from the same hologram
             for k in range(3):
                 again = W.propagator.reconstruct_planes(W.generator.part2.propagator, out["POH"], x[1], x[2], idx)[0]
