@@ -43,7 +43,7 @@ if REPO not in sys.path:
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md, chip-level parameters)
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (same table)
-KERNEL_SOURCES = ("conv_engine.hip", "gg2_kernel.inc", "gg2b_kernel.inc", "gg3s_kernel.inc", "gg4s_kernel.inc", "wg2_kernel.inc", "wg2b_kernel.inc", "wg2s_kernel.inc", "wg3b_kernel.inc", "wg4s_kernel.inc",
+KERNEL_SOURCES = ("conv_engine.hip", "gg2_kernel.inc", "gg2b_kernel.inc", "gg3s_kernel.inc", "gg4s_kernel.inc", "wg2_kernel.inc", "wg2b_kernel.inc", "wg2s_kernel.inc", "wg3b_kernel.inc", "wg4s_kernel.inc", "wg5p_kernel.inc",
                   "wg3_kernel.inc")
 
 

@@ -344,6 +344,7 @@ __global__ __launch_bounds__(256, 2) void wg_kernel(const WGParams p) {
 #include "wg2s_kernel.inc"
 #include "wg3b_kernel.inc"
 #include "wg4s_kernel.inc"
+#include "wg5p_kernel.inc"
 #include "wg3_kernel.inc"
 
 // ------------------------------------------------------------------------------------ small kernels
@@ -603,7 +604,7 @@ static std::map<std::array<int, 12>, int> g_gg_choice, g_wg_choice;
 // LHG_TUNE_CACHE=<file>: choices are appended to that file and read back by later processes (one line per geometry, tagged with
 // TUNE_SCHEMA so that a build with a different variant numbering ignores stale lines).
 constexpr int TUNE_RUNS = 5;
-constexpr const char* TUNE_SCHEMA = "lhg-tune-5";
+constexpr const char* TUNE_SCHEMA = "lhg-tune-6";
 static void tune_cache_load() {
   static bool done = false;
   if (done) return;
@@ -1019,7 +1020,8 @@ static int launch_wg(WGParams& p, int S, hipStream_t st, const WG3Params* p3 = n
   const bool m128 = p.m_pad % 128 == 0, n128 = p.n_pad % 128 == 0;
   // 5: nine-tap fused kernel for 3x3 stride 1; 6..9: bf16-operand kernels; 10..13: split (fp32-faithful) kernels;
   // 14..17: bf16 STORAGE kernels with transposed LDS reads (wg3b_kernel); 18..21: fp16-split kernels with transposed LDS reads (wg4s_kernel)
-  constexpr int NV = 22;
+  // 22..25: the same with producer / consumer waves (wg5p_kernel)
+  constexpr int NV = 26;
   const bool bf16 = g_precision == LHG_PRECISION_BF16;
   const bool split = split_mode();
   const bool f16 = split_f16();
@@ -1027,6 +1029,7 @@ static int launch_wg(WGParams& p, int S, hipStream_t st, const WG3Params* p3 = n
   if (f16) LHG_REQUIRE(p.in_amax != nullptr && p.gout_amax != nullptr, "wgrad (fp32_split_f16 mode): the operands' absmax pointers are missing (lhg_absmax)");
   if (bf16 || split) LHG_REQUIRE(small, "wgrad (bf16 / split mode): tensors of 4 GiB and more are not supported");
   auto valid = [&](int v) {
+    if (v >= 22) return f16 && (v == 22 ? m128 && n128 : v == 23 ? m128 : v == 24 ? n128 : true);
     if (v >= 18) return f16 && (v == 18 ? m128 && n128 : v == 19 ? m128 : v == 20 ? n128 : true);
     if (v >= 14) return bf16 && act16 && (v == 14 ? m128 && n128 : v == 15 ? m128 : v == 16 ? n128 : true);
     if (split) return v >= 10 && (v == 10 ? m128 && n128 : v == 11 ? m128 : v == 12 ? n128 : true);
@@ -1069,6 +1072,10 @@ static int launch_wg(WGParams& p, int S, hipStream_t st, const WG3Params* p3 = n
       case 19: hipLaunchKernelGGL((wg4s_kernel<128, 64>), grid(128, 64), dim3(256), 0, st, p, ib, gb); break;
       case 20: hipLaunchKernelGGL((wg4s_kernel<64, 128>), grid(64, 128), dim3(256), 0, st, p, ib, gb); break;
       case 21: hipLaunchKernelGGL((wg4s_kernel<64, 64>), grid(64, 64), dim3(256), 0, st, p, ib, gb); break;
+      case 22: hipLaunchKernelGGL((wg5p_kernel<128, 128>), grid(128, 128), dim3(512), 0, st, p, ib, gb); break;
+      case 23: hipLaunchKernelGGL((wg5p_kernel<128, 64>), grid(128, 64), dim3(512), 0, st, p, ib, gb); break;
+      case 24: hipLaunchKernelGGL((wg5p_kernel<64, 128>), grid(64, 128), dim3(512), 0, st, p, ib, gb); break;
+      case 25: hipLaunchKernelGGL((wg5p_kernel<64, 64>), grid(64, 64), dim3(512), 0, st, p, ib, gb); break;
       case 14: hipLaunchKernelGGL((wg3b_kernel<128, 128>), grid(128, 128), dim3(256), 0, st, p, ib, gb); break;
       case 15: hipLaunchKernelGGL((wg3b_kernel<128, 64>), grid(128, 64), dim3(256), 0, st, p, ib, gb); break;
       case 16: hipLaunchKernelGGL((wg3b_kernel<64, 128>), grid(64, 128), dim3(256), 0, st, p, ib, gb); break;
