@@ -697,10 +697,10 @@ def test_f16_split_tracks_exact_fp32_over_operand_scales(ops, scale):
         assert torch.isfinite(a).all() and rel_err(a.cpu().double(), b.cpu().double()) < 3e-6, scale
 
 
-@pytest.mark.parametrize("variant", [5, 8, 10], ids=lambda v: f"gg4s_variant{v}")
+@pytest.mark.parametrize("variant", [5, 8], ids=lambda v: f"gg4s_variant{v}")
 def test_strip_kernel_is_exercised_when_forced(variant):
     """The autotuner decides per geometry whether a 3x3 stride-1 launch runs on the strip kernel (gg4s) — on the small shapes of this
-    file it may never win.  Force it (64 x 64, 128 x 128 and 256 x 128 tiles; LHG_GGS_VARIANT is read once per process, hence the child process)
+    file it may never win.  Force it (64 x 64 and 128 x 128 tiles; LHG_GGS_VARIANT is read once per process, hence the child process)
     and run the convolution parity tests, ragged extents and the fp64 comparison included."""
     import os
     import subprocess
