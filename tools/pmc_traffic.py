@@ -13,7 +13,7 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 def kernel_source_sha16():
     h = hashlib.sha256()
-    for name in ("conv_engine.hip", "gg2_kernel.inc", "gg2b_kernel.inc", "gg3s_kernel.inc", "gg4s_kernel.inc", "wg2_kernel.inc", "wg2b_kernel.inc", "wg2s_kernel.inc", "wg3b_kernel.inc", "wg4s_kernel.inc",
+    for name in ("conv_engine.hip", "gg2_kernel.inc", "gg2b_kernel.inc", "gg3s_kernel.inc", "gg4s_kernel.inc", "wg2_kernel.inc", "wg2b_kernel.inc", "wg2s_kernel.inc", "wg3b_kernel.inc", "wg4s_kernel.inc", "wg5p_kernel.inc",
                  "wg3_kernel.inc"):  # = bench.KERNEL_SOURCES
         with open(os.path.join(REPO, "learned_hologram_gan_amd", "csrc", name), "rb") as f:
             h.update(f.read())
