@@ -314,3 +314,46 @@ def test_product_never_imports_the_oracle():
     for fn in [n for n in tree.body if isinstance(n, ast.FunctionDef)]:
         uses = any(isinstance(n, ast.ImportFrom) and (n.module or "").startswith("oracle") for n in ast.walk(fn))
         assert uses == (fn.name == "cpu_baseline"), fn.name
+
+
+def test_deferred_gc_keeps_the_collector_out_and_restores_it(monkeypatch):
+    """hip_ops.deferred_gc (around every train step): the cyclic collector is off inside, back on afterwards — also when the step
+    raises, when the caller had it off to begin with it stays off, and LHG_DEFER_GC=0 leaves it alone."""
+    import gc
+
+    from learned_hologram_gan_amd import hip_ops
+
+    assert gc.isenabled()
+    with hip_ops.deferred_gc():
+        assert not gc.isenabled()
+        with hip_ops.deferred_gc():  # nested (train -> train_step): the inner one finds it off and leaves it off
+            assert not gc.isenabled()
+        assert not gc.isenabled()
+    assert gc.isenabled()
+    with pytest.raises(RuntimeError):
+        with hip_ops.deferred_gc():
+            raise RuntimeError("step failed")
+    assert gc.isenabled()
+    gc.disable()
+    try:
+        with hip_ops.deferred_gc():
+            assert not gc.isenabled()
+        assert not gc.isenabled()  # the caller's choice survives
+    finally:
+        gc.enable()
+    monkeypatch.setattr(hip_ops, "_DEFER_GC", False)
+    with hip_ops.deferred_gc():
+        assert gc.isenabled()
+
+
+def test_pack_item_mirrors_the_header_struct():
+    """native.PackItem is lhg_pack_item of include/lhg_hip.h field for field (two pointers, seven ints: 48 bytes with padding)."""
+    from learned_hologram_gan_amd import native
+
+    names = [n for n, _ in native.PackItem._fields_]
+    assert names == ["w", "dst", "D0", "D1", "KH", "KW", "rows_from_d0", "rows_pad", "k_pad"]
+    assert ctypes.sizeof(native.PackItem) == 48
+    header = open(os.path.join(REPO, "include", "lhg_hip.h")).read()
+    body = header[header.index("typedef struct lhg_pack_item {"):header.index("} lhg_pack_item;")]
+    for n in names:
+        assert n in body
