@@ -62,6 +62,7 @@ struct GGParams {
   const float* w_amax;
   float* out_amax;      // fp16-split mode, optional: max-accumulates max|out| (NHWC outputs)
   int tap_of[9];        // gg4s_kernel: tap index of the 3x3 offset (dy + 1) * 3 + (dx + 1)
+  int strip_rev;        // gg4s_kernel: tap_of is the reversed map (input gradient): walk the offsets downwards = taps upwards
   int prio; // gg3s_kernel: 0 no s_setprio, 1 consumers (MFMA waves) raised, 2 producers (load / split waves) raised
   // gg3s_kernel, merged launch of the output-parity classes of a stride-2 input gradient / a 2x2 transposed conv (same tensors,
   // different sub-grids and tap sets): class c > 0 has geometry gc[c - 1] and owns workgroups cblk[c] .. cblk[c + 1] - 1 (cblk[0] = 0).
@@ -926,6 +927,10 @@ static int launch_gg_split(GGParams& p, hipStream_t st) {
       if ((unsigned)dyi < 3u && (unsigned)dxi < 3u) { p.tap_of[dyi * 3 + dxi] = t; seen |= 1 << (dyi * 3 + dxi); }
     }
     strips = seen == 0x1ff;
+    bool fwd = true, rev = true;
+    for (int i = 0; i < 9; ++i) { fwd = fwd && p.tap_of[i] == i; rev = rev && p.tap_of[i] == 8 - i; }
+    p.strip_rev = rev ? 1 : 0;
+    strips = strips && (fwd || rev);  // any other tap numbering would accumulate in another order than gg3s_kernel does
   }
   auto blocks_strip = [&](int bm, int bn) { return (unsigned)((((long long)g.N * g.Hi * (g.Wi + 2) + bm - 1) / bm) * (p.rows_pad / bn)); };
   const bool f16 = split_f16();

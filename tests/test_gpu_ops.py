@@ -805,3 +805,41 @@ def test_shared_input_conv_adds_the_skip_gradient_in_the_epilogue(ops, stride, w
     assert rel_err(to_nchw(y), yr.detach()) < TOL
     assert rel_err(to_nchw(x.grad), xr.grad) < TOL
     assert rel_err(W1.grad.cpu(), torch.autograd.grad(F.conv2d(x0, w1.requires_grad_(True), b1, stride=stride, padding=1), w1, gy)[0]) < TOL
+
+
+_VARIANT_CHILD = r"""
+import hashlib, torch
+from learned_hologram_gan_amd import hip_ops as ops
+torch.manual_seed(3)
+x = torch.randn(2, 48, 40, 128, device="cuda"); w = torch.randn(128, 128, 3, 3, device="cuda") * 0.05
+gy = torch.randn(2, 48, 40, 128, device="cuda"); gy2 = torch.randn(2, 24, 20, 128, device="cuda")
+with torch.no_grad():
+    y = ops.conv2d_forward_raw(x, w, None, 1)
+    gx = ops.Conv2dInputGradFn.apply(gy, w, 1, 48, 40, 128)
+    gx2 = ops.Conv2dInputGradFn.apply(gy2, w, 2, 48, 40, 128)
+    slot = torch.zeros(128, 128, 3, 3, device="cuda")
+    ops.conv2d_weight_grad_raw(x, gy, (128, 128, 3, 3), 1, slot, ops.operand_absmax(x), ops.operand_absmax(gy))
+torch.cuda.synchronize()
+print("HASH", " ".join(hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest()[:16] for t in (y, gx, gx2, slot)))
+"""
+
+
+def test_every_tiling_variant_gives_the_same_bits():
+    """What the autotuner picks must not show in the results: a 3x3 forward, its input gradient (flipped taps), a stride-2 input
+    gradient (merged parity classes, and one launch per class) and a weight gradient are bit-identical across the gather variants —
+    gg3s tiles, the 64 x 128 tile, strips — and across the weight-gradient kernels wg2s / wg4s / wg5p: every kernel accumulates per
+    32-channel chunk in ascending tap order, two sub-steps of 16, product groups a1 b0, a0 b1, a0 b0.  (One child process per forced
+    pair: LHG_GGS_VARIANT / LHG_WG_VARIANT are read once per process.)"""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    seen = {}
+    for gv, wv in ((2, 21), (0, 18), (9, 22), (5, 25), (8, 10), (12, 13)):
+        env = dict(os.environ, LHG_AUTOTUNE="0", LHG_GGS_VARIANT=str(gv), LHG_WG_VARIANT=str(wv), PYTHONPATH=root)
+        out = subprocess.run([sys.executable, "-c", _VARIANT_CHILD], cwd=root, env=env, capture_output=True, text=True)
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("HASH")]
+        assert out.returncode == 0 and lines, out.stdout[-800:] + out.stderr[-800:]
+        seen[(gv, wv)] = lines[-1]
+    assert len(set(seen.values())) == 1, seen
