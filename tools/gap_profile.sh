@@ -20,6 +20,13 @@ for q, ks in byq.items():
     gaps = [ks[i + 1][0] - ks[i][1] for i in range(len(ks) - 1)]
     small = [g for g in gaps if 0 < g < 200000]
     hist = collections.Counter(min(g // 2000, 10) for g in small)
+    pairs = collections.defaultdict(lambda: [0, 0])
+    for i in range(len(ks) - 1):
+        g = ks[i + 1][0] - ks[i][1]
+        if 0 < g < 200000:
+            a = pairs[(ks[i][2][:34], ks[i + 1][2][:34])]; a[0] += 1; a[1] += g
+    for (a, b), (n, t) in sorted(pairs.items(), key=lambda kv: -kv[1][1])[:10]:
+        print("   %-34s -> %-34s %4d gaps %7.2f ms  avg %5.1f us" % (a, b, n, t / 1e6, t / n / 1e3))
     print("queue %s: %d kernels, busy %.1f ms, gaps < 0.2 ms: %d totalling %.2f ms (median %.1f us); by 2-us bins: %s" % (
         q, len(ks), busy, len(small), sum(small) / 1e6, sorted(small)[len(small) // 2] / 1e3 if small else 0, dict(sorted(hist.items()))))
 PY
