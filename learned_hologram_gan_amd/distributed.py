@@ -73,25 +73,35 @@ class GradSynchronizer:
     Every rank records the same graph, so buckets complete — and collectives are issued — in the same order everywhere.
     """
 
-    def __init__(self, params, offsets, flat_grad: torch.Tensor, n_buckets: int = 4, group=None):
+    def __init__(self, params, offsets, flat_grad: torch.Tensor, n_buckets: int = 4, group=None, first_bucket_elems: int = 1 << 18):
         self.params, self.flat_grad, self.group = list(params), flat_grad, group
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         n = len(self.params)
         total = flat_grad.numel()
         target = max(1, total // max(1, n_buckets))
-        # walk parameters from last to first, closing a bucket every `target` elements
+        # Walk parameters from last to first, closing a bucket every `target` elements.  The FIRST bucket (the parameters next to the
+        # loss) is kept small — it closes before a parameter that would take it past `first_bucket_elems` (1 MiB, as DDP's first
+        # bucket) — so that communication starts early and so that an arrival the op layer cannot observe holds back little: the
+        # critic's head conv is visited by the gradient penalty's inner autograd.grad only (hip_ops.only_input_gradients), its recorded
+        # use is never answered by a contribution, and its bucket is left to finish().  With the head alone in a 37 KB bucket the
+        # three large buckets of the critic are reduced from inside backward.
         self.bucket_of, self.ranges, self.expected = [0] * n, [], []
         hi, count, b = total, 0, 0
         for i in range(n - 1, -1, -1):
+            lo = offsets[i]
+            if b == 0 and count > 0 and first_bucket_elems and hi - lo > first_bucket_elems and hi - offsets[i + 1] < target:
+                self.ranges.append((offsets[i + 1], hi))  # close the small first bucket in front of this parameter
+                self.expected.append(count)
+                hi, count, b = offsets[i + 1], 0, 1
             self.bucket_of[i] = b
             count += 1
-            lo = offsets[i]
             if hi - lo >= target or i == 0:
                 self.ranges.append((lo, hi))
                 self.expected.append(count)
                 hi, count, b = lo, 0, b + 1
         self._arrived = [0] * len(self.ranges)
         self._seen = [False] * n
+        self._real = [False] * n
         self._launched = [False] * len(self.ranges)
         self._work = []
         self._hooks = []
@@ -102,27 +112,38 @@ class GradSynchronizer:
 
             for i, p in enumerate(self.params):
                 self._hooks.append(p.register_post_accumulate_grad_hook(self._make_hook(i)))
+                self._hooks.append(p.register_hook(self._make_grad_seen(i)))  # tells a defined gradient from None
                 hip_ops.set_arrival_listener(p, self._make_listener(i))
 
-    def _arrive(self, i):
+    def _arrive(self, i, via_autograd):
         if not self._armed:
             return
         b = self.bucket_of[i]
+        # A contribution that lands after the bucket's all-reduce went out is a lost update.  The post-accumulate hook also fires when
+        # autograd had NOTHING to add (an op handed back None because it accumulated into the slot itself), so a hook arrival counts as
+        # a contribution only if the tensor hook saw a defined gradient for the parameter in this pass.
+        if self._launched[b] and (not via_autograd or self._real[i]):
+            raise RuntimeError("a gradient arrived for a bucket whose all-reduce had already been launched: a parameter received "
+                               "contributions both through autograd and through the flat-buffer path in one backward pass "
+                               "(every op must deliver ALL of a parameter's contributions one way: hip_ops.note_use / note_contribution)")
         if self._seen[i]:
             return
-        if self._launched[b]:
-            raise RuntimeError("a gradient arrived for a bucket whose all-reduce had already been launched: a parameter received "
-                               "contributions both through autograd and through the flat-buffer path in one backward pass")
         self._seen[i] = True
         self._arrived[b] += 1
         if self._arrived[b] == self.expected[b]:
             self._launch(b, False)
 
     def _make_hook(self, i):
-        return lambda _param: self._arrive(i)
+        return lambda _param: self._arrive(i, True)
+
+    def _make_grad_seen(self, i):
+        def seen(grad):
+            if self._armed and grad is not None:  # the engine calls tensor hooks with None for an undefined gradient
+                self._real[i] = True
+        return seen
 
     def _make_listener(self, i):
-        return lambda: self._arrive(i)
+        return lambda: self._arrive(i, False)
 
     _armed = False
 
@@ -145,6 +166,7 @@ class GradSynchronizer:
         """Call right before ``loss.backward()``."""
         self._arrived = [0] * len(self.ranges)
         self._seen = [False] * len(self.params)
+        self._real = [False] * len(self.params)
         self._launched = [False] * len(self.ranges)
         self._work = []
         self.launch_log = []

@@ -1119,12 +1119,19 @@ def bn_backward_raw(gy, x, y, gamma, stats, act, slope, want_res, ggamma, gbeta,
     return gx, gres
 
 
-class BatchNormGradFn(Function):
-    """First backward of BatchNormTrainFn as a differentiable op (needed by the gradient penalty)."""
+class BatchNormGradFn(TrackedFunction):
+    """First backward of BatchNormTrainFn as a differentiable op (needed by the gradient penalty).
+
+    Its own backward (the double backward) contributes d/d gamma: in a plain backward pass into a registered slot that contribution is
+    ADDED TO THE SLOT here and counted (note_use / note_contribution) like every other contribution of the hot path — a gamma that
+    received some contributions through the slot and this one through autograd's AccumulateGrad could have its bucket's all-reduce
+    launched (distributed.GradSynchronizer) between the two."""
 
     @staticmethod
     def forward(ctx, gy, x, y, gamma, stats, act, slope, want_res):
         Cc = gy.shape[-1]
+        ctx.gamma = gamma if ctx.needs_input_grad[3] else None
+        note_use(ctx.gamma)
         ggamma = torch.empty((Cc,), dtype=torch.float32, device=gy.device)
         gbeta = torch.empty((Cc,), dtype=torch.float32, device=gy.device)
         gx, gres = bn_backward_raw(gy, x, y, gamma, stats, act, slope, want_res, ggamma, gbeta, False)
@@ -1143,6 +1150,8 @@ class BatchNormGradFn(Function):
             raise NotImplementedError("double backward through the residual / gamma / beta gradients of batch norm "
                                       "is not part of the hot path (the gradient penalty differentiates d/dx only)")
         if ggx is None:
+            if param_grads_wanted() and _small_grad_slot(ctx.gamma) is not None:
+                note_contribution(ctx.gamma)  # a zero contribution still answers the recorded use
             return None, None, None, None, None, None, None, None
         N, H, W, Cc = x.shape
         pixels = N * H * W
@@ -1152,6 +1161,13 @@ class BatchNormGradFn(Function):
         ggamma2 = torch.empty((Cc,), dtype=torch.float32, device=x.device)
         call("lhg_bn_backward_backward", ptr(ggx_d), ptr(gy_d), ptr(x_d), ptr(y_d), pixels, Cc, ptr(stats), ptr(gamma),
              ctx.act, float(ctx.slope), ptr(ggy), ptr(gx2), ptr(ggamma2), ptr(_bn_ws(Cc, x.device, 5 * 4096 + 8)), stream_ptr())
+        if not param_grads_wanted():
+            return ggy, gx2, None, None, None, None, None, None
+        slot = _small_grad_slot(ctx.gamma)
+        if slot is not None:  # plain backward into the flat buffer: same delivery as BatchNormTrainFn.backward's d gamma
+            slot.add_(ggamma2)
+            note_contribution(ctx.gamma)
+            return ggy, gx2, None, None, None, None, None, None
         return ggy, gx2, None, ggamma2, None, None, None, None
 
 

@@ -114,5 +114,63 @@ def overlap():
     dist.destroy_process_group()
 
 
+def critic():
+    """Two ranks on one GPU over gloo: the FULL step (one critic update with the gradient penalty, then the generator update) with
+    different data per rank.  The critic's BatchNorm gammas receive contributions from three forward passes and from the penalty's
+    double backward: all of them must be in the flat buffer before the bucket's all-reduce goes out, every large bucket of
+    both models must be launched from inside backward, and the reduced gradients must equal the mean of the local ones."""
+    from learned_hologram_gan_amd import distributed
+    from learned_hologram_gan_amd import hip_ops
+    from learned_hologram_gan_amd.watermelon_hologram.watermelon import watermelon
+    from oracle import seeded
+
+    rank, world, _ = distributed.init_from_env("gloo")
+    dev = "cuda:0"
+    rows = cols = 64
+    stack = torch.linspace(-4e-4, 0.0, 21)[:-1][:8]
+    W = watermelon(filter_radius_coefficient=0.45, pad_size=32, distance_stack=stack, input_shape=(1, 4, rows, cols))
+    W.generator.load_state_dict(seeded.generator_state_dict())
+    W.discriminator.load_state_dict(seeded.critic_state_dict())
+    W.generator.to(dev).train()
+    W.discriminator.to(dev).train()
+    W.configure(1, 0.0, 1, 1e-3, 0.1, 1e-3, 1e-3, 1, 10, grad_buckets=4)
+    rgbd, tamp, tphs = seeded.smooth_batch(2, rows, cols, seed=300 + rank)
+    idx = torch.tensor([5, 2])
+    alphas = [torch.tensor([0.3, 0.8]).view(2, 1, 1, 1).to(dev)]
+    grabbed = {"D": [], "G": []}
+    logs = {"D": [], "G": []}
+    for name, opt, sync in (("D", W._opt_D, W._sync_D), ("G", W._opt_G, W._sync_G)):
+        def no_update(name=name, opt=opt, sync=sync):  # capture instead of Adam: every pass sees the same weights
+            hip_ops.join_side_stream()
+            torch.cuda.synchronize()
+            grabbed[name].append(opt.flat.grad.detach().clone())
+            logs[name].append(list(sync.launch_log))
+        opt.step = no_update
+    x = (rgbd.to(dev), tamp.to(dev), tphs.to(dev), idx, alphas)
+
+    def one_pass(enabled):
+        W._sync_D.enabled = W._sync_G.enabled = enabled
+        W.train_step(*x)
+
+    one_pass(False)   # local (first sight of every geometry)
+    one_pass(True)    # reduced
+    one_pass(False)   # local again
+    out = {"rank": rank}
+    for name, sync in (("D", W._sync_D), ("G", W._sync_G)):
+        local0, reduced, local = grabbed[name]
+        gathered = [torch.empty_like(local) for _ in range(world)]
+        dist.all_gather(gathered, local)
+        mean = sum(gathered) / world
+        both = [torch.empty_like(reduced) for _ in range(world)]
+        dist.all_gather(both, reduced)
+        out[name] = {"err": ((reduced - mean).norm() / mean.norm()).item(), "local_repeatable": bool(torch.equal(local0, local)),
+                     "ranks_agree": bool(torch.equal(both[0], both[1])), "buckets": len(sync.ranges),
+                     "bucket_elems": [hi - lo for lo, hi in sync.ranges],
+                     "launch_log": [(b, bool(ff)) for b, _, ff in logs[name][1]]}
+    print(json.dumps(out), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 if __name__ == "__main__":
-    {"rccl": rccl_world1, "overlap": overlap}[sys.argv[1]]()
+    {"rccl": rccl_world1, "overlap": overlap, "critic": critic}[sys.argv[1]]()

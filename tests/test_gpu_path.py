@@ -900,6 +900,25 @@ def test_gradient_buckets_are_reduced_inside_backward_two_ranks():
     assert not problems, (problems, out)
 
 
+def test_critic_step_with_gradient_penalty_two_ranks():
+    """The full step (critic update with the gradient penalty, then the generator update) on two ranks sharing this GPU over gloo:
+    reduced gradients = mean of the local ones for BOTH models (the critic's BatchNorm gammas collect slot contributions from three
+    forwards and from the penalty's double backward: none may land after its bucket's all-reduce went out), and only the small first
+    bucket (the critic's head conv and last BatchNorm are visited by the penalty's inner autograd.grad only) is left to finish()."""
+    out = sorted(_run_dist_worker("critic", 2), key=lambda r: r["rank"])
+    assert [r["rank"] for r in out] == [0, 1]
+    for r in out:
+        for name in ("D", "G"):
+            m = r[name]
+            assert m["ranks_agree"], (name, m)
+            if m["local_repeatable"]:
+                assert m["err"] < 1e-5, (name, m)
+            from_finish = [b for b, ff in m["launch_log"] if ff]
+            assert len(m["launch_log"]) == m["buckets"] and set(from_finish) <= {0, m["buckets"] - 1}, (name, m)  # first (small) / first-layer bucket at most
+            assert m["bucket_elems"][0] <= (1 << 18) or m["buckets"] == 1, (name, m)
+    assert out[0]["D"]["launch_log"] == out[1]["D"]["launch_log"] and out[0]["G"]["launch_log"] == out[1]["G"]["launch_log"]
+
+
 def test_train_step_repeats_bit_for_bit():
     """One process, one GPU: the same step on the same weights and data gives bit-identical losses, holograms, reconstructions and
     gradients three times in a row — with the weight-gradient GEMMs on the second stream, and with the caching allocator's free blocks
