@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define LHG_ABI_VERSION 3
+#define LHG_ABI_VERSION 4
 
 enum {
   LHG_OK = 0,
@@ -104,8 +104,12 @@ int lhg_nhwc_to_nchw(const float* src, int ld, float* dst, int N, int C, int H, 
  * at half the matrix work of LHG_PRECISION_F32_SPLIT.  fp16's 5-bit exponent needs a power-of-two scale s per tensor,
  * s = 2^(14 - floor(log2 max|x|)): the caller measures max|x| of each activation operand with lhg_absmax and passes the device
  * pointer (`*_absmax` arguments below, ignored in every other mode); lhg_pack_weight measures max|w| itself and keeps it behind
- * the panels.  Elements down to 2^-18 max|x| keep the full relative accuracy, smaller ones an absolute error below 2^-39 max|x|.
- * A non-finite maximum leaves the tensor unscaled (non-finite values then propagate as they do in fp32). */
+ * the panels.  Dynamic range inside one tensor (ABI 4): the residual plane of a GATHERED activation operand (forward / input-gradient
+ * GEMMs) is stored 2^11 times larger and multiplied with b0 2^-11, so activations keep their full relative accuracy down to 2^-29 max|x|
+ * (an absolute error below 2^-50 max|x| under that); weights keep it down to 2^-18 max|w| (2^-39 max|w| absolute under that).  The
+ * weight-gradient GEMMs contract over pixels, where a power-of-two scale PER CHANNEL of either operand factors out of the sum exactly:
+ * their `x_absmax` / `gy_absmax` arguments are per-channel vectors (lhg_channel_absmax), so a channel that sits far below the rest of
+ * its tensor loses nothing.  A non-finite maximum leaves the tensor (channel) unscaled (non-finite values then propagate as in fp32). */
 int lhg_set_conv_precision(int precision);
 int lhg_get_conv_precision(void);
 /* the mode the library starts in: LHG_PRECISION_F32_SPLIT_F16 unless the environment variable LHG_CONV_PRECISION
@@ -121,6 +125,11 @@ long long lhg_packed_weight_floats(int taps, int rows_pad, int k_pad);
  * maximum over several tensors.  The tensor-scale input of LHG_PRECISION_F32_SPLIT_F16: measure each GEMM operand once and pass
  * `out` as its `*_absmax`; any upper bound of max|x| is valid, a loose one only narrows the window of full relative accuracy. */
 int lhg_absmax(const float* x, long long pixels, int C, int ld, float* out, lhg_stream_t s);
+/* out[c] = max over pixels |x[p][c]|, c < C (C and ld multiples of 4, x 16-byte aligned, fp32 tensors; `out` is overwritten: the call
+ * zero-fills it on the stream first).  The per-channel scales of the weight-gradient GEMMs in the LHG_PRECISION_F32_SPLIT_F16 mode:
+ * pass `out` as the `x_absmax` (Ci floats) / `gy_absmax` (Co floats) of lhg_conv2d_backward_weight / lhg_conv_transpose2x2_backward_weight.
+ * Any per-channel upper bound is valid. */
+int lhg_channel_absmax(const float* x, long long pixels, int C, int ld, float* out, lhg_stream_t s);
 
 /* Pack a PyTorch 4-D weight w[D0][D1][KH][KW] into GEMM panels dst[KH*KW][rows_pad][k_pad],
  * K contiguous, zero padded.  rows_from_d0 = 1: rows = D0, K = D1 (Conv2d forward,
@@ -176,7 +185,8 @@ int lhg_conv2d_backward_input_add(const float* gy, int N, int H, int W, int Co, 
                                   const float* gy_absmax, lhg_stream_t s);
 
 /* Partial weight gradients: slabs[S][KH*KW][ci_pad][co_pad] (S = split count chosen by
- * lhg_conv2d_wgrad_splits), to be summed by lhg_wgrad_reduce. */
+ * lhg_conv2d_wgrad_splits), to be summed by lhg_wgrad_reduce.  LHG_PRECISION_F32_SPLIT_F16: `x_absmax` points to Ci floats and
+ * `gy_absmax` to Co floats — per-CHANNEL max|.| of the operands as passed here (lhg_channel_absmax); ignored in every other mode. */
 int lhg_conv2d_wgrad_splits(int N, int H, int W, int Ci, int Co, int KH, int KW, int stride);
 int lhg_conv2d_backward_weight(const float* x, int N, int H, int W, int Ci, int ldx,
                                const float* gy, int Co, int ldgy, int KH, int KW, int stride,

@@ -78,7 +78,7 @@ struct WGParams {
   float* slabs;       // [S][Tslabs][m_pad][n_pad]
   int m_pad, n_pad, Tslabs, kchunk;  // kchunk: pixels per split (multiple of 32)
   int xcd;
-  const float* in_amax;    // fp16-split mode: max|in|, max|gout| (device, lhg_absmax)
+  const float* in_amax;    // fp16-split mode: PER-CHANNEL max|in| (Ci floats) and max|gout| (Co floats), device, lhg_channel_absmax
   const float* gout_amax;
 };
 
@@ -459,6 +459,45 @@ static int launch_absmax(const float* x, long long pixels, int C, int ld, float*
   const int blocks = (int)std::max<long long>(1, std::min<long long>((items + 255) / 256 / 4, 1024));
   hipLaunchKernelGGL(absmax_kernel, dim3(blocks), dim3(256), 0, st, x, pixels, C, ld, reinterpret_cast<unsigned*>(out));
   return check_launch("absmax");
+}
+
+// out[c] = max(out[c], max over pixels |x[p][c]|) as magnitude bits (C % 4 == 0; out zeroed by the caller).  A thread owns one group of four
+// channels and walks pixels with four 16-byte loads in flight; the block's pixel lanes are folded through LDS and one filtered atomicMax
+// per channel and block goes out.  grid.y covers channel groups beyond 256 per block.
+__global__ __launch_bounds__(256) void channel_absmax_kernel(const float* __restrict__ x, long long pixels, int C, int ld, unsigned* __restrict__ out) {
+  const int C4 = C / 4;
+  const int lanes_c = min(C4, 256);            // channel groups per block row
+  const int rows = 256 / lanes_c;              // pixel lanes per block
+  const int cq = blockIdx.y * lanes_c + (int)(threadIdx.x % lanes_c), prow = threadIdx.x / lanes_c;
+  const bool live = cq < C4 && prow < rows;
+  u32x4 m = {0u, 0u, 0u, 0u};
+  if (live) {
+    const long long stride = (long long)gridDim.x * rows;
+    auto at = [&](long long q) { return *reinterpret_cast<const u32x4*>(x + q * ld + cq * 4); };
+    auto fold = [&](u32x4 v) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) m[e] = max(m[e], v[e] & 0x7fffffffu);
+    };
+    long long q = (long long)blockIdx.x * rows + prow;
+    for (; q + 3 * stride < pixels; q += 4 * stride) {
+      const u32x4 a = at(q), b = at(q + stride), c = at(q + 2 * stride), d = at(q + 3 * stride);
+      fold(a); fold(b); fold(c); fold(d);
+    }
+    for (; q < pixels; q += stride) fold(at(q));
+  }
+  __shared__ u32x4 red[256];
+  red[threadIdx.x] = m;
+  __syncthreads();
+  if (live && prow == 0) {
+    for (int r = 1; r < rows; ++r) {
+      const u32x4 o = red[r * lanes_c + (threadIdx.x % lanes_c)];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) m[e] = max(m[e], o[e]);
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e)
+      if (m[e] > *reinterpret_cast<volatile unsigned*>(out + cq * 4 + e)) atomicMax(out + cq * 4 + e, m[e]);
+  }
 }
 
 // ------------------------------------------------------------------ batched weight packing (fp16-split mode)
@@ -1031,12 +1070,13 @@ static int launch_wg(WGParams& p, int S, hipStream_t st, const WG3Params* p3 = n
   const bool split = split_mode();
   const bool f16 = split_f16();
   const int NP = split_planes();
-  if (f16) LHG_REQUIRE(p.in_amax != nullptr && p.gout_amax != nullptr, "wgrad (fp32_split_f16 mode): the operands' absmax pointers are missing (lhg_absmax)");
+  if (f16) LHG_REQUIRE(p.in_amax != nullptr && p.gout_amax != nullptr, "wgrad (fp32_split_f16 mode): the operands' per-channel absmax vectors are missing (lhg_channel_absmax)");
   if (bf16 || split) LHG_REQUIRE(small, "wgrad (bf16 / split mode): tensors of 4 GiB and more are not supported");
   auto valid = [&](int v) {
     if (v >= 22) return f16 && (v == 22 ? m128 && n128 : v == 23 ? m128 : v == 24 ? n128 : true);
     if (v >= 18) return f16 && (v == 18 ? m128 && n128 : v == 19 ? m128 : v == 20 ? n128 : true);
     if (v >= 14) return bf16 && act16 && (v == 14 ? m128 && n128 : v == 15 ? m128 : v == 16 ? n128 : true);
+    if (f16) return false;  // (wg2s_kernel's fp16 form scales per tensor: not offered next to the per-channel kernels above)
     if (split) return v >= 10 && (v == 10 ? m128 && n128 : v == 11 ? m128 : v == 12 ? n128 : true);
     if (v >= 10) return false;
     if (bf16) return v >= 6 && (v == 6 ? m128 && n128 : v == 7 ? m128 : v == 8 ? n128 : true);
@@ -1461,6 +1501,20 @@ int lhg_absmax(const float* x, long long pixels, int C, int ld, float* out, lhg_
   LHG_REQUIRE(pixels >= 0 && C > 0 && ld >= C, "absmax: bad extents (pixels %lld, C %d, ld %d)", pixels, C, ld);
   LHG_REQUIRE(!act_is_bf16(), "absmax: fp32 tensors only (the bf16 storage mode does not use it)");
   return launch_absmax(x, pixels, C, ld, out, as_stream(s), false);
+}
+
+int lhg_channel_absmax(const float* x, long long pixels, int C, int ld, float* out, lhg_stream_t s) {
+  LHG_REQUIRE(pixels >= 0 && C > 0 && C % 4 == 0 && ld >= C && ld % 4 == 0, "channel_absmax: bad extents (pixels %lld, C %d, ld %d; C and ld multiples of 4)", pixels, C, ld);
+  LHG_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "channel_absmax: x must be 16-byte aligned");
+  LHG_REQUIRE(!act_is_bf16(), "channel_absmax: fp32 tensors only (the bf16 storage mode does not use it)");
+  hipStream_t st = as_stream(s);
+  if (hipMemsetAsync(out, 0, (size_t)C * sizeof(float), st) != hipSuccess) return fail(LHG_E_LAUNCH, "channel_absmax: memset failed");
+  if (pixels == 0) return LHG_OK;
+  const int C4 = C / 4, lanes_c = std::min(C4, 256), rows = 256 / lanes_c;
+  const long long want = (pixels + (long long)rows * 8 - 1) / ((long long)rows * 8);  // ~8 pixels per thread
+  const int gx = (int)std::max<long long>(1, std::min<long long>(want, 2048));
+  hipLaunchKernelGGL(channel_absmax_kernel, dim3(gx, (C4 + lanes_c - 1) / lanes_c), dim3(256), 0, st, x, pixels, C, ld, reinterpret_cast<unsigned*>(out));
+  return check_launch("channel_absmax");
 }
 
 int lhg_wgrad_reduce(const float* slabs, int S, int T, int m_pad, int n_pad, float* grad, int D0, int D1, int m_is_d1, int accumulate,

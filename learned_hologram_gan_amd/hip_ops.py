@@ -437,6 +437,24 @@ def operand_absmax(t):
     return out
 
 
+def operand_chanmax(t):
+    """Per-channel max|t| of an NHWC fp32 operand of a WEIGHT-GRADIENT GEMM as a (C,) device tensor (lhg_channel_absmax on the current
+    stream) — the per-channel scales of the "fp32_split_f16" mode (the contraction runs over pixels, so a scale per channel factors
+    out of the sum exactly); None in every other mode.  Cached on the tensor for the stream it was measured on (the input of a
+    ResidualBlock feeds two convolutions, whose weight gradients run on the same stream)."""
+    if _mode() != _F16_SPLIT:
+        return None
+    st = stream_ptr()
+    known = t.__dict__.get("_lhg_cmax")
+    if known is not None and known[0] == t._version and known[1] == st:
+        return known[2]
+    p, N, H, W, Cc, ld = nhwc(t)
+    out = torch.empty((Cc,), dtype=torch.float32, device=t.device)
+    call("lhg_channel_absmax", p, N * H * W, Cc, ld, ptr(out), st)
+    t.__dict__["_lhg_cmax"] = (t._version, st, out)
+    return out
+
+
 def fused_absmax_slot(device):
     """A zeroed slot for a producer kernel that measures max|output| on its way out (lhg_bn_apply, lhg_bn_backward), or None when the
     current modes have no use for it."""
@@ -850,12 +868,11 @@ def conv2d_weight_grad_raw(x, gy, wshape, stride, slot=None, x_amax=None, gy_ama
     ci_pad, co_pad = pad_to(Cx, 64), pad_to(Cg, 64)
     slabs = torch.empty((S, KH * KW, ci_pad, co_pad), dtype=torch.float32, device=x.device)
     native.count_flops(1, 2.0 * N * gy.shape[1] * gy.shape[2] * Co * Ci * KH * KW)
-    if x_amax is None:
-        x_amax = operand_absmax(x)
-    if gy_amax is None or gyp is not gy:
-        gy_amax = operand_absmax(gyp)
+    # fp16-split mode: per-CHANNEL max|.| of both operands (the scalar tensor maxima the forward / input-gradient GEMMs use are not
+    # what this GEMM scales by: x_amax / gy_amax are accepted for the callers' convenience and ignored)
+    x_cmax, gy_cmax = operand_chanmax(x), operand_chanmax(gyp)
     call("lhg_conv2d_backward_weight", px, N, H, W, Cx, ldx, pg, Cg, ldg, KH, KW, stride, ptr(slabs), S, ci_pad, co_pad,
-         ptr(x_amax), ptr(gy_amax), stream_ptr())
+         ptr(x_cmax), ptr(gy_cmax), stream_ptr())
     gw = slot if slot is not None else torch.empty(tuple(wshape), dtype=torch.float32, device=x.device)
     if not gw.is_contiguous():
         raise ValueError("weight-gradient slot must be contiguous")
@@ -961,7 +978,7 @@ class ConvTranspose2x2Fn(TrackedFunction):
                 slabs = torch.empty((S, 4, ci_pad, co_pad), dtype=torch.float32, device=x.device)
                 native.count_flops(1, 2.0 * N * H * W * 4 * Ci * Co)
                 call("lhg_conv_transpose2x2_backward_weight", px, N, H, W, Cx, ldx, pg, Cg, ldg, ptr(slabs), S, ci_pad, co_pad,
-                     ptr(ctx.x_amax), ptr(gy_amax), stream_ptr())
+                     ptr(operand_chanmax(x)), ptr(operand_chanmax(gy)), stream_ptr())
                 out = slot if slot is not None else torch.empty(w.shape, dtype=torch.float32, device=x.device)
                 call("lhg_wgrad_reduce", ptr(slabs), S, 4, ci_pad, co_pad, ptr(out), Ci, Co, 0, int(slot is not None), stream_ptr())
                 return None if slot is not None else out

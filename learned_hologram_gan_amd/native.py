@@ -36,6 +36,8 @@ class PackItem(C.Structure):
 
 
 # name -> argtypes (restype is int unless listed in _RESTYPE)
+ABI_VERSION = 4  # LHG_ABI_VERSION of include/lhg_hip.h this binding was written against
+
 _SIGNATURES = {
     "lhg_abi_version": [],
     "lhg_last_error": [],
@@ -67,6 +69,7 @@ _SIGNATURES = {
     "lhg_conv_transpose2x2_wgrad_splits": [_i, _i, _i, _i, _i],
     "lhg_conv_transpose2x2_backward_weight": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _i, _i, _i, _p, _p, _p],
     "lhg_absmax": [_p, _ll, _i, _i, _p, _p],
+    "lhg_channel_absmax": [_p, _ll, _i, _i, _p, _p],
     "lhg_wgrad_reduce": [_p, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p],
     "lhg_channel_sum": [_p, _ll, _i, _i, _p, _i, _p, _p],
     "lhg_bn_stats": [_p, _ll, _i, _i, _p, _p, _p, _f, _f, _p, _p],
@@ -132,8 +135,8 @@ def load():
         fn.argtypes = argtypes
         fn.restype = _RESTYPE.get(name, C.c_int)
     got = lib.lhg_abi_version()
-    if got != 3:
-        raise NativeLibraryError(f"ABI version mismatch: library {got}, binding 3")
+    if got != ABI_VERSION:
+        raise NativeLibraryError(f"ABI version mismatch: library {got}, binding {ABI_VERSION}")
     _lib = lib
     return lib
 

@@ -132,6 +132,80 @@ def test_split_gemm_is_fp32_faithful(ops, case, mode, spread):
         assert es < 1e-5 and es <= 3.0 * ee + 5e-7, (e_split, e_exact)
 
 
+@pytest.mark.parametrize("case", [(2, 64, 64, 48, 48, 3, 1), (2, 128, 256, 24, 24, 3, 1), (2, 64, 128, 32, 32, 3, 2), (2, 64, 128, 24, 24, 1, 1)],
+                         ids=lambda c: "x".join(map(str, c)))
+@pytest.mark.parametrize("shift", [10, 20, 30])
+def test_split_f16_gemm_structured_dynamic_range(ops, case, shift):
+    """The default GEMM mode where a per-TENSOR scale is weakest: ONE input channel, ONE gout channel and ONE
+    spatial quadrant of x and gy are scaled by 2^-shift, so a whole slice of every result sits far below the tensor's maximum, and each
+    result is scored PER SLICE — max error over the slice relative to the slice's own maximum — against a float64 convolution, next to
+    the exact fp32 MFMA kernels on the same data:
+
+      forward        the quadrant's outputs            (every gathered activation there is 2^-shift below max|x|)
+      input gradient the quadrant's gx                 (gathered gy 2^-shift below max|gy|)
+      weight grad.   dW[:, c_small] and dW[n_small, :] (one operand's channel 2^-shift below the rest of its tensor)
+
+    The fp16-split kernels must be as accurate on the small slices as the exact kernels (boosted residual plane for gathered
+    activations, per-channel scales in the weight-gradient GEMMs); with the round-2 per-tensor scale the 2^-30 slices were off by 1e-3."""
+    N, Ci, Co, H, W, k, stride = case
+    Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+    f = 2.0 ** -shift
+    x = rnd(N, Ci, H, W, seed=21)
+    gy = rnd(N, Co, Ho, Wo, seed=23)
+    w = rnd(Co, Ci, k, k, seed=22, scale=(Ci * k * k) ** -0.5)
+    c_small, n_small = 5, 9
+    x[:, c_small] *= f
+    gy[:, n_small] *= f
+    x[:, :, : H // 2, : W // 2] *= f       # quadrant (the small channel there is 2^-2shift: its slice is scored on the other quadrants' rows)
+    gy[:, :, : Ho // 2, : Wo // 2] *= f
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    yd = F.conv2d(xd, wd, None, stride=stride, padding=k // 2)
+    gxd, gwd = torch.autograd.grad(yd, (xd, wd), gy.double())
+    Cip = ops.pad_to(Ci, 32)
+    xh, gh, wg = to_nhwc(x, Cip), to_nhwc(gy, ops.pad_to(Co, 4)), w.to(DEV)
+    m = 2  # rows / columns next to the quadrant's border mix both scales: scored with the large part
+    slices = {
+        "fwd quadrant": lambda t: t[:, :, : Ho // 2 - m, : Wo // 2 - m],
+        "fwd rest": lambda t: t[:, :, Ho // 2:, :],
+        "dgrad quadrant": lambda t: t[:, :, : H // 2 - m * stride, : W // 2 - m * stride],
+        "dgrad rest": lambda t: t[:, :, H // 2:, :],
+        "wgrad small input channel": lambda t: t[:, c_small],
+        "wgrad small gout channel": lambda t: t[n_small],
+        "wgrad rest": lambda t: t[n_small + 1:, c_small + 1:],
+    }
+
+    def run(mode):
+        ops.set_conv_precision(mode)
+        try:
+            with torch.no_grad():
+                y = to_nchw(ops.conv2d_forward_raw(xh, wg, None, stride))
+                gx = to_nchw(ops.Conv2dInputGradFn.apply(gh, wg, stride, H, W, Cip))[:, :Ci]
+                gw = ops.Conv2dWeightGradFn.apply(xh, gh, w.shape, stride).cpu()
+        finally:
+            ops.set_conv_precision("default")
+        out = {}
+        for name, sl in slices.items():
+            got, ref = {"fwd": (y, yd.detach()), "dgrad": (gx, gxd), "wgrad": (gw, gwd)}[name.split()[0]]
+            out[name] = rel_err(sl(got.double()), sl(ref))
+        return out
+
+    e_split, e_exact = run("fp32_split_f16"), run("fp32")
+    for name in slices:
+        assert e_split[name] < 2e-5 and e_split[name] <= 4.0 * e_exact[name] + 1e-6, (name, shift, e_split, e_exact)
+
+
+def test_channel_absmax_matches_torch(ops):
+    """lhg_channel_absmax: per-channel max|x| of an NHWC slice (the per-channel scales of the fp16-split weight-gradient GEMMs)."""
+    from learned_hologram_gan_amd.native import call, ptr, stream_ptr
+
+    for C, ld, pixels in ((64, 64, 5000), (32, 128, 777), (1024, 1024, 301), (96, 96, 64), (2048, 2048, 19)):
+        t = torch.randn((pixels, ld), device=DEV) * torch.logspace(-6, 3, ld, device=DEV)
+        t[3, 1] = -1e7
+        out = torch.full((C,), 123.0, device=DEV)
+        call("lhg_channel_absmax", ptr(t), pixels, C, ld, ptr(out), stream_ptr())
+        assert torch.equal(out, t[:, :C].abs().amax(dim=0)), (C, ld, pixels)
+
+
 def test_default_gemm_mode_and_env_override():
     """The library starts in the fp32-faithful two-term fp16 split mode unless LHG_CONV_PRECISION names another one (read at load time)."""
     import os
