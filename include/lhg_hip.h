@@ -125,11 +125,11 @@ long long lhg_packed_weight_floats(int taps, int rows_pad, int k_pad);
  * maximum over several tensors.  The tensor-scale input of LHG_PRECISION_F32_SPLIT_F16: measure each GEMM operand once and pass
  * `out` as its `*_absmax`; any upper bound of max|x| is valid, a loose one only narrows the window of full relative accuracy. */
 int lhg_absmax(const float* x, long long pixels, int C, int ld, float* out, lhg_stream_t s);
-/* out[c] = max over pixels |x[p][c]|, c < C (C and ld multiples of 4, x 16-byte aligned, fp32 tensors; `out` is overwritten: the call
- * zero-fills it on the stream first).  The per-channel scales of the weight-gradient GEMMs in the LHG_PRECISION_F32_SPLIT_F16 mode:
+/* out[c] = max over pixels |x[p][c]|, c < C (C and ld multiples of 4, x 16-byte aligned, fp32 tensors; `out` is overwritten;
+ * ws: >= 2048*C floats; two launches, no atomics).  The per-channel scales of the weight-gradient GEMMs in the LHG_PRECISION_F32_SPLIT_F16 mode:
  * pass `out` as the `x_absmax` (Ci floats) / `gy_absmax` (Co floats) of lhg_conv2d_backward_weight / lhg_conv_transpose2x2_backward_weight.
  * Any per-channel upper bound is valid. */
-int lhg_channel_absmax(const float* x, long long pixels, int C, int ld, float* out, lhg_stream_t s);
+int lhg_channel_absmax(const float* x, long long pixels, int C, int ld, float* out, float* ws, lhg_stream_t s);
 
 /* Pack a PyTorch 4-D weight w[D0][D1][KH][KW] into GEMM panels dst[KH*KW][rows_pad][k_pad],
  * K contiguous, zero padded.  rows_from_d0 = 1: rows = D0, K = D1 (Conv2d forward,

@@ -41,6 +41,7 @@ constexpr int kWave = 64;  // CDNA wavefront
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
   switch (act) {

@@ -461,45 +461,6 @@ static int launch_absmax(const float* x, long long pixels, int C, int ld, float*
   return check_launch("absmax");
 }
 
-// out[c] = max(out[c], max over pixels |x[p][c]|) as magnitude bits (C % 4 == 0; out zeroed by the caller).  A thread owns one group of four
-// channels and walks pixels with four 16-byte loads in flight; the block's pixel lanes are folded through LDS and one filtered atomicMax
-// per channel and block goes out.  grid.y covers channel groups beyond 256 per block.
-__global__ __launch_bounds__(256) void channel_absmax_kernel(const float* __restrict__ x, long long pixels, int C, int ld, unsigned* __restrict__ out) {
-  const int C4 = C / 4;
-  const int lanes_c = min(C4, 256);            // channel groups per block row
-  const int rows = 256 / lanes_c;              // pixel lanes per block
-  const int cq = blockIdx.y * lanes_c + (int)(threadIdx.x % lanes_c), prow = threadIdx.x / lanes_c;
-  const bool live = cq < C4 && prow < rows;
-  u32x4 m = {0u, 0u, 0u, 0u};
-  if (live) {
-    const long long stride = (long long)gridDim.x * rows;
-    auto at = [&](long long q) { return *reinterpret_cast<const u32x4*>(x + q * ld + cq * 4); };
-    auto fold = [&](u32x4 v) {
-#pragma unroll
-      for (int e = 0; e < 4; ++e) m[e] = max(m[e], v[e] & 0x7fffffffu);
-    };
-    long long q = (long long)blockIdx.x * rows + prow;
-    for (; q + 3 * stride < pixels; q += 4 * stride) {
-      const u32x4 a = at(q), b = at(q + stride), c = at(q + 2 * stride), d = at(q + 3 * stride);
-      fold(a); fold(b); fold(c); fold(d);
-    }
-    for (; q < pixels; q += stride) fold(at(q));
-  }
-  __shared__ u32x4 red[256];
-  red[threadIdx.x] = m;
-  __syncthreads();
-  if (live && prow == 0) {
-    for (int r = 1; r < rows; ++r) {
-      const u32x4 o = red[r * lanes_c + (threadIdx.x % lanes_c)];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) m[e] = max(m[e], o[e]);
-    }
-#pragma unroll
-    for (int e = 0; e < 4; ++e)
-      if (m[e] > *reinterpret_cast<volatile unsigned*>(out + cq * 4 + e)) atomicMax(out + cq * 4 + e, m[e]);
-  }
-}
-
 // ------------------------------------------------------------------ batched weight packing (fp16-split mode)
 // After an optimiser step every conv weight of the model needs its panels again: per weight that is a fill of the max|w| word, the
 // max|w| pass and the pack — three small launches, ~200 per train step.  lhg_pack_weights does the same work for up to PACK_BATCH
@@ -1501,20 +1462,6 @@ int lhg_absmax(const float* x, long long pixels, int C, int ld, float* out, lhg_
   LHG_REQUIRE(pixels >= 0 && C > 0 && ld >= C, "absmax: bad extents (pixels %lld, C %d, ld %d)", pixels, C, ld);
   LHG_REQUIRE(!act_is_bf16(), "absmax: fp32 tensors only (the bf16 storage mode does not use it)");
   return launch_absmax(x, pixels, C, ld, out, as_stream(s), false);
-}
-
-int lhg_channel_absmax(const float* x, long long pixels, int C, int ld, float* out, lhg_stream_t s) {
-  LHG_REQUIRE(pixels >= 0 && C > 0 && C % 4 == 0 && ld >= C && ld % 4 == 0, "channel_absmax: bad extents (pixels %lld, C %d, ld %d; C and ld multiples of 4)", pixels, C, ld);
-  LHG_REQUIRE((reinterpret_cast<uintptr_t>(x) & 15) == 0, "channel_absmax: x must be 16-byte aligned");
-  LHG_REQUIRE(!act_is_bf16(), "channel_absmax: fp32 tensors only (the bf16 storage mode does not use it)");
-  hipStream_t st = as_stream(s);
-  if (hipMemsetAsync(out, 0, (size_t)C * sizeof(float), st) != hipSuccess) return fail(LHG_E_LAUNCH, "channel_absmax: memset failed");
-  if (pixels == 0) return LHG_OK;
-  const int C4 = C / 4, lanes_c = std::min(C4, 256), rows = 256 / lanes_c;
-  const long long want = (pixels + (long long)rows * 8 - 1) / ((long long)rows * 8);  // ~8 pixels per thread
-  const int gx = (int)std::max<long long>(1, std::min<long long>(want, 2048));
-  hipLaunchKernelGGL(channel_absmax_kernel, dim3(gx, (C4 + lanes_c - 1) / lanes_c), dim3(256), 0, st, x, pixels, C, ld, reinterpret_cast<unsigned*>(out));
-  return check_launch("channel_absmax");
 }
 
 int lhg_wgrad_reduce(const float* slabs, int S, int T, int m_pad, int n_pad, float* grad, int D0, int D1, int m_is_d1, int accumulate,

@@ -450,7 +450,8 @@ def operand_chanmax(t):
         return known[2]
     p, N, H, W, Cc, ld = nhwc(t)
     out = torch.empty((Cc,), dtype=torch.float32, device=t.device)
-    call("lhg_channel_absmax", p, N * H * W, Cc, ld, ptr(out), st)
+    ws = torch.empty((2048 * Cc,), dtype=torch.float32, device=t.device)
+    call("lhg_channel_absmax", p, N * H * W, Cc, ld, ptr(out), ptr(ws), st)
     t.__dict__["_lhg_cmax"] = (t._version, st, out)
     return out
 

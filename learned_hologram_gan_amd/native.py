@@ -69,7 +69,7 @@ _SIGNATURES = {
     "lhg_conv_transpose2x2_wgrad_splits": [_i, _i, _i, _i, _i],
     "lhg_conv_transpose2x2_backward_weight": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _i, _i, _i, _p, _p, _p],
     "lhg_absmax": [_p, _ll, _i, _i, _p, _p],
-    "lhg_channel_absmax": [_p, _ll, _i, _i, _p, _p],
+    "lhg_channel_absmax": [_p, _ll, _i, _i, _p, _p, _p],
     "lhg_wgrad_reduce": [_p, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p],
     "lhg_channel_sum": [_p, _ll, _i, _i, _p, _i, _p, _p],
     "lhg_bn_stats": [_p, _ll, _i, _i, _p, _p, _p, _f, _f, _p, _p],

@@ -68,8 +68,10 @@ def _bf16(kind):
 
     if kind == "storage":
         hip_ops.set_activation_storage("bf16")
+    elif kind == "fp32":
+        hip_ops.set_conv_precision("default")  # "fp32" = fp32 tensors in the SHIPPED default GEMM mode (fp32_split_f16), not the exact kernels
     else:
-        hip_ops.set_conv_precision(kind if kind == "fp32" else "bf16")
+        hip_ops.set_conv_precision("bf16")
     try:
         yield
     finally:

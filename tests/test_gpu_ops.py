@@ -202,7 +202,8 @@ def test_channel_absmax_matches_torch(ops):
         t = torch.randn((pixels, ld), device=DEV) * torch.logspace(-6, 3, ld, device=DEV)
         t[3, 1] = -1e7
         out = torch.full((C,), 123.0, device=DEV)
-        call("lhg_channel_absmax", ptr(t), pixels, C, ld, ptr(out), stream_ptr())
+        ws = torch.empty((2048 * C,), device=DEV)
+        call("lhg_channel_absmax", ptr(t), pixels, C, ld, ptr(out), ptr(ws), stream_ptr())
         assert torch.equal(out, t[:, :C].abs().amax(dim=0)), (C, ld, pixels)
 
 

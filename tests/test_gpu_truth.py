@@ -20,8 +20,37 @@ pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 WL = torch.tensor([638e-9, 520e-9, 450e-9])
 PITCH = 3.74e-6
-K = 10.0  # GPU fp32 error <= K x CPU fp32 error (+ a floor of a few fp32 ulps of the output scale): same order of magnitude —
-# the ratio of two rounding-error realisations of an ill-conditioned map scatters between ~0.5 and ~6 from case to case
+# GPU fp32 error <= K x CPU fp32 error (+ a floor of a few fp32 ulps of the output scale) for the statistics that average over the tensor
+# (L2 norms, 99.9 % quantiles); the MAX norm of an ill-conditioned map is one pixel next to a zero of the field, where two rounding
+# realisations differ by more: it is bounded by KMAX.  Measured at 384^2 (profiles/r03_truth_by_mode*.json): L2 / quantile ratios
+# 1.5-2.0 in the exact and the default mode alike, max-norm ratios 1.7 (fp32) / 3.2 (fp32_split_f16) / 5.7 (fp32_split), while the
+# optics alone, fed with the truth's UNet output, are 3-4x CLOSER to the truth than the CPU's (GPU 1.7e-6, CPU 6.4e-6): what the GPU loses
+# it loses in the 27 convolutions + 18 train-mode BatchNorms of the UNet (6e-6 against 3e-6 in the max norm, in EVERY mode — the exact
+# fp32 MFMA kernels included), and the tail amplifies that ~20x in the max norm.
+K = 3.0
+KMAX = 8.0
+MODES = ("fp32_split_f16", "fp32", "fp32_split")
+RECORD = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r03_truth_tests.jsonl")
+
+
+def _record(test, mode, **values):
+    """Every measured (e_gpu, e_cpu) pair of these tests is kept: one JSON line per test and mode (copied to profiles/ by hand)."""
+    import json
+
+    os.makedirs(os.path.dirname(RECORD), exist_ok=True)
+    with open(RECORD, "a") as f:
+        f.write(json.dumps({"test": test, "mode": mode, **{k: [float(a), float(b)] for k, (a, b) in values.items()}}) + "\n")
+
+
+@pytest.fixture(params=MODES)
+def gemm_mode(request):
+    from learned_hologram_gan_amd import hip_ops
+
+    hip_ops.set_conv_precision(request.param)
+    try:
+        yield request.param
+    finally:
+        hip_ops.set_conv_precision("default")
 
 
 def _phase_dist(a, b):
@@ -33,7 +62,7 @@ def _l2(a, b):
 
 
 @pytest.mark.parametrize("rows,pad,batch", [(64, 32, 4), (96, 16, 2)])
-def test_generator_tail_vs_fp64_truth(rows, pad, batch):
+def test_generator_tail_vs_fp64_truth(rows, pad, batch, gemm_mode):
     """Full train-mode Generator (UNet -> x1.1 / x2pi -> back-propagation -> symmetric stencil -> normalise -> double-phase encode) and
     its reconstruction at the fixed distance, with gradients of a fixed projection of the reconstructed amplitude back to the input and
     to the parameters."""
@@ -72,22 +101,29 @@ def test_generator_tail_vs_fp64_truth(rows, pad, batch):
     # (the single worst pixel sits next to a zero of the field, where angle() amplifies without bound: it is bounded loosely)
     e_gpu, e_cpu = _phase_dist(poh.detach().cpu(), poh64), _phase_dist(poh32, poh64)
     q = lambda e, p: torch.quantile(e, p).item()  # noqa: E731
-    assert q(e_gpu, 0.999) <= K * q(e_cpu, 0.999) + 1e-5, (q(e_gpu, 0.999), q(e_cpu, 0.999))
-    assert e_gpu.max() <= 2 * K * e_cpu.max() + 1e-3, (e_gpu.max().item(), e_cpu.max().item())
-    assert rel_err(amp.detach().cpu().double(), amp64) <= K * rel_err(amp32, amp64) + 2e-6
-    assert _l2(x.grad.cpu(), dx64) <= K * _l2(dx32, dx64) + 1e-5
+    rec = {"poh_q999": (q(e_gpu, 0.999), q(e_cpu, 0.999)), "poh_max": (e_gpu.max().item(), e_cpu.max().item()),
+           "amp_max": (rel_err(amp.detach().cpu().double(), amp64), rel_err(amp32, amp64)), "amp_l2": (_l2(amp.detach().cpu(), amp64), _l2(amp32, amp64)),
+           "dx_l2": (_l2(x.grad.cpu(), dx64), _l2(dx32, dx64))}
     named = dict(G.named_parameters())
-    worst = 0.0
+    worst, worst_key = 0.0, None
     for k, g64 in gw64.items():
         if k.endswith(("convolution_layer_1.bias", "convolution_layer_2.bias")) or g64.norm() == 0:
             continue  # analytically zero (feeds a train-mode BatchNorm)
         e_g, e_c = _l2(named[k].grad.cpu(), g64), _l2(gw32[k], g64)
-        assert e_g <= 2 * K * e_c + 1e-4, (k, e_g, e_c)
-        worst = max(worst, e_g / max(e_c, 1e-12))
+        if e_g / max(e_c, 1e-12) > worst:
+            worst, worst_key = e_g / max(e_c, 1e-12), (e_g, e_c)
+        assert e_g <= KMAX * e_c + 1e-4, (k, e_g, e_c)
+    rec["param_grad_l2_worst_ratio"] = worst_key
+    _record(f"generator_tail[{rows}]", gemm_mode, **rec)
     assert worst > 0
+    assert rec["poh_q999"][0] <= K * rec["poh_q999"][1] + 1e-5, rec
+    assert rec["poh_max"][0] <= KMAX * rec["poh_max"][1] + 1e-3, rec
+    assert rec["amp_l2"][0] <= K * rec["amp_l2"][1] + 2e-6, rec
+    assert rec["amp_max"][0] <= KMAX * rec["amp_max"][1] + 2e-6, rec
+    assert rec["dx_l2"][0] <= K * rec["dx_l2"][1] + 1e-5, rec
 
 
-def test_full_size_step_vs_fp64_truth(oracle_full_step, oracle_full_step_fp64):
+def test_full_size_step_vs_fp64_truth(oracle_full_step, oracle_full_step_fp64, gemm_mode):
     """BASELINE configs[1] at full size (384x384, batch 4, one critic update with the gradient penalty, both Adam steps): every
     quantity the loose tolerances of test_full_size_train_step_vs_oracle cover, measured against the float64 evaluation."""
     from learned_hologram_gan_amd.watermelon_hologram.watermelon import watermelon
@@ -104,11 +140,20 @@ def test_full_size_step_vs_fp64_truth(oracle_full_step, oracle_full_step_fp64):
     got = dict(zip(("focal_phase_gradient_loss", "perceptual_loss", "pixel_loss", "TV_loss", "gan_loss", "G_loss", "D_loss"), W.train_losses_tensor.tolist()))
 
     e_gpu, e_cpu = _phase_dist(out["POH"].cpu(), ref64["POH"])[::7], _phase_dist(ref32["POH"], ref64["POH"])[::7]
-    assert torch.quantile(e_gpu, 0.999) <= K * torch.quantile(e_cpu, 0.999) + 1e-5, (torch.quantile(e_gpu, 0.999).item(), torch.quantile(e_cpu, 0.999).item())
-    assert e_gpu.max() <= 2 * K * e_cpu.max() + 1e-3, (e_gpu.max().item(), e_cpu.max().item())
+    rec = {"poh_q999": (torch.quantile(e_gpu, 0.999).item(), torch.quantile(e_cpu, 0.999).item()), "poh_max": (e_gpu.max().item(), e_cpu.max().item())}
     for key in ("hat_amps", "target_amps"):
-        eg, ec = rel_err(out[key].cpu().double(), ref64[key]), rel_err(ref32[key].double(), ref64[key])
-        assert eg <= K * ec + 2e-6, (key, eg, ec)
+        rec[key + "_max"] = (rel_err(out[key].cpu().double(), ref64[key]), rel_err(ref32[key].double(), ref64[key]))
+        rec[key + "_l2"] = (_l2(out[key].cpu(), ref64[key]), _l2(ref32[key], ref64[key]))
     for key in ("focal_phase_gradient_loss", "pixel_loss", "TV_loss", "gan_loss", "G_loss", "D_loss"):
-        eg, ec = abs(got[key] - ref64[key]), abs(ref32[key] - ref64[key])
-        assert eg <= K * ec + 2e-6 * abs(ref64[key]) + 1e-9, (key, got[key], ref32[key], ref64[key])
+        rec[key] = (abs(got[key] - ref64[key]) / abs(ref64[key]), abs(ref32[key] - ref64[key]) / abs(ref64[key]))
+    _record("full_size_step", gemm_mode, **rec)
+    assert rec["poh_q999"][0] <= K * rec["poh_q999"][1] + 1e-5, rec
+    assert rec["poh_max"][0] <= KMAX * rec["poh_max"][1] + 1e-3, rec
+    for key in ("hat_amps", "target_amps"):
+        assert rec[key + "_l2"][0] <= K * rec[key + "_l2"][1] + 2e-6, (key, rec)
+        assert rec[key + "_max"][0] <= KMAX * rec[key + "_max"][1] + 2e-6, (key, rec)
+    # north_star's 1e-4 on the reconstructed amplitudes: held in the L2 norm by every mode (6e-6 measured); in the max norm the CPU's own
+    # fp32 evaluation sits at 3.3e-5, the exact fp32 MFMA kernels at 5.6e-5 and the default mode at 1.0e-4 (the worst of 1.8 M pixels)
+    assert rec["hat_amps_l2"][0] <= 2e-5 and rec["hat_amps_max"][0] <= 3e-4, rec
+    for key in ("focal_phase_gradient_loss", "pixel_loss", "TV_loss", "gan_loss", "G_loss", "D_loss"):
+        assert rec[key][0] <= KMAX * rec[key][1] + 2e-6, (key, got[key], ref32[key], ref64[key], rec)
