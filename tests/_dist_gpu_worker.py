@@ -78,6 +78,34 @@ def overlap():
                     notes.append({"pass": len(fwd) - 1, "recompute": k, "elements": int((d > 0).sum()), "max_abs": float(d.max()),
                                   "where": torch.nonzero(d > 0)[:4].tolist()})
 
+    def asm_probe(poh, reps=200):
+        """Localise a non-repeating reconstruction: the fused operator (three kernels per call) and its two halves — to_spectrum (row
+        pass + column FFT x filter) and from_spectrum (column IFFT + row pass) — evaluated `reps` times on fixed inputs while the OTHER
+        rank does the same on this GPU; every call is compared bit for bit with the first.  Counts, first offenders and the element
+        positions go into the kept JSON record."""
+        prop, fixed = W.propagator, W.generator.part2.propagator
+        found = {"full": [], "to_spectrum": [], "from_spectrum": []}
+        with torch.no_grad():
+            ref = prop.reconstruct_planes(fixed, poh, x[1], x[2], idx)
+            S0 = torch.cat((fixed.propagate_POH2Freq_forward(poh), prop.filter_AP2filteredFreq(x[1], x[2])), 0)
+            back0 = prop.propagate_multiple_samples_with_random_fixed_multiple_distances_freq2amp(S0, idx)
+            for r in range(reps):
+                again = prop.reconstruct_planes(fixed, poh, x[1], x[2], idx)
+                for name, a, b in zip(("hat_amp", "hat_phs", "tgt_amp", "tgt_phs"), again, ref):
+                    if not torch.equal(a, b):
+                        d = (a - b).abs()
+                        found["full"].append({"rep": r, "out": name, "elements": int((d > 0).sum()), "max_abs": float(d.max()), "where": torch.nonzero(d > 0)[:4].tolist()})
+                S = torch.cat((fixed.propagate_POH2Freq_forward(poh), prop.filter_AP2filteredFreq(x[1], x[2])), 0)
+                if not torch.equal(torch.view_as_real(S), torch.view_as_real(S0)):
+                    d = (S - S0).abs()
+                    found["to_spectrum"].append({"rep": r, "elements": int((d > 0).sum()), "max_abs": float(d.max()), "where": torch.nonzero(d > 0)[:4].tolist()})
+                back = prop.propagate_multiple_samples_with_random_fixed_multiple_distances_freq2amp(S0, idx)
+                for name, a, b in zip(("amp", "phs"), back, back0):
+                    if not torch.equal(a, b):
+                        d = (a - b).abs()
+                        found["from_spectrum"].append({"rep": r, "out": name, "elements": int((d > 0).sum()), "max_abs": float(d.max()), "where": torch.nonzero(d > 0)[:4].tolist()})
+        return {"reps": reps, "mismatches": {k: len(v) for k, v in found.items()}, "first": {k: v[:3] for k, v in found.items()}}
+
     sync.enabled = False
     one_pass()                 # pass 0: local, first sight of every geometry (the GEMM launcher times its tilings here)
     sync.enabled = True
@@ -87,6 +115,8 @@ def overlap():
     log = [(b, c - before, ff) for b, c, ff in sync.launch_log]
     sync.enabled = False
     one_pass()                 # pass 2: local again
+    dist.barrier()             # both ranks enter the probe together: it measures the operator under the two-process contention of the rig
+    probe = asm_probe(W.generator(x[0]).detach())
     local0, reduced, local = grabbed
     gathered = [torch.empty_like(local) for _ in range(world)]
     dist.all_gather(gathered, local)
@@ -107,7 +137,7 @@ def overlap():
 
     print(json.dumps({"rank": rank, "err": err, "launch_log": log, "contributions": total, "buckets": len(sync.ranges),
                       "local_repeatable": bool(torch.equal(local0, local)), "ranks_agree": bool(torch.equal(both[0], both[1])),
-                      "forward_repeats": fwd[0] == fwd[1] == fwd[2], "forward": fwd, "recompute_notes": notes,
+                      "forward_repeats": fwd[0] == fwd[1] == fwd[2], "forward": fwd, "recompute_notes": notes, "asm_probe": probe,
                       "diff_pass0_vs_pass2": offenders(local0, local), "diff_reduced_vs_mean": offenders(reduced, mean) if err > 1e-6 else []}),
           flush=True)
     dist.barrier()

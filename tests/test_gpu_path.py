@@ -3,6 +3,9 @@
 north_star tolerance: 1e-4 relative fp32 (max-norm), phases compared modulo 2*pi.
 """
 
+import json
+import os
+
 import pytest
 import torch
 
@@ -863,13 +866,20 @@ def test_gradient_buckets_are_reduced_inside_backward_two_ranks():
     import warnings
 
     # "reduced == mean of the local gradients" compares three passes over the same data, so it presumes passes that repeat.  With TWO
-    # PROCESSES time-slicing one GPU (this rig only: production is one process per GPU) about one run in twenty shows a pass that
-    # differs from the other two in a few bits — a loss, or reconstructed amplitudes from a bit-identical hologram (the worker reports
-    # which: forward, recompute_notes, diff_pass0_vs_pass2).  In ONE process the step and the operator repeat bit for bit
-    # (test_train_step_repeats_bit_for_bit; tools/asm_determinism.py: 9000 calls; tools/scribble_probe.py: results do not depend on what
-    # other kernels leave in LDS or registers), so a run that does not repeat is run once more before it counts as a failure.
-    def attempt():
+    # PROCESSES sharing one GPU (this rig only: production is one process per GPU) round 2 saw about one run in twenty with a pass that
+    # differed from the other two in a few bits; the cause is NOT established (DESIGN.md §5 lists what has been excluded).  Every run
+    # therefore keeps the worker's full record — forward checksums per pass, which reconstruction pixels differed, which parameters'
+    # gradients differed, and a 200-call determinism probe of the angular-spectrum operator and of its two halves under the same
+    # two-process contention — as gpurun_out/r03_two_rank_overlap.jsonl.  A run that does not repeat is run ONCE more; if the second does
+    # not repeat either the test FAILS, and the "reduced == mean" assertion is never dropped.
+    record = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r03_two_rank_overlap.jsonl")
+
+    def attempt(n):
         out = sorted(_run_dist_worker("overlap", 2), key=lambda r: r["rank"])
+        os.makedirs(os.path.dirname(record), exist_ok=True)
+        with open(record, "a") as f:
+            for r in out:
+                f.write(json.dumps(dict(r, attempt=n)) + "\n")
         problems = []
         if [r["rank"] for r in out] != [0, 1]:
             return ["ranks missing"], False, out
@@ -890,13 +900,12 @@ def test_gradient_buckets_are_reduced_inside_backward_two_ranks():
             problems.append("launch logs differ between the ranks")
         return problems, repeatable, out
 
-    problems, repeatable, out = attempt()
-    if problems or not repeatable:
-        warnings.warn(f"two-process rig, first run: {problems or 'a pass did not repeat'}: "
-                      f"{[(r['forward'], r['recompute_notes'], r['diff_pass0_vs_pass2']) for r in out]}")
-        problems, repeatable, out = attempt()
-        if not repeatable:
-            warnings.warn("two-process rig: a pass did not repeat in the second run either; the checks that do not presume it still hold")
+    problems, repeatable, out = attempt(0)
+    if not problems and not repeatable:
+        warnings.warn("two-process rig, first run: a pass did not repeat: "
+                      f"{[(r['forward'], r['recompute_notes'], r['diff_pass0_vs_pass2'], r['asm_probe']) for r in out]}")
+        problems, repeatable, out = attempt(1)
+        assert repeatable, ("two-process rig: a pass did not repeat in two runs in a row", out)
     assert not problems, (problems, out)
 
 
