@@ -43,8 +43,12 @@ if REPO not in sys.path:
 
 FP32_MFMA_PEAK_TFLOPS = 157.3  # MI355X dense fp32 matrix peak (MI355X_MICROARCH.md, chip-level parameters)
 BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (same table)
-KERNEL_SOURCES = ("conv_engine.hip", "gg2_kernel.inc", "gg2b_kernel.inc", "gg3s_kernel.inc", "gg4s_kernel.inc", "wg2_kernel.inc", "wg2b_kernel.inc", "wg2s_kernel.inc", "wg3b_kernel.inc", "wg4s_kernel.inc", "wg5p_kernel.inc",
-                  "wg3_kernel.inc")
+
+
+def kernel_sources():
+    """Every kernel source of the conv engine (conv_engine.hip and the .inc files it includes): a glob, so a new include cannot be forgotten."""
+    d = os.path.join(REPO, "learned_hologram_gan_amd", "csrc")
+    return sorted(glob.glob(os.path.join(d, "*.inc")) + [os.path.join(d, "conv_engine.hip"), os.path.join(d, "common.h")])
 
 
 def parse():
@@ -59,12 +63,13 @@ def parse():
     ap.add_argument("--d-ratio", type=int, default=1, help="critic updates per generator update (BASELINE.md assembled step: 1)")
     ap.add_argument("--cpu-baseline", type=int, default=1, help="0 skips the CPU oracle timing")
     ap.add_argument("--cpu-rows", type=int, default=0, help="frame size of the CPU sample (0 = same as --rows)")
+    ap.add_argument("--cpu-batch", type=int, default=0, help="frames per CPU step (0 = same as --batch)")
     ap.add_argument("--secondary", type=int, default=1, help="0 skips the 4K inference leg (north_star's second target)")
     ap.add_argument("--profile-steps", type=int, default=5, help="steps of each instrumented pass behind `roofline`")
     ap.add_argument("--other-modes", type=int, default=1, help="0 skips the informational timing of the other GEMM formulations")
     ap.add_argument("--graph", type=int, default=0, help="infer mode: replay a captured hipGraph instead of eager launches")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
-                    help="f32 (the benchmark metric): exact fp32 MFMA.  bf16 (BASELINE configs[2]/[4], informational): bf16 conv-GEMM operands, "
+                    help="f32 (the benchmark metric): fp32 tensors, conv GEMMs in the library's default fp32-faithful mode.  bf16 (BASELINE configs[2]/[4], informational): bf16 conv-GEMM operands, "
                          "fp32 accumulation")
     ap.add_argument("--precision", choices=("default", "fp32", "fp32_split", "fp32_split2", "fp32_split_f16", "bf16"), default="default",
                     help="conv-GEMM arithmetic (hip_ops.set_conv_precision); default: fp32 tensors with the library's default fp32 GEMM mode, "
@@ -81,8 +86,8 @@ def parse():
 
 def kernel_source_sha16():
     h = hashlib.sha256()
-    for name in KERNEL_SOURCES:
-        with open(os.path.join(REPO, "learned_hologram_gan_amd", "csrc", name), "rb") as f:
+    for path in kernel_sources():
+        with open(path, "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
 
@@ -103,9 +108,9 @@ def pmc_traffic():
 
 
 def cpu_baseline(args):
-    """The same train step through the CPU oracle (checker code timed as the reported baseline): 1 warm-up + median of 3 runs
-    (BASELINE.md §3).  Sample: ONE frame (batch 1) — a batch-4 step costs ~4x as much on the CPU (no batch economy there), which would
-    push the default run past the 10-30 s the baseline leg may use; frames/s is per frame either way."""
+    """The same train step through the CPU oracle (checker code timed as the reported baseline) ON THE BENCH WORKLOAD — the same frame
+    size and the same batch per step as the GPU line beside it: 1 warm-up + median of 3 runs (~5 s per run at 384^2 bs=4
+    on the box's 16-core share, ~20 s in all)."""
     from oracle import seeded, step
 
     # the GPU box gives one GPU a 16-CPU share although it reports every core of the host
@@ -113,19 +118,22 @@ def cpu_baseline(args):
     torch.set_num_threads(threads)
     rows = args.cpu_rows or args.rows
     cols = args.cpu_rows or args.cols
+    B = args.cpu_batch or args.batch
     stack = torch.linspace(-4e-4, 0.0, 21)[:-1]
     st = step.make_state(rows, cols, args.pad, 0.45, stack, seeded.generator_state_dict(), seeded.critic_state_dict())
-    rgbd, amp, phs = seeded.synthetic_batch(1, rows, cols)
+    rgbd, amp, phs = seeded.synthetic_batch(B, rows, cols)
     w = step.LossWeights(d_ratio=args.d_ratio)
+    idx = torch.tensor([(7 + 3 * b) % 20 for b in range(B)])
     times = []
     for _ in range(4):
         t0 = time.perf_counter()
-        step.train_step(st, rgbd, amp, phs, w, torch.tensor([7]), [torch.full((1, 1, 1, 1), 0.5) for _ in range(max(args.d_ratio, 1))])
+        step.train_step(st, rgbd, amp, phs, w, idx, [torch.full((B, 1, 1, 1), 0.5) for _ in range(max(args.d_ratio, 1))])
         times.append(time.perf_counter() - t0)
     dt = statistics.median(times[1:])
-    return {"value": round(1.0 / dt, 5), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"1 frame {rows}x{cols} (batch 1) per run, one full train step (G fwd+bwd, {args.d_ratio} critic update(s) with gradient "
-                      f"penalty, Adam x2) through oracle/step.py; 1 warm-up ({times[0]:.1f} s) + median of 3 runs ({dt:.2f} s)"}
+    return {"value": round(B / dt, 5), "unit": "frames/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{B} frames {rows}x{cols} per run (the bench workload: batch {B}), one full train step (G fwd+bwd, {args.d_ratio} critic "
+                      f"update(s) with gradient penalty, Adam x2) through oracle/step.py; 1 warm-up ({times[0]:.1f} s) + median of 3 runs "
+                      f"({dt:.2f} s per step = {dt / B:.2f} s per frame)"}
 
 
 def roofline_block(res, steps, peak):
@@ -217,6 +225,12 @@ def main():
     peak_note = ("dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32)" if products is None else
                  f"dense 16-bit MFMA peak {BF16_MFMA_PEAK_TFLOPS:.0f} TFLOP/s (bf16 and fp16 alike) / {products} product(s) per multiply-add of the '{mode}' formulation"
                  + ("" if bf16 else f"; the exact-fp32 MFMA formulation peaks at {FP32_MFMA_PEAK_TFLOPS}"))
+    # the arithmetic type the path computes in: fp32 tensors everywhere; the conv GEMMs' formulation is part of the label because the default
+    # one is NOT the reference's arithmetic (fp32-faithful emulation on the fp16 matrix pipe; tests/test_gpu_truth.py measures it per mode)
+    dtype_label = {"fp32": "f32", "fp32_split_f16": "f32 (conv GEMMs: fp16x2-split operands, 3 MFMA products, fp32 accumulate)",
+                   "fp32_split": "f32 (conv GEMMs: bf16x3-split operands, 6 MFMA products, fp32 accumulate)",
+                   "fp32_split2": "f32 (conv GEMMs: bf16x2-split operands, 3 MFMA products: ~2^-16)", "bf16": "bf16"}[mode]
+
     def build_trainer():
         stack = torch.linspace(-4e-4, 0.0, 21)[:-1]  # trainingModel.py:62
         perceptual = None
@@ -351,7 +365,7 @@ def main():
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
-            "dtype": args.dtype,
+            "dtype": dtype_label,
             "data": "synthetic random RGBD / target amplitude+phase in [0,1), reference-style random-init weights",
             "config": {"workload": f"{args.rows}x{args.cols}x3 bs={B}/GPU generator+critic train step (d_ratio={args.d_ratio}, "
                                    f"lambda_gp=10, pad {args.pad} -> {args.rows + 2 * args.pad}^2 FFTs, 20-plane stack, "
@@ -363,7 +377,18 @@ def main():
         }
 
     # ---- the same step with the other fp32-tensor GEMM formulations (informational; a few steps each, every rank: collectives inside)
-    other = {}
+    other, by_mode = {}, {}
+
+    def mode_roofline(peak, note):
+        """gather-GEMM rate of the CURRENT mode from an instrumented pass of 2 steps (second stream on: the timed conditions)."""
+        with native.kernel_profile() as pm:
+            for _ in range(2):
+                W.train_step(rgbd, tamp, tphs)
+            torch.cuda.synchronize()
+        blk = roofline_block(pm.result, 2, peak)
+        return {"achieved": blk["achieved"], "peak": peak, "frac": blk["frac"], "unit": "TFLOP/s", "peak_note": note,
+                "kernel_ms_per_step": blk["kernel_ms_per_step"], "wgrad_kernel": blk["wgrad_kernel"]}
+
     if args.mode == "train" and not bf16 and args.other_modes:
         for name in ("fp32", "fp32_split", "fp32_split2"):
             if name == mode:
@@ -377,6 +402,11 @@ def main():
                 W.train_step(rgbd, tamp, tphs)
             sync()
             other[name] = round((time.perf_counter() - t0) / 4 * 1e3, 3)
+            if name == "fp32":
+                by_mode["fp32"] = dict(mode_roofline(FP32_MFMA_PEAK_TFLOPS, "dense fp32 MFMA peak (v_mfma_f32_32x32x2_f32): the reference's arithmetic"),
+                                       ms_per_step=other[name])
+            elif name == "fp32_split":
+                by_mode["fp32_split"] = dict(mode_roofline(round(BF16_MFMA_PEAK_TFLOPS / 6, 1), "dense bf16 MFMA peak / 6 products"), ms_per_step=other[name])
         hip_ops.set_conv_precision(mode)
         # bf16 NHWC activation storage (what `--dtype bf16` measures): a fresh trainer, the mode is process-wide
         del W
@@ -392,9 +422,18 @@ def main():
             W.train_step(rgbd, tamp, tphs)
         sync()
         other["bf16_storage"] = round((time.perf_counter() - t0) / 8 * 1e3, 3)
+        by_mode["bf16_storage"] = dict(mode_roofline(BF16_MFMA_PEAK_TFLOPS, "dense bf16 MFMA peak, one product per multiply-add (bf16 operands AND bf16 activation storage: "
+                                                     "informational, not the reference's precision)"), ms_per_step=other["bf16_storage"])
         hip_ops.set_activation_storage("fp32")
         if args.precision != "default":
             hip_ops.set_conv_precision(args.precision)
+    if rank == 0 and by_mode:
+        r0 = out["roofline"]
+        by_mode[mode] = {"achieved": r0["achieved"], "peak": r0["peak"], "frac": r0["frac"], "unit": "TFLOP/s", "peak_note": r0["peak_note"],
+                         "kernel_ms_per_step": r0["kernel_ms_per_step"], "wgrad_kernel": r0["wgrad_kernel"], "ms_per_step": out["ms_per_step"], "headline": True}
+        out["roofline_by_mode"] = dict(by_mode, note="gather-GEMM (dominant kernel) rate of the same step per GEMM formulation, each priced against the matrix peak of ITS "
+                                       "formulation, under the timed conditions (weight gradients concurrently on the second stream); the exact-fp32 step is the "
+                                       "reference's arithmetic, the headline mode is fp32-faithful (tests/test_gpu_truth.py, profiles/r03_truth_*.json)")
     if rank == 0 and other:
         out["other_modes_ms_per_step"] = dict(other, note="fp32: exact fp32 MFMA (v_mfma_f32_32x32x2_f32).  fp32_split: three bf16 terms per operand, six MFMA products "
                                               "(round 2's first fp32-faithful formulation).  fp32_split2: two bf16 terms per operand, "

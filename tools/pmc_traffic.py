@@ -12,23 +12,24 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def kernel_source_sha16():
+    """= bench.kernel_source_sha16(): every .inc of csrc/ plus conv_engine.hip and common.h."""
+    d = os.path.join(REPO, "learned_hologram_gan_amd", "csrc")
     h = hashlib.sha256()
-    for name in ("conv_engine.hip", "gg2_kernel.inc", "gg2b_kernel.inc", "gg3s_kernel.inc", "gg4s_kernel.inc", "wg2_kernel.inc", "wg2b_kernel.inc", "wg2s_kernel.inc", "wg3b_kernel.inc", "wg4s_kernel.inc", "wg5p_kernel.inc",
-                 "wg3_kernel.inc"):  # = bench.KERNEL_SOURCES
-        with open(os.path.join(REPO, "learned_hologram_gan_amd", "csrc", name), "rb") as f:
+    for path in sorted(glob.glob(os.path.join(d, "*.inc")) + [os.path.join(d, "conv_engine.hip"), os.path.join(d, "common.h")]):
+        with open(path, "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
 
 
 def family(name):
+    """gg* kernels (gg, gg2, gg2b, gg3s, gg4s ...) -> "gg", wg* kernels (wg, wg2, wg2s, wg3b, wg4s, wg5p ...) -> "wg"; mangled or demangled names."""
+    import re
+
     head = name.split("(")[0]
-    if "wgrad_reduce" in head or "pack_weight" in head:
+    if "wgrad_reduce" in head or "pack_weight" in head or "thin_" in head:
         return None
-    if "gg2_kernel" in head or "gg_kernel" in head or "gg3s_kernel" in head or "gg2b_kernel" in head:
-        return "gg"
-    if "wg3_kernel" in head or "wg2_kernel" in head or "wg_kernel" in head or "wg2s_kernel" in head or "wg2b_kernel" in head:
-        return "wg"
-    return None
+    m = re.search(r"(?<![a-z_])(gg|wg)[0-9]*[a-z]{0,2}_kernel", head)
+    return m.group(1) if m else None
 
 
 def tail_mean(d, counter, frac):
@@ -55,7 +56,7 @@ res = {"command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE|WRITE_SIZE (separat
                "stream (MI355X_MICROARCH.md, HBM), hence the factor 2 on the read side",
        "git_sha": git_sha, "kernel_src_sha16": kernel_source_sha16(), "kernels": {}}
 for fam in ("gg", "wg"):
-    res["kernels"][fam] = {"launches_sampled": fe[fam][0], "fetch_kib_per_launch": round(fe[fam][1], 1),
+    res["kernels"][fam] = {"launches_sampled": fe[fam][0], "write_launches_sampled": wr[fam][0], "fetch_kib_per_launch": round(fe[fam][1], 1),
                            "write_kib_per_launch": round(wr[fam][1], 1),
                            "hbm_bytes_per_launch_corrected": int((2 * fe[fam][1] + wr[fam][1]) * 1024)}
 json.dump(res, open(out_path, "w"), indent=1)
