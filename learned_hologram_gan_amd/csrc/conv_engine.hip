@@ -1130,13 +1130,19 @@ static int launch_wg(WGParams& p, int S, hipStream_t st, const WG3Params* p3 = n
 
 static inline int pad64(int c) { return (c + 63) / 64 * 64; }
 
-// Split count for the pixel (K) axis of a weight gradient: enough workgroups to fill 256 CUs x 2-3 resident blocks a
-// few times over, assuming the largest tile the padded extents allow (the launcher autotunes the tile for that S).
+// Split count for the pixel (K) axis of a weight gradient.  Every split writes a full dW-sized slab that lhg_wgrad_reduce reads back, so S
+// is the factor by which the launch's output traffic exceeds dW itself: round 2 aimed at 1536 workgroups of the LARGEST tile the
+// extents allow (S = 6 on a 1024 -> 512 layer whose 288 tile x tap pairs already fill the chip: 113 MB of slabs for an 18.9 MB
+// gradient; 2.5 GB per train step in all, read again by the reduction).  Now the count assumes the SMALLEST tile (64 x 64: four times
+// the tile x tap pairs, the autotuner still picks the tile per geometry and S) and a target of LHG_WG_TARGET = 1024 workgroups: the
+// layers that hold most of the parameters run unsplit (S = 1: the slab IS dW) and only the narrow layers, whose gradients are small,
+// split deep.  LHG_WG_BASE_TILE=128 restores round 2's assumption for A/B measurements.
 static int pick_splits(long long pixels, int m_pad, int n_pad, int taps) {
-  const int bm = m_pad % 128 == 0 ? 128 : 64, bn = n_pad % 128 == 0 ? 128 : 64;
+  static const int base = [] { const char* e = getenv("LHG_WG_BASE_TILE"); return e && atoi(e) == 128 ? 128 : 64; }();
+  const int bm = (base == 128 && m_pad % 128 == 0) ? 128 : 64, bn = (base == 128 && n_pad % 128 == 0) ? 128 : 64;
   const long long tiles = (long long)(m_pad / bm) * (n_pad / bn) * taps;
   const long long steps = (pixels + BK - 1) / BK;
-  static const long long target = [] { const char* e = getenv("LHG_WG_TARGET"); return e ? atoll(e) : 1536ll; }();
+  static const long long target = [] { const char* e = getenv("LHG_WG_TARGET"); return e ? atoll(e) : 1024ll; }();
   long long s = (target + tiles - 1) / tiles;
   const long long cap = steps / 8 > 1 ? steps / 8 : 1;
   if (s > cap) s = cap;
