@@ -268,6 +268,23 @@ int lhg_bn_backward_backward(const float* ggx, const float* gy, const float* x, 
                              int act, float slope, float* ggy, float* gx2, float* ggamma2,
                              float* ws, lhg_stream_t s);
 
+/* Synchronised batch statistics for data-parallel replicas (the reference is single-device: a global batch of 2B on two replicas of B has
+ * to normalise over all 2B samples to reproduce it; SURVEY §5 "Distributed comm backend").  The two calls above split in halves with the
+ * per-channel sums in the caller's hands: `..._sums` writes the LOCAL sums (2*C floats: sum g, sum g*xhat; double backward 5*C floats:
+ * S_g, S_gx, S_q, S_qx, S_gq with xc = x - mean), the caller all-reduces them (and takes ggamma / gbeta from the LOCAL ones), `..._apply`
+ * finishes with inv_count = 1 / (samples behind the sums).  `stats` are the GLOBAL mean / invstd.  ws as for the unsplit calls. */
+int lhg_bn_backward_sums(const float* gy, int ldgy, const float* x, int ldx, const float* y, int ldy, long long pixels, int C,
+                         const float* stats, const float* gamma, int act, float slope, float* sums, float* ws, const float* beta,
+                         lhg_stream_t s);
+int lhg_bn_backward_apply(const float* gy, int ldgy, const float* x, int ldx, const float* y, int ldy, long long pixels, int C,
+                          const float* stats, const float* gamma, const float* sums, float inv_count, int act, float slope,
+                          float* gx, int ldgx, float* gres, int ldgres, float* gx_absmax, const float* beta, lhg_stream_t s);
+int lhg_bn_backward_backward_sums(const float* ggx, const float* gy, const float* x, const float* y, long long pixels, int C,
+                                  const float* stats, const float* gamma, int act, float slope, float* sums, float* ws, lhg_stream_t s);
+int lhg_bn_backward_backward_apply(const float* ggx, const float* gy, const float* x, const float* y, long long pixels, int C,
+                                   const float* stats, const float* gamma, const float* sums, float inv_count, int act, float slope,
+                                   float* ggy, float* gx2, float* ggamma2, lhg_stream_t s);
+
 /* ------------------------------------------------------------------ pointwise / pooling */
 /* 2x2 stride-2 max pool, NHWC.  ref: neural_network_components.py:252-268. */
 int lhg_maxpool2x2_forward(const float* x, int N, int H, int W, int C, int ldx, float* y, int ldy, lhg_stream_t s);

@@ -312,9 +312,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const T* __restrict__ gy, in
                                                     const float* __restrict__ sums, int act, float slope,
                                                     T* __restrict__ gx, int ldgx, T* __restrict__ gres, int ldgres,
                                                     float* __restrict__ ggamma, float* __restrict__ gbeta, int accumulate, int lanes_c,
-                                                    int rows, float* __restrict__ gx_amax, const float* __restrict__ beta) {
+                                                    int rows, float* __restrict__ gx_amax, const float* __restrict__ beta, float invn) {
   const int tx = threadIdx.x % lanes_c, ty = threadIdx.x / lanes_c;
-  const float invn = 1.f / (float)pixels;
   unsigned am = 0;
   const unsigned seen = amax_peek(gx_amax);
   for (int cb = (blockIdx.y * lanes_c + tx) * 4; cb < C; cb += gridDim.y * lanes_c * 4) {
@@ -392,9 +391,8 @@ __global__ __launch_bounds__(256) void bn_bwd2_apply(const T* __restrict__ ggx, 
                                                      const float* __restrict__ stats, const float* __restrict__ gamma,
                                                      const float* __restrict__ sums, int act, float slope,
                                                      T* __restrict__ ggy, T* __restrict__ gx2, float* __restrict__ ggamma2,
-                                                     int lanes_c, int rows) {
+                                                     int lanes_c, int rows, float invM) {
   const int tx = threadIdx.x % lanes_c, ty = threadIdx.x / lanes_c;
-  const float invM = 1.f / (float)pixels;
   for (int cb = (blockIdx.y * lanes_c + tx) * 4; cb < C; cb += gridDim.y * lanes_c * 4) {
     const f32x4 mean = ld4(stats + cb), r = ld4(stats + C + cb), gam = ld4(gamma + cb);
     const f32x4 Sg = ld4(sums + cb), Sgx = ld4(sums + C + cb), Sq = ld4(sums + 2 * C + cb), Sqx = ld4(sums + 3 * C + cb),
@@ -687,45 +685,60 @@ static int bn_apply_impl(const float* x, int ldx, long long pixels, int C, const
   return check_launch("bn_apply");
 }
 
+// phase 0: sums + apply (one call);  1: sums only -> `sums` (2C floats, caller's);  2: apply only from `sums`, statistics over 1/inv_count
+// samples (the GLOBAL batch when the sums were all-reduced: synchronised batch statistics)
 template <class T>
 static int bn_backward_impl(const float* gy, int ldgy, const float* x, int ldx, const float* y, int ldy, long long pixels, int C,
                             const float* stats, const float* gamma, int act, float slope, float* gx, int ldgx, float* gres, int ldgres,
-                            float* ggamma, float* gbeta, int accumulate, float* ws, float* gx_absmax, const float* beta, lhg_stream_t s) {
+                            float* ggamma, float* gbeta, int accumulate, float* ws, float* gx_absmax, const float* beta, lhg_stream_t s,
+                            int phase = 0, float* sums_io = nullptr, float inv_count = 0.f) {
   LHG_NHWC_OK(gy, C, ldgy, "bn_backward(gy)");
   LHG_NHWC_OK(x, C, ldx, "bn_backward(x)");
-  LHG_NHWC_OK(gx, C, ldgx, "bn_backward(gx)");
+  if (phase != 1) LHG_NHWC_OK(gx, C, ldgx, "bn_backward(gx)");
   if (act != LHG_ACT_NONE && y) LHG_NHWC_OK(y, C, ldy, "bn_backward(y)");
   if (act != LHG_ACT_NONE && !y)
     LHG_REQUIRE(beta != nullptr && gres == nullptr && (act == LHG_ACT_RELU || act == LHG_ACT_LEAKY),
                 "bn_backward: without y the mask is recomputed from x: needs beta, no residual, ReLU / LeakyReLU");
   if (gres) LHG_NHWC_OK(gres, C, ldgres, "bn_backward(gres)");
+  LHG_REQUIRE(phase == 0 || sums_io != nullptr, "bn_backward: the split phases need the caller's sums buffer (2*C floats)");
   const ColMap cm = col_map(C);
   const int nblk = partial_blocks(pixels, cm.gy);
-  float* sums = ws + (size_t)nblk * 2 * C;
-  hipLaunchKernelGGL((bn_bwd_partial<T>), dim3(nblk, cm.gy), dim3(256), 0, as_stream(s), as_act<T>(gy), ldgy, as_act<T>(x), ldx, as_act<T>(y), ldy, pixels, C,
-                     stats, gamma, beta, act, slope, cm.lanes_c, cm.rows, ws);
-  hipLaunchKernelGGL(reduce_partials<2>, dim3((C + 31) / 32, 2), dim3(1024), 0, as_stream(s), ws, nblk, C, sums, 0);
-  const int nb2 = grid_for((size_t)pixels, cm.rows * 4, std::max(1, 2048 / cm.gy));
-  hipLaunchKernelGGL((bn_bwd_apply<T>), dim3(nb2, cm.gy), dim3(256), 0, as_stream(s), as_act<T>(gy), ldgy, as_act<T>(x), ldx, as_act<T>(y), ldy, pixels, C, stats,
-                     gamma, sums, act, slope, as_act<T>(gx), ldgx, as_act<T>(gres), ldgres, ggamma, gbeta, accumulate, cm.lanes_c, cm.rows, gx_absmax, beta);
+  float* sums = phase == 0 ? ws + (size_t)nblk * 2 * C : sums_io;
+  if (phase != 2) {
+    hipLaunchKernelGGL((bn_bwd_partial<T>), dim3(nblk, cm.gy), dim3(256), 0, as_stream(s), as_act<T>(gy), ldgy, as_act<T>(x), ldx, as_act<T>(y), ldy, pixels, C,
+                       stats, gamma, beta, act, slope, cm.lanes_c, cm.rows, ws);
+    hipLaunchKernelGGL(reduce_partials<2>, dim3((C + 31) / 32, 2), dim3(1024), 0, as_stream(s), ws, nblk, C, sums, 0);
+  }
+  if (phase != 1) {
+    const int nb2 = grid_for((size_t)pixels, cm.rows * 4, std::max(1, 2048 / cm.gy));
+    const float invn = phase == 2 ? inv_count : 1.f / (float)pixels;
+    hipLaunchKernelGGL((bn_bwd_apply<T>), dim3(nb2, cm.gy), dim3(256), 0, as_stream(s), as_act<T>(gy), ldgy, as_act<T>(x), ldx, as_act<T>(y), ldy, pixels, C, stats,
+                       gamma, sums, act, slope, as_act<T>(gx), ldgx, as_act<T>(gres), ldgres, ggamma, gbeta, accumulate, cm.lanes_c, cm.rows, gx_absmax, beta, invn);
+  }
   return check_launch("bn_backward");
 }
 
 template <class T>
 static int bn_backward_backward_impl(const float* ggx, const float* gy, const float* x, const float* y, long long pixels, int C,
                                      const float* stats, const float* gamma, int act, float slope, float* ggy, float* gx2, float* ggamma2,
-                                     float* ws, lhg_stream_t s) {
+                                     float* ws, lhg_stream_t s, int phase = 0, float* sums_io = nullptr, float inv_count = 0.f) {
   LHG_NHWC_OK(ggx, C, C, "bn_backward_backward(ggx)");
-  LHG_REQUIRE(aligned16(gy) && aligned16(x) && aligned16(ggy) && aligned16(gx2), "bn_backward_backward: unaligned tensor");
+  LHG_REQUIRE(aligned16(gy) && aligned16(x) && (phase == 1 || (aligned16(ggy) && aligned16(gx2))), "bn_backward_backward: unaligned tensor");
+  LHG_REQUIRE(phase == 0 || sums_io != nullptr, "bn_backward_backward: the split phases need the caller's sums buffer (5*C floats)");
   const ColMap cm = col_map(C);
   const int nblk = partial_blocks(pixels, cm.gy);
-  float* sums = ws + (size_t)nblk * 5 * C;
-  hipLaunchKernelGGL((bn_bwd2_partial<T>), dim3(nblk, cm.gy), dim3(256), 0, as_stream(s), as_act<T>(ggx), as_act<T>(gy), as_act<T>(x), as_act<T>(y), pixels, C,
-                     stats, act, slope, cm.lanes_c, cm.rows, ws);
-  hipLaunchKernelGGL(reduce_partials<5>, dim3((C + 31) / 32, 5), dim3(1024), 0, as_stream(s), ws, nblk, C, sums, 0);
-  const int nb2 = grid_for((size_t)pixels, cm.rows * 4, std::max(1, 4096 / cm.gy));
-  hipLaunchKernelGGL((bn_bwd2_apply<T>), dim3(nb2, cm.gy), dim3(256), 0, as_stream(s), as_act<T>(ggx), as_act<T>(gy), as_act<T>(x), as_act<T>(y), pixels, C, stats,
-                     gamma, sums, act, slope, as_act<T>(ggy), as_act<T>(gx2), ggamma2, cm.lanes_c, cm.rows);
+  float* sums = phase == 0 ? ws + (size_t)nblk * 5 * C : sums_io;
+  if (phase != 2) {
+    hipLaunchKernelGGL((bn_bwd2_partial<T>), dim3(nblk, cm.gy), dim3(256), 0, as_stream(s), as_act<T>(ggx), as_act<T>(gy), as_act<T>(x), as_act<T>(y), pixels, C,
+                       stats, act, slope, cm.lanes_c, cm.rows, ws);
+    hipLaunchKernelGGL(reduce_partials<5>, dim3((C + 31) / 32, 5), dim3(1024), 0, as_stream(s), ws, nblk, C, sums, 0);
+  }
+  if (phase != 1) {
+    const int nb2 = grid_for((size_t)pixels, cm.rows * 4, std::max(1, 4096 / cm.gy));
+    const float invM = phase == 2 ? inv_count : 1.f / (float)pixels;
+    hipLaunchKernelGGL((bn_bwd2_apply<T>), dim3(nb2, cm.gy), dim3(256), 0, as_stream(s), as_act<T>(ggx), as_act<T>(gy), as_act<T>(x), as_act<T>(y), pixels, C, stats,
+                       gamma, sums, act, slope, as_act<T>(ggy), as_act<T>(gx2), ggamma2, cm.lanes_c, cm.rows, invM);
+  }
   return check_launch("bn_backward_backward");
 }
 
@@ -809,6 +822,31 @@ int lhg_bn_backward_backward(const float* ggx, const float* gy, const float* x, 
                              const float* stats, const float* gamma, int act, float slope, float* ggy, float* gx2, float* ggamma2,
                              float* ws, lhg_stream_t s) {
   return LHG_ACT_CALL(bn_backward_backward_impl, ggx, gy, x, y, pixels, C, stats, gamma, act, slope, ggy, gx2, ggamma2, ws, s);
+}
+// ---- synchronised batch statistics (data-parallel replicas normalising over the GLOBAL batch): the two halves of the calls above, with the
+// per-channel sums in the caller's hands in between (all-reduce them, then apply with inv_count = 1 / global sample count)
+int lhg_bn_backward_sums(const float* gy, int ldgy, const float* x, int ldx, const float* y, int ldy, long long pixels, int C,
+                         const float* stats, const float* gamma, int act, float slope, float* sums, float* ws, const float* beta, lhg_stream_t s) {
+  return LHG_ACT_CALL(bn_backward_impl, gy, ldgy, x, ldx, y, ldy, pixels, C, stats, gamma, act, slope, nullptr, C, nullptr, C, nullptr, nullptr, 0, ws,
+                      nullptr, beta, s, 1, sums, 0.f);
+}
+int lhg_bn_backward_apply(const float* gy, int ldgy, const float* x, int ldx, const float* y, int ldy, long long pixels, int C,
+                          const float* stats, const float* gamma, const float* sums, float inv_count, int act, float slope, float* gx, int ldgx,
+                          float* gres, int ldgres, float* gx_absmax, const float* beta, lhg_stream_t s) {
+  LHG_REQUIRE(inv_count > 0.f, "bn_backward_apply: inv_count must be 1 / (samples behind the sums)");
+  return LHG_ACT_CALL(bn_backward_impl, gy, ldgy, x, ldx, y, ldy, pixels, C, stats, gamma, act, slope, gx, ldgx, gres, ldgres, nullptr, nullptr, 0, nullptr,
+                      gx_absmax, beta, s, 2, const_cast<float*>(sums), inv_count);
+}
+int lhg_bn_backward_backward_sums(const float* ggx, const float* gy, const float* x, const float* y, long long pixels, int C,
+                                  const float* stats, const float* gamma, int act, float slope, float* sums, float* ws, lhg_stream_t s) {
+  return LHG_ACT_CALL(bn_backward_backward_impl, ggx, gy, x, y, pixels, C, stats, gamma, act, slope, nullptr, nullptr, nullptr, ws, s, 1, sums, 0.f);
+}
+int lhg_bn_backward_backward_apply(const float* ggx, const float* gy, const float* x, const float* y, long long pixels, int C,
+                                   const float* stats, const float* gamma, const float* sums, float inv_count, int act, float slope,
+                                   float* ggy, float* gx2, float* ggamma2, lhg_stream_t s) {
+  LHG_REQUIRE(inv_count > 0.f, "bn_backward_backward_apply: inv_count must be 1 / (samples behind the sums)");
+  return LHG_ACT_CALL(bn_backward_backward_impl, ggx, gy, x, y, pixels, C, stats, gamma, act, slope, ggy, gx2, ggamma2, nullptr, s, 2,
+                      const_cast<float*>(sums), inv_count);
 }
 int lhg_maxpool2x2_forward(const float* x, int N, int H, int W, int C, int ldx, float* y, int ldy, lhg_stream_t s) {
   return LHG_ACT_CALL(maxpool_fwd_impl, x, N, H, W, C, ldx, y, ldy, s);

@@ -1069,6 +1069,55 @@ class ConvBiasActFn(TrackedFunction):
         return gx, gw, gb, None, None, None
 
 
+# --------------------------------------------------------------------------- synchronised batch statistics (data-parallel replicas)
+# The reference is single-device: at a global batch of W x B it normalises every train-mode BatchNorm over all W x B samples, takes the
+# focal loss's two max normalisers over the whole batch and the TV difference of whole-batch means (neural_network_components.py:23-24,
+# loss_func.py:94-98, 152-157).  Replicas of B samples each reproduce that only if those statistics are all-reduced:
+# ``set_sync_batch_stats(True)`` (watermelon.configure(sync_batch_stats=True)) switches every BatchNorm of the op layer and
+# poh_ops.ReconLossFn to global-batch statistics when torch.distributed is initialised with more than one rank.  Per BatchNorm layer that
+# is one small all-reduce in forward (mean, E[x^2]), one in backward (sum g, sum g xhat) and one in the double backward (five sums);
+# parameter gradients stay LOCAL sums (the gradient all-reduce averages them), as in torch.nn.SyncBatchNorm.
+_SYNC_STATS = False
+
+
+def set_sync_batch_stats(on: bool) -> None:
+    global _SYNC_STATS
+    _SYNC_STATS = bool(on)
+
+
+def sync_world() -> int:
+    """Ranks whose batches are normalised together (1: per-replica statistics)."""
+    if not _SYNC_STATS:
+        return 1
+    import torch.distributed as dist
+
+    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+
+
+def all_reduce_(t, op="sum"):
+    import torch.distributed as dist
+
+    dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
+    return t
+
+
+def _global_batch_stats(stats, Cc, pixels, world, running_mean, running_var):
+    """Local (mean, invstd) -> global ones in place: the replicas hold equal sample counts, so mean = avg(mean_r) and
+    E[x^2] = avg(var_r + mean_r^2); combined in float64 (var = E[x^2] - mean^2 cancels).  Running statistics as nn.BatchNorm2d keeps them."""
+    mean_l = stats[:Cc].double()
+    var_l = stats[Cc:].double().pow(-2) - BN_EPS
+    buf = torch.stack((mean_l, var_l + mean_l * mean_l))
+    all_reduce_(buf).div_(world)
+    mean, var = buf[0], (buf[1] - buf[0] * buf[0]).clamp_min_(0)
+    stats[:Cc] = mean.float()
+    stats[Cc:] = (var + BN_EPS).rsqrt().float()
+    n = float(pixels * world)
+    if running_mean is not None:
+        running_mean.mul_(1 - BN_MOMENTUM).add_(mean.float(), alpha=BN_MOMENTUM)
+    if running_var is not None:
+        running_var.mul_(1 - BN_MOMENTUM).add_((var * (n / max(n - 1, 1))).float(), alpha=BN_MOMENTUM)
+
+
 # --------------------------------------------------------------------------- batch norm
 def _bn_ws(Cc, device, mult=8192):
     return torch.empty((mult * Cc,), dtype=torch.float32, device=device)
@@ -1084,8 +1133,14 @@ class BatchNormTrainFn(TrackedFunction):
         px, N, H, W, Cc, ldx = nhwc(x)
         pixels = N * H * W
         stats = torch.empty((2 * Cc,), dtype=torch.float32, device=x.device)
-        call("lhg_bn_stats", px, pixels, Cc, ldx, ptr(stats), ptr(running_mean), ptr(running_var), BN_MOMENTUM, BN_EPS,
-             ptr(_bn_ws(Cc, x.device, 4104)), stream_ptr())
+        world = sync_world()
+        ctx.world = world
+        if world > 1:  # statistics over the global batch
+            call("lhg_bn_stats", px, pixels, Cc, ldx, ptr(stats), None, None, BN_MOMENTUM, BN_EPS, ptr(_bn_ws(Cc, x.device, 4104)), stream_ptr())
+            _global_batch_stats(stats, Cc, pixels, world, running_mean, running_var)
+        else:
+            call("lhg_bn_stats", px, pixels, Cc, ldx, ptr(stats), ptr(running_mean), ptr(running_var), BN_MOMENTUM, BN_EPS,
+                 ptr(_bn_ws(Cc, x.device, 4104)), stream_ptr())
         y = _resolve_out(out, (N, H, W, Cc), x.device)
         py, _, _, _, _, ldy = nhwc(y)
         pres, ldres = (None, 0)
@@ -1111,17 +1166,18 @@ class BatchNormTrainFn(TrackedFunction):
         s_beta = _small_grad_slot(ctx.beta)
         if s_gamma is not None and s_beta is not None and param_grads_wanted():
             # plain backward into the flat gradient buffer: the kernel adds d gamma / d beta to their slots itself
-            gx, gres = bn_backward_raw(gy, x, y, gamma, stats, ctx.act, ctx.slope, ctx.has_res, s_gamma, s_beta, True, ctx.beta_value)
+            gx, gres = bn_backward_raw(gy, x, y, gamma, stats, ctx.act, ctx.slope, ctx.has_res, s_gamma, s_beta, True, ctx.beta_value, ctx.world)
             note_contribution(gamma)
             note_contribution(ctx.beta)
             return gx, None, None, None, None, (gres if ctx.has_res else None), None, None, None
-        gx, gres, ggamma, gbeta = BatchNormGradFn.apply(gy, x, y, gamma, stats, ctx.act, ctx.slope, ctx.has_res)
+        gx, gres, ggamma, gbeta = BatchNormGradFn.apply(gy, x, y, gamma, stats, ctx.act, ctx.slope, ctx.has_res, ctx.world)
         return gx, ggamma, gbeta, None, None, (gres if ctx.has_res else None), None, None, None
 
 
-def bn_backward_raw(gy, x, y, gamma, stats, act, slope, want_res, ggamma, gbeta, accumulate, beta=None):
+def bn_backward_raw(gy, x, y, gamma, stats, act, slope, want_res, ggamma, gbeta, accumulate, beta=None, world=1):
     """lhg_bn_backward; ggamma / gbeta are written (or, with ``accumulate``, added to).  Returns (gx, gres).  With ``beta`` (and no
-    residual, ReLU / LeakyReLU) the kernels recompute the activation mask from x instead of reading y."""
+    residual, ReLU / LeakyReLU) the kernels recompute the activation mask from x instead of reading y.  ``world`` > 1: `stats` are
+    global-batch statistics — the two per-channel sums are all-reduced between the kernel's halves, ggamma / gbeta take the LOCAL sums."""
     pg, N, H, W, Cc, ldg = nhwc(gy)
     px, _, _, _, _, ldx = nhwc(x)
     py, _, _, _, _, ldy = nhwc(y)
@@ -1130,6 +1186,18 @@ def bn_backward_raw(gy, x, y, gamma, stats, act, slope, want_res, ggamma, gbeta,
     gx = new_nhwc(N, H, W, Cc, gy.device)
     gres = new_nhwc(N, H, W, Cc, gy.device) if want_res else None
     gx_amax = fused_absmax_slot(gy.device)  # gx is the gy of the preceding conv's two backward GEMMs
+    if world > 1:
+        sums = torch.empty((2 * Cc,), dtype=torch.float32, device=gy.device)
+        call("lhg_bn_backward_sums", pg, ldg, px, ldx, py, ldy, N * H * W, Cc, ptr(stats), ptr(gamma), act, float(slope), ptr(sums),
+             ptr(_bn_ws(Cc, gy.device)), ptr(beta), stream_ptr())
+        for dst, local in ((gbeta, sums[:Cc]), (ggamma, sums[Cc:])):  # parameter gradients: this replica's samples only
+            if dst is not None:
+                dst.add_(local) if accumulate else dst.copy_(local)
+        all_reduce_(sums)
+        call("lhg_bn_backward_apply", pg, ldg, px, ldx, py, ldy, N * H * W, Cc, ptr(stats), ptr(gamma), ptr(sums), 1.0 / float(N * H * W * world),
+             act, float(slope), ptr(gx), Cc, ptr(gres), Cc, ptr(gx_amax), ptr(beta), stream_ptr())
+        tag_absmax(gx, gx_amax)
+        return gx, gres
     call("lhg_bn_backward", pg, ldg, px, ldx, py, ldy, N * H * W, Cc, ptr(stats), ptr(gamma), act, float(slope),
          ptr(gx), Cc, ptr(gres), Cc, ptr(ggamma), ptr(gbeta), int(accumulate), ptr(_bn_ws(Cc, gy.device)), ptr(gx_amax), ptr(beta),
          stream_ptr())
@@ -1146,15 +1214,15 @@ class BatchNormGradFn(TrackedFunction):
     launched (distributed.GradSynchronizer) between the two."""
 
     @staticmethod
-    def forward(ctx, gy, x, y, gamma, stats, act, slope, want_res):
+    def forward(ctx, gy, x, y, gamma, stats, act, slope, want_res, world=1):
         Cc = gy.shape[-1]
         ctx.gamma = gamma if ctx.needs_input_grad[3] else None
         note_use(ctx.gamma)
         ggamma = torch.empty((Cc,), dtype=torch.float32, device=gy.device)
         gbeta = torch.empty((Cc,), dtype=torch.float32, device=gy.device)
-        gx, gres = bn_backward_raw(gy, x, y, gamma, stats, act, slope, want_res, ggamma, gbeta, False)
+        gx, gres = bn_backward_raw(gy, x, y, gamma, stats, act, slope, want_res, ggamma, gbeta, False, None, world)
         ctx.save_for_backward(gy, x, y, gamma, stats)
-        ctx.act, ctx.slope, ctx.want_res = act, slope, want_res
+        ctx.act, ctx.slope, ctx.want_res, ctx.world = act, slope, want_res, world
         ctx.set_materialize_grads(False)
         if gres is None:
             gres = torch.empty(0, device=gy.device)
@@ -1167,26 +1235,39 @@ class BatchNormGradFn(TrackedFunction):
         if ggres is not None or gggamma is not None or ggbeta is not None:
             raise NotImplementedError("double backward through the residual / gamma / beta gradients of batch norm "
                                       "is not part of the hot path (the gradient penalty differentiates d/dx only)")
+        nothing = (None,) * 9
         if ggx is None:
             if param_grads_wanted() and _small_grad_slot(ctx.gamma) is not None:
                 note_contribution(ctx.gamma)  # a zero contribution still answers the recorded use
-            return None, None, None, None, None, None, None, None
+            return nothing
         N, H, W, Cc = x.shape
         pixels = N * H * W
         ggx_d, gy_d, x_d, y_d = _dense(ggx), _dense(gy), _dense(x), _dense(y)
         ggy = new_nhwc(N, H, W, Cc, x.device)
         gx2 = new_nhwc(N, H, W, Cc, x.device)
         ggamma2 = torch.empty((Cc,), dtype=torch.float32, device=x.device)
-        call("lhg_bn_backward_backward", ptr(ggx_d), ptr(gy_d), ptr(x_d), ptr(y_d), pixels, Cc, ptr(stats), ptr(gamma),
-             ctx.act, float(ctx.slope), ptr(ggy), ptr(gx2), ptr(ggamma2), ptr(_bn_ws(Cc, x.device, 5 * 4096 + 8)), stream_ptr())
+        ws = _bn_ws(Cc, x.device, 5 * 4096 + 8)
+        if ctx.world > 1:  # global-batch statistics: the five sums are all-reduced between the kernel's halves
+            sums = torch.empty((5 * Cc,), dtype=torch.float32, device=x.device)
+            call("lhg_bn_backward_backward_sums", ptr(ggx_d), ptr(gy_d), ptr(x_d), ptr(y_d), pixels, Cc, ptr(stats), ptr(gamma), ctx.act,
+                 float(ctx.slope), ptr(sums), ptr(ws), stream_ptr())
+            all_reduce_(sums)
+            call("lhg_bn_backward_backward_apply", ptr(ggx_d), ptr(gy_d), ptr(x_d), ptr(y_d), pixels, Cc, ptr(stats), ptr(gamma), ptr(sums),
+                 1.0 / float(pixels * ctx.world), ctx.act, float(ctx.slope), ptr(ggy), ptr(gx2), ptr(ggamma2), stream_ptr())
+            # every term of d/d gamma is linear in ggx, whose scale is this replica's loss (W times the global-batch loss's): the
+            # formula over the GLOBAL sums is W times the global-batch gradient on every rank; its share here is 1/W of it
+            ggamma2.div_(ctx.world)
+        else:
+            call("lhg_bn_backward_backward", ptr(ggx_d), ptr(gy_d), ptr(x_d), ptr(y_d), pixels, Cc, ptr(stats), ptr(gamma),
+                 ctx.act, float(ctx.slope), ptr(ggy), ptr(gx2), ptr(ggamma2), ptr(ws), stream_ptr())
         if not param_grads_wanted():
-            return ggy, gx2, None, None, None, None, None, None
+            return (ggy, gx2) + nothing[2:]
         slot = _small_grad_slot(ctx.gamma)
         if slot is not None:  # plain backward into the flat buffer: same delivery as BatchNormTrainFn.backward's d gamma
             slot.add_(ggamma2)
             note_contribution(ctx.gamma)
-            return ggy, gx2, None, None, None, None, None, None
-        return ggy, gx2, None, ggamma2, None, None, None, None
+            return (ggy, gx2) + nothing[2:]
+        return (ggy, gx2, None, ggamma2) + nothing[4:]
 
 
 def batch_norm_eval_affine(gamma, beta, running_mean, running_var):

@@ -76,6 +76,10 @@ _SIGNATURES = {
     "lhg_bn_apply": [_p, _i, _ll, _i, _p, _p, _p, _p, _i, _i, _f, _p, _i, _p, _p],
     "lhg_bn_backward": [_p, _i, _p, _i, _p, _i, _ll, _i, _p, _p, _i, _f, _p, _i, _p, _i, _p, _p, _i, _p, _p, _p, _p],
     "lhg_bn_backward_backward": [_p, _p, _p, _p, _ll, _i, _p, _p, _i, _f, _p, _p, _p, _p, _p],
+    "lhg_bn_backward_sums": [_p, _i, _p, _i, _p, _i, _ll, _i, _p, _p, _i, _f, _p, _p, _p, _p],
+    "lhg_bn_backward_apply": [_p, _i, _p, _i, _p, _i, _ll, _i, _p, _p, _p, _f, _i, _f, _p, _i, _p, _i, _p, _p, _p],
+    "lhg_bn_backward_backward_sums": [_p, _p, _p, _p, _ll, _i, _p, _p, _i, _f, _p, _p, _p],
+    "lhg_bn_backward_backward_apply": [_p, _p, _p, _p, _ll, _i, _p, _p, _p, _f, _i, _f, _p, _p, _p, _p],
     "lhg_maxpool2x2_forward": [_p, _i, _i, _i, _i, _i, _p, _i, _p],
     "lhg_maxpool2x2_backward": [_p, _i, _p, _i, _i, _i, _i, _i, _p, _i, _p],
     "lhg_act_backward": [_p, _i, _p, _i, _ll, _i, _i, _f, _p, _i, _p],

@@ -69,6 +69,26 @@ class ReconLossFn(Function):
         losses = torch.empty((3,), dtype=torch.float32, device=ha.device)
         ws = torch.empty((nblk * 9,), dtype=torch.float32, device=ha.device)
         call("lhg_recon_loss_forward", ptr(ha), ptr(ta), ptr(hp), ptr(tp), planes, H, W, ptr(sums), ptr(losses), ptr(ws), stream_ptr())
+        from . import hip_ops
+
+        world = hip_ops.sync_world()
+        if world > 1:
+            # Global-batch normalisers (hip_ops.set_sync_batch_stats): the focal loss divides by the WHOLE batch's max |difference| (loss_func.py:
+            # 152-157) and the TV term is |TV(hat) - TV(target)| of whole-batch means (:94-98).  Per replica: local sums over the global max, and
+            # sign(global TV difference) x the local TV difference — their mean over the replicas is the single-device loss, and so are the
+            # gradients after the gradient all-reduce.  sums[1], sums[3] <- global max; sums[5:9] <- global means (the backward kernel takes
+            # the sign from them); the reported TV value is the global one.
+            mx = sums[[1, 3]].contiguous()
+            hip_ops.all_reduce_(mx, "max")
+            a_w, a_h = float(planes * H * (W - 1)), float(planes * (H - 1) * W)
+            tvg = sums[5:9].clone()
+            hip_ops.all_reduce_(tvg).div_(world)
+            sums[1], sums[3] = mx[0], mx[1]
+            sums[5:9] = tvg
+            s64 = sums.double()
+            n_w, n_h = 2.0 * a_w, 2.0 * a_h
+            tv_global = (s64[5] / a_w + s64[6] / a_h) - (s64[7] / a_w + s64[8] / a_h)
+            losses = torch.stack((s64[0] / (n_w * s64[1]) + s64[2] / (n_h * s64[3]), s64[4] / float(planes * H * W), tv_global.abs())).float()
         ctx.save_for_backward(ha, ta, hp, tp, sums)
         return losses
 

@@ -6,7 +6,8 @@ the parity tests drive exactly what ``train`` runs.  Differences that are delibe
   * hat / target planes come from one fused propagation each (no (2B,3,R,C) spectra in HBM);
   * both Adam updates are single fused launches over flat parameter buffers;
   * with torch.distributed initialised, gradients are averaged across ranks (RCCL) with
-    bucketed all-reduces overlapped with backward; BN / loss normalisers stay per replica.
+    bucketed all-reduces overlapped with backward; BN statistics / loss normalisers are per replica, or over
+    the global batch with ``configure(sync_batch_stats=True)`` (W replicas of B == the reference at W x B).
 The VGG19 perceptual term (loss_func.py:12-51) is ``perceptual.perceptualLoss``; it needs a local weights
 file, so the trainer takes it as a constructor argument and ``perceptual_loss_weight`` must be 0 without one.
 """
@@ -107,7 +108,12 @@ class watermelon:
     # ------------------------------------------------------------------ configuration of one run
     def configure(self, phs_gradient_loss_weight=1, perceptual_loss_weight=1.0, pixel_loss_weight=1.0, TV_loss_weight=1e-3,
                   discriminator_loss_weight=1.0, lr_G=1e-3, lr_D=1e-3, discriminator_train_ratio=2, discriminator_lambda=10,
-                  grad_buckets=4):
+                  grad_buckets=4, sync_batch_stats=False):
+        """``sync_batch_stats`` (data-parallel runs): normalise every train-mode BatchNorm, the focal loss's max normalisers and the TV
+        means over the GLOBAL batch (all-reduced statistics, hip_ops.set_sync_batch_stats) — W replicas of B samples then reproduce the
+        reference's single-device step at batch W x B (ref: neural_network_components.py:23-24, loss_func.py:94-98, 152-157).  Off
+        (default): those statistics are per replica, which at one sample per replica (BASELINE configs[4]: bs=8 over 8 GPUs) is a
+        different model from the reference's."""
         if perceptual_loss_weight and not self._has_perceptual:
             raise ValueError("perceptual_loss_weight != 0 needs a perceptual module: construct the trainer with "
                              "perceptual_loss=perceptualLoss(weights_path=...) (watermelon_hologram/perceptual.py)")
@@ -115,6 +121,7 @@ class watermelon:
         self.pixel_loss_weight, self.TV_loss_weight = pixel_loss_weight, TV_loss_weight
         self.discriminator_loss_weight = discriminator_loss_weight
         self.discriminator_train_ratio, self.discriminator_lambda = discriminator_train_ratio, discriminator_lambda
+        hip_ops.set_sync_batch_stats(sync_batch_stats)
         self.generator.to(self.device)
         flat_G = FlatParams(self.generator)
         broadcast_module_state(self.generator, flat_G.data)  # data-parallel replicas start from rank 0's weights

@@ -928,6 +928,19 @@ def test_critic_step_with_gradient_penalty_two_ranks():
     assert out[0]["D"]["launch_log"] == out[1]["D"]["launch_log"] and out[0]["G"]["launch_log"] == out[1]["G"]["launch_log"]
 
 
+def test_sync_batch_stats_two_ranks_equal_one_process_at_twice_the_batch():
+    """configure(sync_batch_stats=True): 2 ranks x 2 samples (sharing this GPU over gloo) against one process at 4 samples — the full
+    step with the critic's gradient penalty.  Global BatchNorm statistics in forward, backward and double backward, the focal loss's
+    global max normalisers and the global TV means make the averaged gradients of both models, the reconstructions, the losses and the
+    running statistics those of the single process (ref: the single-device step, watermelon.py:207-277; loss_func.py:94-98, 152-157)."""
+    out = {r["rank"]: r for r in _run_dist_worker("syncbn", 2)}
+    r0 = out[0]
+    assert r0["hat_err"] < 2e-5 and r0["bn_err"] < 1e-5, r0
+    assert r0["g_err"] < 2e-3 and r0["d_err"] < 2e-3, r0  # gradients behind 18 / 5 train-mode BatchNorm backwards (test_gpu_truth.py: ill conditioned)
+    for got, want in zip(r0["losses"], r0["ref_losses"]):
+        assert abs(got - want) <= 2e-4 * abs(want) + 1e-7, r0
+
+
 def test_train_step_repeats_bit_for_bit():
     """One process, one GPU: the same step on the same weights and data gives bit-identical losses, holograms, reconstructions and
     gradients three times in a row — with the weight-gradient GEMMs on the second stream, and with the caching allocator's free blocks
