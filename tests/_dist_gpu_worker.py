@@ -75,8 +75,20 @@ def overlap():
                 again = W.propagator.reconstruct_planes(W.generator.part2.propagator, out["POH"], x[1], x[2], idx)[0]
                 if not torch.equal(again, out["hat_amps"]):
                     d = (again - out["hat_amps"]).abs()
-                    notes.append({"pass": len(fwd) - 1, "recompute": k, "elements": int((d > 0).sum()), "max_abs": float(d.max()),
-                                  "where": torch.nonzero(d > 0)[:4].tolist()})
+                    nz = torch.nonzero(d > 0)
+                    note = {"pass": len(fwd) - 1, "recompute": k, "elements": int((d > 0).sum()), "max_abs": float(d.max()),
+                            "where": nz[:4].tolist()}
+                    if k == 0:  # the SHAPE of the damage and what the differing values look like: which buffer / kernel granularity it matches
+                        tgt = out["target_amps"]
+                        note.update(planes=sorted({(int(a), int(b)) for a, b in nz[:, :2].tolist()}), rows=sorted(set(nz[:, 2].tolist())),
+                                    cols=[int(nz[:, 3].min()), int(nz[:, 3].max()), len(set(nz[:, 3].tolist()))],
+                                    flat_offset_bytes=int((((nz[0, 0] * 3 + nz[0, 1]) * rows + nz[0, 2]) * cols + nz[0, 3]) * 4),
+                                    data_ptr_mod_2MiB=int(out["hat_amps"].data_ptr() % (1 << 21)),
+                                    samples=[{"at": p, "step": float(out["hat_amps"][tuple(p)]), "again": float(again[tuple(p)]),
+                                              "target": float(tgt[tuple(p)])} for p in nz[:: max(1, len(nz) // 6)][:6].tolist()],
+                                    step_equals_target_there=bool(torch.equal(out["hat_amps"][d > 0], tgt[d > 0])),
+                                    finite=bool(torch.isfinite(out["hat_amps"]).all()))
+                    notes.append(note)
 
     def asm_probe(poh, reps=200):
         """Localise a non-repeating reconstruction: the fused operator (three kernels per call) and its two halves — to_spectrum (row
@@ -240,9 +252,11 @@ def syncbn():
         torch.cuda.synchronize()
         bn = torch.cat([b.detach().flatten().float() for n, b in list(W.generator.named_buffers()) + list(W.discriminator.named_buffers())
                         if n.endswith(("running_mean", "running_var"))])
-        return out, grads, W.train_losses_tensor.detach().clone(), bn
+        names = {"G": [(n, p_.numel()) for n, p_ in zip([k for k, _ in W.generator.named_parameters()], W._opt_G.flat.params)],
+                 "D": [(n, p_.numel()) for n, p_ in zip([k for k, _ in W.discriminator.named_parameters()], W._opt_D.flat.params)]}
+        return out, grads, W.train_losses_tensor.detach().clone(), bn, names
 
-    out, grads, losses, bn = run(data[rank], idxs[rank], alphas[rank], True)
+    out, grads, losses, bn, names = run(data[rank], idxs[rank], alphas[rank], True)
     res = {"rank": rank}
     gathered = [torch.empty_like(losses) for _ in range(world)]
     dist.all_gather(gathered, losses)
@@ -251,11 +265,47 @@ def syncbn():
     hip_ops.set_sync_batch_stats(False)
     # (every rank runs the reference: configure() broadcasts rank 0's weights, a collective all ranks must enter)
     cat = tuple(torch.cat([data[r][k] for r in range(world)], 0) for k in range(3))
-    ref_out, ref_grads, ref_losses, ref_bn = run(cat, torch.cat(idxs), torch.cat(alphas), False)
+    ref_out, ref_grads, ref_losses, ref_bn, _ = run(cat, torch.cat(idxs), torch.cat(alphas), False)
+    # Both ranks have just computed the SAME single-process step (same weights, same data, no collective inside it) concurrently on this
+    # GPU: their results must agree bit for bit.  When they do not (the unexplained two-process non-repeat of DESIGN.md §5) the record
+    # says which tensor differs first along the step, the shape of the damage and which rank a fresh evaluation sides with.
+    agree = {}
+    for key in ("POH", "hat_amps", "target_amps"):
+        both = [torch.empty_like(ref_out[key]) for _ in range(world)]
+        dist.all_gather(both, ref_out[key].contiguous())
+        same = bool(torch.equal(both[0], both[1]))
+        agree[key] = same
+        if not same:
+            d = (both[0] - both[1]).abs()
+            nz = torch.nonzero(d > 0)
+            info = {"elements": int(len(nz)), "max_abs": float(d.max()), "planes": sorted({(int(a), int(b)) for a, b in nz[:, :2].tolist()}),
+                    "rows": sorted(set(nz[:, 2].tolist())), "cols": [int(nz[:, 3].min()), int(nz[:, 3].max()), len(set(nz[:, 3].tolist()))],
+                    "samples": [{"at": q, "rank0": float(both[0][tuple(q)]), "rank1": float(both[1][tuple(q)])} for q in nz[:: max(1, len(nz) // 6)][:6].tolist()]}
+            if key == "hat_amps":  # arbiter: the reconstruction evaluated again from rank 0's hologram
+                with torch.no_grad():
+                    W2 = watermelon(filter_radius_coefficient=0.45, pad_size=32, distance_stack=stack, input_shape=(1, 4, rows, cols))
+                    again = W2.propagator.reconstruct_planes(W2.generator.part2.propagator, both[0].new_tensor(0) + ref_out["POH"], cat[1].to(dev), cat[2].to(dev), torch.cat(idxs))[0]
+                info["fresh_evaluation_equals"] = {"rank0": bool(torch.equal(again, both[0])), "rank1": bool(torch.equal(again, both[1]))}
+            agree[key + "_damage"] = info
+    for m in ("G", "D"):
+        both = [torch.empty_like(ref_grads[m]) for _ in range(world)]
+        dist.all_gather(both, ref_grads[m])
+        agree["grads_" + m] = bool(torch.equal(both[0], both[1]))
+    res["single_process_step_agrees_between_ranks"] = agree
     if rank == 0:
         l2 = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-300)).item()  # noqa: E731
         mean_losses = sum(gathered) / world
         # the TV value every rank reports under sync is already the global one; the other terms average over the ranks
+        worst = {}
+        for m in ("G", "D"):  # which parameters carry the difference (a wrong normaliser shows as a whole family off by a factor)
+            o, rows_ = 0, []
+            for n, k in names[m]:
+                a, b = grads[m][o:o + k], ref_grads[m][o:o + k]
+                o += k
+                if b.norm() > 0:
+                    rows_.append((n, round(l2(a, b), 6), round((a.norm() / b.norm()).item(), 5)))
+            worst[m] = sorted(rows_, key=lambda t: -t[1])[:6]
+        res.update(worst=worst)
         res.update(g_err=l2(grads["G"], ref_grads["G"]), d_err=l2(grads["D"], ref_grads["D"]), bn_err=l2(bn, ref_bn),
                    hat_err=l2(torch.cat(hat, 0), ref_out["hat_amps"]), losses=mean_losses.tolist(), ref_losses=ref_losses.tolist())
     print(json.dumps(res), flush=True)
@@ -263,5 +313,75 @@ def syncbn():
     dist.destroy_process_group()
 
 
+def syncops():
+    """The synchronised operators one by one, where the comparison is well conditioned: a train-mode BatchNorm with its backward and
+    its double backward (the gradient penalty's pattern) and the reconstruction losses, two ranks x half the batch against one process
+    on the whole batch.  Per-rank loss = mean over the rank's samples, so input gradients must come out W times the single process's,
+    parameter gradients average to it, outputs and loss values match."""
+    from learned_hologram_gan_amd import distributed, hip_ops
+    from learned_hologram_gan_amd.poh_ops import ReconLossFn
+
+    rank, world, _ = distributed.init_from_env("gloo")
+    dev = "cuda:0"
+    g = torch.Generator().manual_seed(77)
+    N, H, Wd, C = 4, 12, 10, 64
+    x_all = (torch.randn((N, H, Wd, C), generator=g) * torch.linspace(0.2, 3.0, C) + torch.linspace(-2, 2, C)).to(dev)
+    p1_all, p2_all = torch.randn((N, H, Wd, C), generator=g).to(dev), torch.randn((N, H, Wd, C), generator=g).to(dev)
+    gamma0, beta0 = (torch.rand(C, generator=g) + 0.5).to(dev), torch.randn(C, generator=g).to(dev)
+    l2 = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-300)).item()  # noqa: E731
+
+    def bn_case(x, p1, p2, act, sync):
+        hip_ops.set_sync_batch_stats(sync)
+        x = x.clone().requires_grad_(True)
+        gamma, beta = gamma0.clone().requires_grad_(True), beta0.clone().requires_grad_(True)
+        rm, rv = torch.zeros(C, device=dev), torch.ones(C, device=dev)
+        y = hip_ops.BatchNormTrainFn.apply(x, gamma, beta, rm, rv, None, act, 0.2, None)
+        (gx,) = torch.autograd.grad((y * p1).sum(), x, create_graph=True)       # first backward, differentiable (the penalty's inner grad)
+        n_local = x.shape[0]
+        loss = ((gx * gx).sum() + (y * p2).sum()) / n_local                        # second-order term + a first-order term
+        loss.backward()
+        return y.detach(), gx.detach(), x.grad, gamma.grad, beta.grad, rm, rv, loss.detach()
+
+    res = {"rank": rank}
+    half = slice(rank * N // world, (rank + 1) * N // world)
+    for act, tag in ((hip_ops.ACT_NONE, "bn"), (hip_ops.ACT_LEAKY, "bn_leaky")):
+        y, gx, dx, dg, db, rm, rv, loss = bn_case(x_all[half], p1_all[half], p2_all[half], act, True)
+        for t in (dg, db):
+            dist.all_reduce(t)
+            t /= world
+        lsum = loss.clone()
+        dist.all_reduce(lsum)
+        Y, GX, DX, DG, DB, RM, RV, LOSS = bn_case(x_all, p1_all, p2_all, act, False)
+        res[tag] = dict(y=l2(y, Y[half]), gx=l2(gx, GX[half]), dx=l2(dx, world * DX[half]), dgamma=l2(dg, DG), dbeta=l2(db, DB), run_mean=l2(rm, RM),
+                        run_var=l2(rv, RV), loss=abs(float(lsum / world) - float(LOSS)) / abs(float(LOSS)))
+
+    # reconstruction losses
+    B, Hh, Ww = 4, 24, 20
+    ha, ta = torch.rand((B, 3, Hh, Ww), generator=g).to(dev), torch.rand((B, 3, Hh, Ww), generator=g).to(dev)
+    hp, tp = (6.28 * torch.rand((B, 3, Hh, Ww), generator=g)).to(dev), (6.28 * torch.rand((B, 3, Hh, Ww), generator=g)).to(dev)
+    wts = torch.tensor([1.0, 0.7, 0.3], device=dev)
+
+    def loss_case(sl, sync):
+        hip_ops.set_sync_batch_stats(sync)
+        a, p_ = ha[sl].clone().requires_grad_(True), hp[sl].clone().requires_grad_(True)
+        out = ReconLossFn.apply(a, ta[sl], p_, tp[sl])
+        (out * wts).sum().backward()
+        return out.detach(), a.grad, p_.grad
+
+    hb = slice(rank * B // world, (rank + 1) * B // world)
+    out, ga, gp = loss_case(hb, True)
+    osum = out.clone()
+    dist.all_reduce(osum)
+    OUT, GA, GP = loss_case(slice(0, B), False)
+    mean_out = osum / world
+    res["recon"] = dict(focal=abs(float(mean_out[0] - OUT[0])) / float(OUT[0]), pixel=abs(float(mean_out[1] - OUT[1])) / float(OUT[1]),
+                        tv_reported=abs(float(out[2] - OUT[2])) / float(OUT[2]),  # every rank reports the GLOBAL TV difference
+                        g_amp=l2(ga, GA[hb] * world), g_phs=l2(gp, GP[hb] * world))
+    hip_ops.set_sync_batch_stats(False)
+    print(json.dumps(res), flush=True)
+    dist.barrier()
+    dist.destroy_process_group()
+
+
 if __name__ == "__main__":
-    {"rccl": rccl_world1, "overlap": overlap, "critic": critic, "syncbn": syncbn}[sys.argv[1]]()
+    {"rccl": rccl_world1, "overlap": overlap, "critic": critic, "syncbn": syncbn, "syncops": syncops}[sys.argv[1]]()
