@@ -284,7 +284,7 @@ def syncbn():
             if key == "hat_amps":  # arbiter: the reconstruction evaluated again from rank 0's hologram
                 with torch.no_grad():
                     W2 = watermelon(filter_radius_coefficient=0.45, pad_size=32, distance_stack=stack, input_shape=(1, 4, rows, cols))
-                    again = W2.propagator.reconstruct_planes(W2.generator.part2.propagator, both[0].new_tensor(0) + ref_out["POH"], cat[1].to(dev), cat[2].to(dev), torch.cat(idxs))[0]
+                    again = W2.propagator.reconstruct_planes(W2.generator.part2.propagator, ref_out["POH"], cat[1].to(dev), cat[2].to(dev), torch.cat(idxs))[0]
                 info["fresh_evaluation_equals"] = {"rank0": bool(torch.equal(again, both[0])), "rank1": bool(torch.equal(again, both[1]))}
             agree[key + "_damage"] = info
     for m in ("G", "D"):
