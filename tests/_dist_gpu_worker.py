@@ -10,6 +10,8 @@ import torch.distributed as dist
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
+# which tiling variant the autotuner picked for every geometry goes into the kept record (the library appends to this file)
+os.environ.setdefault("LHG_TUNE_CACHE", os.path.join("/tmp", f"lhg_tune_rank{os.environ.get('RANK', '0')}_{os.getpid()}.txt"))
 
 
 def rccl_world1():
@@ -66,8 +68,20 @@ def overlap():
 
     notes = []
 
+    kept = []  # (POH, hat_amps, target_amps) of every pass: the shape of the damage when a pass does not repeat
+
+    def damage(a, b):
+        d = (a - b).abs()
+        nz = torch.nonzero(d > 0)
+        if len(nz) == 0:
+            return None
+        return {"elements": int(len(nz)), "max_abs": float(d.max()), "planes": sorted({(int(u), int(v)) for u, v in nz[:, :2].tolist()}),
+                "rows": sorted(set(nz[:, 2].tolist())), "cols": [int(nz[:, 3].min()), int(nz[:, 3].max()), len(set(nz[:, 3].tolist()))],
+                "samples": [{"at": q, "this": float(a[tuple(q)]), "pass0": float(b[tuple(q)])} for q in nz[:: max(1, len(nz) // 6)][:6].tolist()]}
+
     def one_pass():
         out = W.train_step(*x)
+        kept.append(tuple(out[k].detach().clone() for k in ("POH", "hat_amps", "target_amps")))
         fwd.append((float(out["G_loss"]), float(out["POH"].double().sum()), float(out["hat_amps"].double().sum()),
                     float(out["target_amps"].double().sum())))
         with torch.no_grad():  # the reconstruction of the step against fresh evaluations from the same hologram
@@ -150,6 +164,9 @@ def overlap():
     print(json.dumps({"rank": rank, "err": err, "launch_log": log, "contributions": total, "buckets": len(sync.ranges),
                       "local_repeatable": bool(torch.equal(local0, local)), "ranks_agree": bool(torch.equal(both[0], both[1])),
                       "forward_repeats": fwd[0] == fwd[1] == fwd[2], "forward": fwd, "recompute_notes": notes, "asm_probe": probe,
+                      "damage_vs_pass0": {f"pass{k}.{name}": dmg for k in (1, 2) for name, a, b in zip(("POH", "hat_amps", "target_amps"), kept[k], kept[0])
+                                          if (dmg := damage(a, b)) is not None},
+                      "tune_cache": open(os.environ["LHG_TUNE_CACHE"]).read().splitlines() if os.path.exists(os.environ.get("LHG_TUNE_CACHE", "")) else None,
                       "diff_pass0_vs_pass2": offenders(local0, local), "diff_reduced_vs_mean": offenders(reduced, mean) if err > 1e-6 else []}),
           flush=True)
     dist.barrier()
