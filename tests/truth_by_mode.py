@@ -8,7 +8,7 @@ CPU (truth), in fp32 on the CPU (the reference's arithmetic: oracle/) and on the
   e2e       POH / hat_amps / target_amps of the whole forward
 
 and writes e_gpu / e_cpu per quantity and mode to gpurun_out/r03_truth_by_mode.json (copied to profiles/ by hand).
-Test infrastructure: imports oracle/.  Usage: python tools/truth_by_mode.py [rows] [batch]
+Test infrastructure (lives under tests/: it imports oracle/; not collected by pytest).  Usage: python tests/truth_by_mode.py [rows] [batch]
 """
 import json
 import os
@@ -19,7 +19,6 @@ import torch
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, REPO)
-sys.path.insert(0, os.path.join(REPO, "tests"))
 
 from oracle import nets, optics, seeded  # noqa: E402
 
