@@ -300,6 +300,10 @@ def main():
                                                      + (", hipGraph replay" if args.graph else "")}}))
         return
 
+    # LHG_MAIN_PRIORITY=high (A/B measurements): the step's main chain of kernels on a high-priority stream
+    if os.environ.get("LHG_MAIN_PRIORITY") == "high":
+        _least, greatest = torch.cuda.Stream.priority_range()
+        torch.cuda.set_stream(torch.cuda.Stream(dev, priority=greatest))
     # ---- the timed region: no instrumentation of any kind
     for _ in range(args.warmup):
         W.train_step(rgbd, tamp, tphs)

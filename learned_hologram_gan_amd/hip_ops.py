@@ -325,7 +325,14 @@ def _grad_slot(w):
 def _side_stream(device):
     key = torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device()
     if key not in _SIDE_STREAMS:
-        _SIDE_STREAMS[key] = torch.cuda.Stream(key)
+        # LHG_SIDE_PRIORITY (A/B measurements): "low" = the least priority the device offers — the weight-gradient stream has slack and
+        # should yield compute units to the chain of kernels the step waits for; default: the stream's default priority
+        prio = os.environ.get("LHG_SIDE_PRIORITY", "")
+        if prio == "low":
+            least, _greatest = torch.cuda.Stream.priority_range()
+            _SIDE_STREAMS[key] = torch.cuda.Stream(key, priority=least)
+        else:
+            _SIDE_STREAMS[key] = torch.cuda.Stream(key)
     return _SIDE_STREAMS[key]
 
 
