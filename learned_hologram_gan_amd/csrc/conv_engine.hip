@@ -1133,21 +1133,37 @@ static inline int pad64(int c) { return (c + 63) / 64 * 64; }
 // Split count for the pixel (K) axis of a weight gradient.  Every split writes a full dW-sized slab that lhg_wgrad_reduce reads back, so S
 // is the factor by which the launch's output traffic exceeds dW itself: round 2 aimed at 1536 workgroups of the LARGEST tile the
 // extents allow (S = 6 on a 1024 -> 512 layer whose 288 tile x tap pairs already fill the chip: 113 MB of slabs for an 18.9 MB
-// gradient; 2.5 GB per train step in all, read again by the reduction).  Now the count assumes the SMALLEST tile (64 x 64: four times
-// the tile x tap pairs, the autotuner still picks the tile per geometry and S) and a target of LHG_WG_TARGET = 1024 workgroups: the
-// layers that hold most of the parameters run unsplit (S = 1: the slab IS dW) and only the narrow layers, whose gradients are small,
-// split deep.  LHG_WG_BASE_TILE=128 restores round 2's assumption for A/B measurements.
+// gradient; 2.5 GB per train step in all, read again by the reduction).  Two policies (LHG_WG_POLICY):
+//   "fill" (default)  the SMALLEST S whose workgroups of the largest tile fill >= 80 % of the chip's resident slots in their last wave
+//                     (512 slots for 128-wide tiles: two workgroups per CU; 768 for 64 x 64) — quantisation is what an unsplit or thinly
+//                     split launch loses (288 workgroups on 512 slots: 0.56), while a slab costs only ~2 x dW bytes of traffic;
+//   "bytes"           S from the smallest tile and LHG_WG_TARGET = 1024 workgroups: the fewest slab bytes (S = 1 on the wide layers).
+// LHG_WG_BASE_TILE=128 LHG_WG_POLICY=bytes LHG_WG_TARGET=1536 is round 2's rule.
 static int pick_splits(long long pixels, int m_pad, int n_pad, int taps) {
+  static const bool fill = [] { const char* e = getenv("LHG_WG_POLICY"); return !e || std::string(e) != "bytes"; }();
+  const long long steps = (pixels + BK - 1) / BK;
+  const long long cap = std::min<long long>(steps / 8 > 1 ? steps / 8 : 1, 4096);
+  if (fill) {
+    const bool big = m_pad % 128 == 0 && n_pad % 128 == 0;
+    const int t = big ? 128 : 64;
+    const long long tiles = (long long)(m_pad / t) * (n_pad / t) * taps, slots = big ? 512 : 768;
+    long long best = 1;
+    double best_util = 0;
+    for (long long s = 1; s <= cap && tiles * s <= 4 * slots; ++s) {
+      const long long wg = tiles * s, waves = (wg + slots - 1) / slots;
+      const double util = (double)wg / (double)(waves * slots);
+      if (util >= 0.8) return (int)s;
+      if (util > best_util) { best_util = util; best = s; }
+    }
+    return (int)best;
+  }
   static const int base = [] { const char* e = getenv("LHG_WG_BASE_TILE"); return e && atoi(e) == 128 ? 128 : 64; }();
   const int bm = (base == 128 && m_pad % 128 == 0) ? 128 : 64, bn = (base == 128 && n_pad % 128 == 0) ? 128 : 64;
   const long long tiles = (long long)(m_pad / bm) * (n_pad / bn) * taps;
-  const long long steps = (pixels + BK - 1) / BK;
   static const long long target = [] { const char* e = getenv("LHG_WG_TARGET"); return e ? atoll(e) : 1024ll; }();
   long long s = (target + tiles - 1) / tiles;
-  const long long cap = steps / 8 > 1 ? steps / 8 : 1;
   if (s > cap) s = cap;
   if (s < 1) s = 1;
-  if (s > 4096) s = 4096;
   return (int)s;
 }
 

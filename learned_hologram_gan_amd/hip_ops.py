@@ -429,6 +429,29 @@ def conv_precision() -> str:
     return _PRECISION_NAMES[_mode()]
 
 
+class precision:
+    """``with hip_ops.precision("fp32"): ...`` — the conv-GEMM arithmetic (and, with ``storage="bf16"``, the activation storage) for a
+    region, restored on exit whatever happens inside.  The switches are process-global (one host thread per process, as in the
+    reference); this is the form tests and tools use, so that one forgotten ``finally`` cannot change every later call's arithmetic."""
+
+    def __init__(self, name: str = "default", storage: str | None = None):
+        self.name, self.storage = name, storage
+
+    def __enter__(self):
+        self.prev_mode, self.prev_storage = conv_precision(), activation_storage()
+        if self.storage is not None and self.storage != self.prev_storage:
+            set_activation_storage(self.storage)
+        if not (self.storage == "bf16"):
+            set_conv_precision(self.name)
+        return self
+
+    def __exit__(self, *exc):
+        if activation_storage() != self.prev_storage:
+            set_activation_storage(self.prev_storage)
+        set_conv_precision(self.prev_mode)
+        return False
+
+
 def operand_absmax(t):
     """max|t| of an NHWC fp32 GEMM operand as a one-element device tensor (lhg_absmax on the current stream) — the tensor scale of
     the "fp32_split_f16" mode; None in every other mode.  Measured once per operand and handed to each GEMM that reads it."""

