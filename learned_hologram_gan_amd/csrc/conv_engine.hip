@@ -1134,7 +1134,7 @@ static inline int pad64(int c) { return (c + 63) / 64 * 64; }
 // is the factor by which the launch's output traffic exceeds dW itself: round 2 aimed at 1536 workgroups of the LARGEST tile the
 // extents allow (S = 6 on a 1024 -> 512 layer whose 288 tile x tap pairs already fill the chip: 113 MB of slabs for an 18.9 MB
 // gradient; 2.5 GB per train step in all, read again by the reduction).  Two policies (LHG_WG_POLICY):
-//   "fill" (default)  the SMALLEST S whose workgroups of the largest tile fill >= 80 % of the chip's resident slots in their last wave
+//   "fill" (default)  the SMALLEST S whose workgroups of the largest tile fill >= 90 % (LHG_WG_FILL) of the chip's resident slots in their last wave
 //                     (512 slots for 128-wide tiles: two workgroups per CU; 768 for 64 x 64) — quantisation is what an unsplit or thinly
 //                     split launch loses (288 workgroups on 512 slots: 0.56), while a slab costs only ~2 x dW bytes of traffic;
 //   "bytes"           S from the smallest tile and LHG_WG_TARGET = 1024 workgroups: the fewest slab bytes (S = 1 on the wide layers).
@@ -1146,13 +1146,15 @@ static int pick_splits(long long pixels, int m_pad, int n_pad, int taps) {
   if (fill) {
     const bool big = m_pad % 128 == 0 && n_pad % 128 == 0;
     const int t = big ? 128 : 64;
-    const long long tiles = (long long)(m_pad / t) * (n_pad / t) * taps, slots = big ? 512 : 768;
+    static const double want = [] { const char* e = getenv("LHG_WG_FILL"); return e ? atof(e) : 0.9; }();
+    static const long long slots_big = [] { const char* e = getenv("LHG_WG_SLOTS"); return e ? atoll(e) : 512ll; }();
+    const long long tiles = (long long)(m_pad / t) * (n_pad / t) * taps, slots = big ? slots_big : slots_big * 3 / 2;
     long long best = 1;
     double best_util = 0;
     for (long long s = 1; s <= cap && tiles * s <= 4 * slots; ++s) {
       const long long wg = tiles * s, waves = (wg + slots - 1) / slots;
       const double util = (double)wg / (double)(waves * slots);
-      if (util >= 0.8) return (int)s;
+      if (util >= want) return (int)s;
       if (util > best_util) { best_util = util; best = s; }
     }
     return (int)best;
