@@ -119,11 +119,11 @@ def main():
             out.append("")
     path = os.path.join(REPO, "profiles", f"{TAG}_pmc_mfma.jsonl")
     if os.path.exists(path):
-        out += [f"**Matrix-pipe occupancy** (`profiles/{TAG}_pmc_mfma.jsonl`):", "", "| layer (tools/one_layer.py args) | kernel | us | busy | clock GHz |", "|---|---|---|---|---|"]
+        out += [f"**Matrix-pipe occupancy** (`profiles/{TAG}_pmc_mfma.jsonl`):", "", "| layer (tag: mode_Cin_Cout_extent) | kernel matched | us | matrix pipe busy | clock GHz |", "|---|---|---|---|---|"]
         for ln in open(path):
             if ln.strip().startswith("{"):
                 d = json.loads(ln)
-                out.append(f"| {' '.join(d['args'])} | {d['kernel']} | {d['us_under_pmc'][-1]} | {d.get('matrix_pipe_busy')} | {d.get('shader_clock_ghz')} |")
+                out.append(f"| {d['tag']} | {d['kernel']} | {d['us_under_pmc'][-1]} | {d.get('matrix_pipe_busy')} | {d.get('shader_clock_ghz')} |")
         out.append("")
     out.append(END)
     path = os.path.join(REPO, "DESIGN.md")
