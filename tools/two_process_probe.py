@@ -1,0 +1,100 @@
+"""Diagnostic for the two-process non-repeat: N identical train steps per process, `procs` processes sharing this GPU at the
+same time (no torch.distributed, no collectives: each process is an ordinary single-GPU run).  Every step's outputs are compared bit for
+bit with the process's first step; a differing step is recorded with the SHAPE of the damage of each tensor (planes, rows, columns, a few
+value triples), so that the granularity can be matched against buffers and kernels.  One JSON line per process.
+
+    python tools/two_process_probe.py [steps=40] [procs=2] [mode=step|forward]      (GPU box; seeded weights need no oracle)
+"""
+import json
+import os
+import subprocess
+import sys
+
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def damage(a, b):
+    import torch
+
+    d = (a - b).abs()
+    nz = torch.nonzero(d > 0)
+    if len(nz) == 0:
+        return None
+    out = {"elements": int(len(nz)), "max_abs": float(d.max()), "shape": list(a.shape)}
+    if a.dim() == 4:
+        out.update(planes=sorted({(int(u), int(v)) for u, v in nz[:, :2].tolist()})[:8], rows=sorted(set(nz[:, 2].tolist())),
+                   cols=[int(nz[:, 3].min()), int(nz[:, 3].max()), len(set(nz[:, 3].tolist()))])
+    flat = torch.nonzero((a - b).flatten() != 0).flatten()
+    out["flat_first_last"] = [int(flat[0]), int(flat[-1])]
+    out["flat_runs"] = int((flat[1:] - flat[:-1] != 1).sum()) + 1  # number of contiguous runs of differing elements
+    out["samples"] = [{"at": int(i), "this": float(a.flatten()[i]), "first": float(b.flatten()[i])} for i in flat[:: max(1, len(flat) // 5)][:5].tolist()]
+    out["byte_offset_of_first"] = int(flat[0]) * a.element_size()
+    out["data_ptr_mod_4096"] = int(a.data_ptr() % 4096)
+    return out
+
+
+def worker(steps, mode):
+    import torch
+
+    sys.path.insert(0, REPO)
+    from learned_hologram_gan_amd import hip_ops
+    from learned_hologram_gan_amd.watermelon_hologram.watermelon import watermelon
+
+    dev = "cuda:0"
+    rows = cols = 64
+    torch.manual_seed(1234)  # both processes: the same weights and data (compared within a process only)
+    stack = torch.linspace(-4e-4, 0.0, 21)[:-1][:8]
+    W = watermelon(filter_radius_coefficient=0.45, pad_size=32, distance_stack=stack, input_shape=(1, 4, rows, cols))
+    W.generator.to(dev).train()
+    W.discriminator.to(dev).train()
+    W.configure(1, 0.0, 1, 1e-3, 0.1, 1e-3, 1e-3, 1 if mode == "step" else 0, 10)
+    g = torch.Generator().manual_seed(7)
+    x = [torch.rand((2, c, rows, cols), generator=g).to(dev) for c in (4, 3, 3)]
+    idx = torch.tensor([5, 2])
+    alphas = [torch.tensor([0.3, 0.8]).view(2, 1, 1, 1).to(dev)]
+    grads = {}
+    for name, opt in (("D", W._opt_D), ("G", W._opt_G)):
+        if opt is None:
+            continue
+
+        def no_update(name=name, opt=opt):  # capture instead of Adam: every step sees the same weights
+            hip_ops.join_side_stream()
+            grads[name] = opt.flat.grad.detach().clone()
+        opt.step = no_update
+    first, events = None, []
+    for k in range(steps):
+        if mode == "forward":
+            with torch.no_grad():
+                poh, hat_a, tgt_a, hat_p, tgt_p = W.reconstruct(x[0], x[1], x[2], idx)
+            cur = {"POH": poh, "hat_amps": hat_a, "target_amps": tgt_a, "hat_phs": hat_p, "tgt_phs": tgt_p}
+        else:
+            out = W.train_step(x[0], x[1], x[2], idx, alphas)
+            cur = {"POH": out["POH"], "hat_amps": out["hat_amps"], "target_amps": out["target_amps"], "grad_G": grads["G"], "grad_D": grads.get("D", grads["G"])}
+        torch.cuda.synchronize()
+        cur = {n: t.detach().clone() for n, t in cur.items()}
+        if first is None:
+            first = cur
+            continue
+        bad = {n: dmg for n in cur if (dmg := damage(cur[n], first[n])) is not None}
+        if bad:
+            events.append({"step": k, "damage": {n: v for n, v in bad.items()}})
+    print(json.dumps({"pid": os.getpid(), "steps": steps, "mode": mode, "events": len(events), "first_events": events[:4],
+                      "env": {k: os.environ[k] for k in ("AMD_SERIALIZE_KERNEL", "LHG_SIDE_WGRAD", "LHG_AUTOTUNE", "HIP_LAUNCH_BLOCKING") if k in os.environ}}), flush=True)
+
+
+if __name__ == "__main__":
+    if len(sys.argv) > 1 and sys.argv[1] == "--worker":
+        worker(int(sys.argv[2]), sys.argv[3])
+    else:
+        steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+        procs = int(sys.argv[2]) if len(sys.argv) > 2 else 2
+        mode = sys.argv[3] if len(sys.argv) > 3 else "step"
+        ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker", str(steps), mode], stdout=subprocess.PIPE, text=True) for _ in range(procs)]
+        rc = 0
+        for p_ in ps:
+            out, _ = p_.communicate(timeout=900)
+            rc |= p_.returncode
+            for ln in out.splitlines():
+                if ln.startswith("{"):
+                    print(ln, flush=True)
+        sys.exit(rc)
