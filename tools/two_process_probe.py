@@ -3,7 +3,7 @@ same time (no torch.distributed, no collectives: each process is an ordinary sin
 bit with the process's first step; a differing step is recorded with the SHAPE of the damage of each tensor (planes, rows, columns, a few
 value triples), so that the granularity can be matched against buffers and kernels.  One JSON line per process.
 
-    python tools/two_process_probe.py [steps=40] [procs=2] [mode=step|forward]      (GPU box; seeded weights need no oracle)
+    python tools/two_process_probe.py [steps=40] [procs=2] [mode=step|forward|torch]      (GPU box; seeded weights need no oracle)
 """
 import json
 import os
@@ -33,9 +33,43 @@ def damage(a, b):
     return out
 
 
+def torch_only_worker(steps):
+    """Control experiment: the same two-process set-up with stock ATen / MIOpen / rocFFT kernels only (no kernel of this repository):
+    a small conv -> batch-norm -> relu -> conv -> fft2 -> filter -> ifft2 -> abs chain on tensors of the rig's sizes."""
+    import torch
+    import torch.nn.functional as F
+
+    dev = "cuda:0"
+    torch.manual_seed(5)
+    x = torch.rand((2, 4, 64, 64), device=dev)
+    ws = [torch.randn((64, 4, 3, 3), device=dev) * 0.2] + [torch.randn((64, 64, 3, 3), device=dev) * 0.05 for _ in range(6)] + [torch.randn((6, 64, 1, 1), device=dev) * 0.1]
+    H = torch.exp(1j * torch.rand((3, 128, 128), device=dev) * 6.28)
+    first, events = None, []
+    for k in range(steps):
+        with torch.no_grad():
+            h = x
+            for w in ws[:-1]:
+                h = F.relu(F.batch_norm(F.conv2d(h, w, padding=1), None, None, training=True))
+            y = torch.sigmoid(F.conv2d(h, ws[-1]))
+            field = F.pad(y[:, :3] * torch.exp(1j * 6.28 * y[:, 3:]), (32, 32, 32, 32))
+            z = torch.fft.ifft2(torch.fft.fft2(field) * H)[:, :, 32:-32, 32:-32]
+            cur = {"y": y, "amp": z.abs(), "phs": z.angle()}
+        torch.cuda.synchronize()
+        cur = {n: t.detach().clone() for n, t in cur.items()}
+        if first is None:
+            first = cur
+            continue
+        bad = {n: dmg for n in cur if (dmg := damage(cur[n], first[n])) is not None}
+        if bad:
+            events.append({"step": k, "damage": bad})
+    print(json.dumps({"pid": os.getpid(), "steps": steps, "mode": "torch", "events": len(events), "first_events": events[:4], "env": {}}), flush=True)
+
+
 def worker(steps, mode):
     import torch
 
+    if mode == "torch":
+        return torch_only_worker(steps)
     sys.path.insert(0, REPO)
     from learned_hologram_gan_amd import hip_ops
     from learned_hologram_gan_amd.watermelon_hologram.watermelon import watermelon
