@@ -192,7 +192,7 @@ __device__ __forceinline__ void stages_2304(float2* buf, int nf, int stride, con
 // the same Stockham step as the radix-4 / 2 / 3 stages with the R-point DFT written out (R^2 complex multiply-adds, the powers of
 // w_R taken from the twiddle table at compile-time indices).  16 / R butterflies per thread, read-all / barrier / write-all.
 template <int R, bool INV>
-__device__ void stage_prime(float2* buf, int n, int p, int nf, int stride, const float2* tw) {
+__device__ __forceinline__ void stage_prime(float2* buf, int n, int p, int nf, int stride, const float2* tw) {
   constexpr int ITS = 16 / R;
   const int nthreads = blockDim.x, tid = threadIdx.x;
   const int T = n / R, total = nf * T, twstep = n / (p * R), wstep = n / R;
@@ -245,7 +245,7 @@ __device__ void stage_prime(float2* buf, int n, int p, int nf, int stride, const
 // PRIMES: the length may contain the factors 5 / 7 / 11 / 13.  A separate instantiation: with the prime stages compiled into it the
 // kernel of the 2^a 3^b lengths (the 4K geometry 2304 x 4096) ran 15 % slower (register pressure of the 13-point butterfly).
 template <bool INV, bool PRIMES = false>
-__device__ void lds_fft(float2* buf, int n, int nf, int stride, const float2* tw) {
+__device__ __forceinline__ void lds_fft(float2* buf, int n, int nf, int stride, const float2* tw) {
   switch (n) {  // wave-uniform
     case 64: return stages_pow2<64, 1, INV>(buf, nf, stride, tw);
     case 128: return stages_pow2<128, 1, INV>(buf, nf, stride, tw);
@@ -408,7 +408,7 @@ __device__ __forceinline__ float2 apply_filter(float2 z, float2 f, int op) {
 // FFT_m(c wrapped) / m], all evaluated from exact integer j^2 mod 2n in double.  The inverse transform is conj(forward(conj(x))).
 // tw: the m twiddles (LDS); tab: the table in global memory.  All threads of the workgroup call this.
 template <bool INV>
-__device__ void bluestein_fft(float2* buf, int n, int m, int nf, int stride, const float2* tw, const float2* __restrict__ tab) {
+__device__ __forceinline__ void bluestein_fft(float2* buf, int n, int m, int nf, int stride, const float2* tw, const float2* __restrict__ tab) {
   const float2* chirp = tab + m;
   const float2* bf = tab + m + n;
   const int tid = threadIdx.x, nth = blockDim.x;
@@ -508,8 +508,10 @@ struct ColsParams {
   const float2* tw;                           // R entries
 };
 
+// (PRIMES: at most 512 threads, so that the 13-point butterflies keep their values in registers — with 1024 threads the 128-VGPR budget
+// spills them to scratch)
 template <bool PRIMES>
-__global__ __launch_bounds__(1024) void cols_filter_kernel(const ColsParams p) {
+__global__ __launch_bounds__(PRIMES ? 512 : 1024) void cols_filter_kernel(const ColsParams p) {
   const int L = p.M ? p.M : p.R;
   float2* twl = reinterpret_cast<float2*>(lds_raw);
   float2* buf = p.tw_in_lds ? twl + L : twl;
@@ -764,7 +766,7 @@ static int run_cols(ColsParams& p, hipStream_t st) {
   int G = 16;
   while (G > 1 && (size_t)G * (L + 1) * sizeof(float2) + (size_t)L * sizeof(float2) > 150 * 1024) G >>= 1;
   p.tw_in_lds = tw_fits((size_t)G * (L + 1) * sizeof(float2), L);
-  int threads = 1024;
+  int threads = has_prime_radix(L) ? 512 : 1024;
   const long long budget = fft_budget(L);
   while (G > 1 && (long long)G * L > budget * threads) G >>= 1;
   if ((long long)G * L > budget * threads) return fail(LHG_E_ARG, "asm: column length %d unsupported", p.R);
