@@ -96,6 +96,26 @@ def worker(steps, mode):
             grads[name] = opt.flat.grad.detach().clone()
         opt.step = no_update
     first, events = None, []
+    if mode in ("asm", "unet"):  # one half of the forward only: the angular-spectrum operators on fixed inputs / the UNet alone
+        with torch.no_grad():
+            poh0 = W.generator(x[0])
+        for k in range(steps):
+            with torch.no_grad():
+                if mode == "asm":
+                    r = W.propagator.reconstruct_planes(W.generator.part2.propagator, poh0, x[1], x[2], idx)
+                    cur = {"hat_amps": r[0], "target_amps": r[2]}
+                else:
+                    cur = {"unet": W.generator.part1.part1(x[0])}
+            torch.cuda.synchronize()
+            cur = {n: t.detach().clone() for n, t in cur.items()}
+            if first is None:
+                first = cur
+                continue
+            bad = {n: dmg for n in cur if (dmg := damage(cur[n], first[n])) is not None}
+            if bad:
+                events.append({"step": k, "damage": bad})
+        print(json.dumps({"pid": os.getpid(), "steps": steps, "mode": mode, "events": len(events), "first_events": events[:4], "env": {}}), flush=True)
+        return
     for k in range(steps):
         if mode == "forward":
             with torch.no_grad():
@@ -123,7 +143,10 @@ if __name__ == "__main__":
         steps = int(sys.argv[1]) if len(sys.argv) > 1 else 40
         procs = int(sys.argv[2]) if len(sys.argv) > 2 else 2
         mode = sys.argv[3] if len(sys.argv) > 3 else "step"
-        ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker", str(steps), mode], stdout=subprocess.PIPE, text=True) for _ in range(procs)]
+        modes = mode.split("+")  # "forward+torch": process i runs modes[i % len(modes)] (who must be the co-tenant for the damage to show?)
+        mult = {"torch": 3, "asm": 8, "unet": 1}
+        ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker", str(steps * mult.get(modes[i % len(modes)], 1)), modes[i % len(modes)]],
+                               stdout=subprocess.PIPE, text=True) for i in range(procs)]
         rc = 0
         for p_ in ps:
             out, _ = p_.communicate(timeout=900)
