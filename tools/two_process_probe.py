@@ -65,11 +65,52 @@ def torch_only_worker(steps):
     print(json.dumps({"pid": os.getpid(), "steps": steps, "mode": "torch", "events": len(events), "first_events": events[:4], "env": {}}), flush=True)
 
 
+def kernel_family_worker(steps, mode):
+    """Co-tenant that runs ONE family of this repository's kernels in a loop (which one does the co-tenant have to run for the damage
+    to show in the other process?): conv = gather-GEMM forward 3x3 64->64, conv1 = 1x1, bn = statistics + apply, thin = 4->64 / 64->6,
+    pool = max-pool + layout."""
+    import torch
+
+    sys.path.insert(0, REPO)
+    from learned_hologram_gan_amd import hip_ops as ops
+
+    dev = "cuda:0"
+    torch.manual_seed(3)
+    x = torch.randn((2, 64, 64, 64), device=dev)
+    w3, w1 = torch.randn((64, 64, 3, 3), device=dev) * 0.05, torch.randn((64, 64, 1, 1), device=dev) * 0.1
+    x4 = torch.randn((2, 64, 64, 32), device=dev)
+    wt_in, wt_out = torch.randn((64, 4, 3, 3), device=dev) * 0.2, torch.randn((6, 64, 1, 1), device=dev) * 0.1
+    gamma, beta, rm, rv = torch.ones(64, device=dev), torch.zeros(64, device=dev), torch.zeros(64, device=dev), torch.ones(64, device=dev)
+    xn = torch.randn((2, 4, 64, 64), device=dev)
+    first, events = None, 0
+    with torch.no_grad():
+        for k in range(steps):
+            for _ in range(20):
+                if mode == "conv":
+                    y = ops.conv2d_forward_raw(x, w3, None, 1)
+                elif mode == "conv1":
+                    y = ops.conv2d_forward_raw(x, w1, None, 1)
+                elif mode == "bn":
+                    y = ops.BatchNormTrainFn.apply(x, gamma, beta, rm, rv, None, ops.ACT_RELU, 0.0, None)
+                elif mode == "thin":
+                    y = ops.conv2d_forward_raw(ops.conv2d_forward_raw(x4[..., :32], wt_in, None, 1), wt_out, None, 1, act=ops.ACT_SIGMOID, planar=True)
+                else:
+                    y = ops.MaxPool2x2Fn.apply(ops.ToNHWC.apply(xn, 32))
+            torch.cuda.synchronize()
+            c = y.float().double().sum().item()
+            if first is None:
+                first = c
+            events += c != first
+    print(json.dumps({"pid": os.getpid(), "steps": steps, "mode": mode, "events": int(events), "first_events": [], "env": {}}), flush=True)
+
+
 def worker(steps, mode):
     import torch
 
     if mode == "torch":
         return torch_only_worker(steps)
+    if mode in ("conv", "conv1", "bn", "thin", "pool"):
+        return kernel_family_worker(steps, mode)
     sys.path.insert(0, REPO)
     from learned_hologram_gan_amd import hip_ops
     from learned_hologram_gan_amd.watermelon_hologram.watermelon import watermelon
@@ -144,7 +185,7 @@ if __name__ == "__main__":
         procs = int(sys.argv[2]) if len(sys.argv) > 2 else 2
         mode = sys.argv[3] if len(sys.argv) > 3 else "step"
         modes = mode.split("+")  # "forward+torch": process i runs modes[i % len(modes)] (who must be the co-tenant for the damage to show?)
-        mult = {"torch": 3, "asm": 8, "unet": 1}
+        mult = {"torch": 3, "asm": 8, "unet": 1, "conv": 2, "conv1": 2, "bn": 2, "thin": 2, "pool": 2}
         ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker", str(steps * mult.get(modes[i % len(modes)], 1)), modes[i % len(modes)]],
                                stdout=subprocess.PIPE, text=True) for i in range(procs)]
         rc = 0
