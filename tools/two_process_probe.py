@@ -76,8 +76,9 @@ def kernel_family_worker(steps, mode):
 
     dev = "cuda:0"
     torch.manual_seed(3)
-    x = torch.randn((2, 64, 64, 64), device=dev)
-    w3, w1 = torch.randn((64, 64, 3, 3), device=dev) * 0.05, torch.randn((64, 64, 1, 1), device=dev) * 0.1
+    ci, co, hw = (int(v) for v in os.environ.get("PROBE_CONV", "64,64,64").split(","))  # PROBE_CONV=Ci,Co,extent of the conv co-tenant
+    x = torch.randn((2, hw, hw, ci), device=dev)
+    w3, w1 = torch.randn((co, ci, 3, 3), device=dev) * 0.05, torch.randn((co, ci, 1, 1), device=dev) * 0.1
     x4 = torch.randn((2, 64, 64, 32), device=dev)
     wt_in, wt_out = torch.randn((64, 4, 3, 3), device=dev) * 0.2, torch.randn((6, 64, 1, 1), device=dev) * 0.1
     gamma, beta, rm, rv = torch.ones(64, device=dev), torch.zeros(64, device=dev), torch.zeros(64, device=dev), torch.ones(64, device=dev)
@@ -91,7 +92,7 @@ def kernel_family_worker(steps, mode):
                 elif mode == "conv1":
                     y = ops.conv2d_forward_raw(x, w1, None, 1)
                 elif mode == "bn":
-                    y = ops.BatchNormTrainFn.apply(x, gamma, beta, rm, rv, None, ops.ACT_RELU, 0.0, None)
+                    y = ops.BatchNormTrainFn.apply(x[..., :64], gamma, beta, rm, rv, None, ops.ACT_RELU, 0.0, None)
                 elif mode == "thin":
                     y = ops.conv2d_forward_raw(ops.conv2d_forward_raw(x4[..., :32], wt_in, None, 1), wt_out, None, 1, act=ops.ACT_SIGMOID, planar=True)
                 else:
