@@ -188,8 +188,11 @@ if __name__ == "__main__":
         mode = sys.argv[3] if len(sys.argv) > 3 else "step"
         modes = mode.split("+")  # "forward+torch": process i runs modes[i % len(modes)] (who must be the co-tenant for the damage to show?)
         mult = {"torch": 3, "asm": 8, "unet": 1, "conv": 2, "conv1": 2, "bn": 2, "thin": 2, "pool": 2}
-        ps = [subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker", str(steps * mult.get(modes[i % len(modes)], 1)), modes[i % len(modes)]],
-                               stdout=subprocess.PIPE, text=True) for i in range(procs)]
+        ps = []
+        for i in range(procs):  # "asm@HIP_LAUNCH_BLOCKING=1+unet": VAR=value pairs after '@' go into that process's environment only
+            m, *envs = modes[i % len(modes)].split("@")
+            env = dict(os.environ, **dict(e.split("=", 1) for e in envs))
+            ps.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker", str(steps * mult.get(m, 1)), m], stdout=subprocess.PIPE, text=True, env=env))
         rc = 0
         for p_ in ps:
             out, _ = p_.communicate(timeout=900)
