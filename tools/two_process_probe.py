@@ -86,14 +86,18 @@ def kernel_family_worker(steps, mode):
     first, events = None, 0
     with torch.no_grad():
         for k in range(steps):
-            for _ in range(20):
-                if mode == "conv":
+            for j in range(20):
+                mode_j = mode
+                if mode.startswith("mix"):  # "mix:conv,bn,pool": cycle through the named families
+                    fams = mode.split(":")[1].split(",")
+                    mode_j = fams[j % len(fams)]
+                if mode_j == "conv":
                     y = ops.conv2d_forward_raw(x, w3, None, 1)
-                elif mode == "conv1":
+                elif mode_j == "conv1":
                     y = ops.conv2d_forward_raw(x, w1, None, 1)
-                elif mode == "bn":
+                elif mode_j == "bn":
                     y = ops.BatchNormTrainFn.apply(x[..., :64], gamma, beta, rm, rv, None, ops.ACT_RELU, 0.0, None)
-                elif mode == "thin":
+                elif mode_j == "thin":
                     y = ops.conv2d_forward_raw(ops.conv2d_forward_raw(x4[..., :32], wt_in, None, 1), wt_out, None, 1, act=ops.ACT_SIGMOID, planar=True)
                 else:
                     y = ops.MaxPool2x2Fn.apply(ops.ToNHWC.apply(xn, 32))
@@ -110,7 +114,7 @@ def worker(steps, mode):
 
     if mode == "torch":
         return torch_only_worker(steps)
-    if mode in ("conv", "conv1", "bn", "thin", "pool"):
+    if mode in ("conv", "conv1", "bn", "thin", "pool") or mode.startswith("mix"):
         return kernel_family_worker(steps, mode)
     sys.path.insert(0, REPO)
     from learned_hologram_gan_amd import hip_ops
@@ -187,12 +191,12 @@ if __name__ == "__main__":
         procs = int(sys.argv[2]) if len(sys.argv) > 2 else 2
         mode = sys.argv[3] if len(sys.argv) > 3 else "step"
         modes = mode.split("+")  # "forward+torch": process i runs modes[i % len(modes)] (who must be the co-tenant for the damage to show?)
-        mult = {"torch": 3, "asm": 8, "unet": 1, "conv": 2, "conv1": 2, "bn": 2, "thin": 2, "pool": 2}
+        mult = {"torch": 3, "asm": 8, "unet": 1, "conv": 2, "conv1": 2, "bn": 2, "thin": 2, "pool": 2, "mix": 2}
         ps = []
         for i in range(procs):  # "asm@HIP_LAUNCH_BLOCKING=1+unet": VAR=value pairs after '@' go into that process's environment only
             m, *envs = modes[i % len(modes)].split("@")
             env = dict(os.environ, **dict(e.split("=", 1) for e in envs))
-            ps.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker", str(steps * mult.get(m, 1)), m], stdout=subprocess.PIPE, text=True, env=env))
+            ps.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), "--worker", str(steps * mult.get(m.split(":")[0], 1)), m], stdout=subprocess.PIPE, text=True, env=env))
         rc = 0
         for p_ in ps:
             out, _ = p_.communicate(timeout=900)
