@@ -675,6 +675,13 @@ static int set_dyn_lds(const void* fn, size_t bytes) {
   return LHG_OK;
 }
 
+// LHG_ASM_LDS_PAD=<bytes> (diagnostics): every angular-spectrum launch requests at least this much dynamic LDS, so that a workgroup can be
+// given a compute unit's LDS to itself (no co-resident workgroup with a large LDS footprint)
+static size_t lds_request(size_t need) {
+  static const size_t pad = [] { const char* e = getenv("LHG_ASM_LDS_PAD"); return e ? (size_t)atoll(e) : (size_t)0; }();
+  return std::max(need, std::min<size_t>(pad, 160 * 1024));
+}
+
 static bool asm_reg_enabled() {
   static const bool reg = [] { const char* e = getenv("LHG_ASM_REG"); return e ? atoi(e) != 0 : true; }();
   return reg;
@@ -683,7 +690,7 @@ static bool asm_reg_enabled() {
 template <int N1, int NF>
 static int run_rows_forward_reg(const float* in_a, const float* in_b, int in_mode, float phase_scale, int total_rows, int cols0, int pad_c,
                                 const float* tw_cols, float2* t1, hipStream_t st) {
-  const size_t lds = RegFftLds<N1>::bytes(NF);
+  const size_t lds = lds_request(RegFftLds<N1>::bytes(NF));
   int rc = set_dyn_lds(reinterpret_cast<const void*>(rows_fwd_reg_kernel<N1, NF>), lds);
   if (rc) return rc;
   hipLaunchKernelGGL((rows_fwd_reg_kernel<N1, NF>), dim3((total_rows + NF - 1) / NF), dim3(N1 * NF), lds, st, in_a, in_b, in_mode, phase_scale,
@@ -694,7 +701,7 @@ static int run_rows_forward_reg(const float* in_a, const float* in_b, int in_mod
 template <int N1, int NF>
 static int run_rows_inverse_reg(const float2* t2, int total_rows, int cols0, int pad_c, const float* tw_cols, float* out_a, float* out_b,
                                 float* out_c, int out_mode, hipStream_t st) {
-  const size_t lds = RegFftLds<N1>::bytes(NF);
+  const size_t lds = lds_request(RegFftLds<N1>::bytes(NF));
   int rc = set_dyn_lds(reinterpret_cast<const void*>(rows_inv_reg_kernel<N1, NF>), lds);
   if (rc) return rc;
   hipLaunchKernelGGL((rows_inv_reg_kernel<N1, NF>), dim3((total_rows + NF - 1) / NF), dim3(N1 * NF), lds, st, t2, total_rows, cols0, pad_c,
@@ -709,7 +716,7 @@ static int run_rows_forward(const float* in_a, const float* in_b, int in_mode, f
   const int m = bluestein_len(cols), L = m ? m : cols;
   const int nf = rows_nf(L);
   const int tw_lds = tw_fits((size_t)nf * L * sizeof(float2), L);
-  const size_t lds = (size_t)((tw_lds ? L : 0) + nf * L) * sizeof(float2);
+  const size_t lds = lds_request((size_t)((tw_lds ? L : 0) + nf * L) * sizeof(float2));
   const int total_rows = planes * rows0;
   auto launch = [&](auto kernel) {
     int rc = set_dyn_lds(reinterpret_cast<const void*>(kernel), lds);
@@ -730,7 +737,7 @@ static int run_rows_inverse(const float2* t2, int planes, int rows0, int cols0, 
   const int m = bluestein_len(cols), L = m ? m : cols;
   const int nf = rows_nf(L);
   const int tw_lds = tw_fits((size_t)nf * L * sizeof(float2), L);
-  const size_t lds = (size_t)((tw_lds ? L : 0) + nf * L) * sizeof(float2);
+  const size_t lds = lds_request((size_t)((tw_lds ? L : 0) + nf * L) * sizeof(float2));
   const int total_rows = planes * rows0;
   auto launch = [&](auto kernel) {
     int rc = set_dyn_lds(reinterpret_cast<const void*>(kernel), lds);
@@ -746,7 +753,7 @@ static int run_rows_inverse(const float2* t2, int planes, int rows0, int cols0, 
 
 template <int N1, int G>
 static int run_cols_reg(ColsParams& p, hipStream_t st) {
-  const size_t lds = RegFftLds<N1>::bytes(G);
+  const size_t lds = lds_request(RegFftLds<N1>::bytes(G));
   int rc = set_dyn_lds(reinterpret_cast<const void*>(cols_reg_kernel<N1, G>), lds);
   if (rc) return rc;
   p.G = G;
@@ -774,7 +781,7 @@ static int run_cols(ColsParams& p, hipStream_t st) {
   while (threads > 64 && (long long)G * L <= 2ll * threads) threads >>= 1;  // small transforms: fewer idle waves
   p.G = G;
   p.tw_in_lds = tw_fits((size_t)G * (L + 1) * sizeof(float2), L);
-  const size_t lds = ((size_t)G * (L + 1) + (p.tw_in_lds ? L : 0)) * sizeof(float2);
+  const size_t lds = lds_request(((size_t)G * (L + 1) + (p.tw_in_lds ? L : 0)) * sizeof(float2));
   auto launch = [&](auto kernel) {
     int rc = set_dyn_lds(reinterpret_cast<const void*>(kernel), lds);
     if (rc) return rc;
