@@ -143,7 +143,7 @@ def worker(steps, mode):
             grads[name] = opt.flat.grad.detach().clone()
         opt.step = no_update
     first, events = None, []
-    if mode in ("asm", "unet", "asm1"):  # one half of the forward only: the angular-spectrum operators on fixed inputs / the UNet alone
+    if mode in ("asm", "unet", "asm1", "asmto", "asmfrom"):  # one half of the forward only: the angular-spectrum operators on fixed inputs / the UNet alone
         with torch.no_grad():
             poh0 = W.generator(x[0])
         for k in range(steps):
@@ -151,6 +151,15 @@ def worker(steps, mode):
                 if mode == "asm":
                     r = W.propagator.reconstruct_planes(W.generator.part2.propagator, poh0, x[1], x[2], idx)
                     cur = {"hat_amps": r[0], "target_amps": r[2]}
+                elif mode in ("asmto", "asmfrom"):  # the halves of the operator: row pass + column FFT x filter / column IFFT + row pass
+                    fp = W.generator.part2.propagator
+                    if mode == "asmto":
+                        cur = {"spectrum": torch.view_as_real(fp.propagate_POH2Freq_forward(poh0))}
+                    else:
+                        if first is None:
+                            S_fixed = fp.propagate_POH2Freq_forward(poh0)
+                        r = W.propagator.propagate_multiple_samples_with_random_fixed_multiple_distances_freq2amp(S_fixed, idx)
+                        cur = {"amp": r[0], "phs": r[1]}
                 elif mode == "asm1":  # the SAME operator call twice per iteration: its workspace block only ever holds one content
                     fp = W.generator.part2.propagator
                     r = fp.propagate_POH2AP_forward(poh0)
@@ -196,7 +205,7 @@ if __name__ == "__main__":
         procs = int(sys.argv[2]) if len(sys.argv) > 2 else 2
         mode = sys.argv[3] if len(sys.argv) > 3 else "step"
         modes = mode.split("+")  # "forward+torch": process i runs modes[i % len(modes)] (who must be the co-tenant for the damage to show?)
-        mult = {"torch": 3, "asm": 8, "asm1": 8, "unet": 1, "conv": 2, "conv1": 2, "bn": 2, "thin": 2, "pool": 2, "mix": 2}
+        mult = {"torch": 3, "asm": 8, "asm1": 8, "asmto": 8, "asmfrom": 8, "unet": 1, "conv": 2, "conv1": 2, "bn": 2, "thin": 2, "pool": 2, "mix": 2}
         ps = []
         for i in range(procs):  # "asm@HIP_LAUNCH_BLOCKING=1+unet": VAR=value pairs after '@' go into that process's environment only
             m, *envs = modes[i % len(modes)].split("@")
