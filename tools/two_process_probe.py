@@ -27,6 +27,8 @@ def damage(a, b):
     flat = torch.nonzero((a - b).flatten() != 0).flatten()
     out["flat_first_last"] = [int(flat[0]), int(flat[-1])]
     out["flat_runs"] = int((flat[1:] - flat[:-1] != 1).sum()) + 1  # number of contiguous runs of differing elements
+    if len(flat) <= 256:
+        out["flat_all"] = flat.tolist()
     out["samples"] = [{"at": int(i), "this": float(a.flatten()[i]), "first": float(b.flatten()[i])} for i in flat[:: max(1, len(flat) // 5)][:5].tolist()]
     out["byte_offset_of_first"] = int(flat[0]) * a.element_size()
     out["data_ptr_mod_4096"] = int(a.data_ptr() % 4096)
