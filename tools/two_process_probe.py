@@ -111,9 +111,49 @@ def kernel_family_worker(steps, mode):
     print(json.dumps({"pid": os.getpid(), "steps": steps, "mode": mode, "events": int(events), "first_events": [], "env": {}}), flush=True)
 
 
+def same_process_worker(steps):
+    """ONE process, two HIP streams: the angular-spectrum operator in a loop on one stream, the deep 3x3 convolution (the strongest
+    co-tenant of the two-process experiments) on the other — does the damage need two PROCESSES, or only two queues?"""
+    import torch
+
+    sys.path.insert(0, REPO)
+    from learned_hologram_gan_amd import hip_ops as ops
+    from learned_hologram_gan_amd.watermelon_hologram.watermelon import watermelon
+
+    dev = "cuda:0"
+    torch.manual_seed(1234)
+    stack = torch.linspace(-4e-4, 0.0, 21)[:-1][:8]
+    W = watermelon(filter_radius_coefficient=0.45, pad_size=32, distance_stack=stack, input_shape=(1, 4, 64, 64))
+    W.generator.to(dev).train()
+    g = torch.Generator().manual_seed(7)
+    x0 = torch.rand((2, 4, 64, 64), generator=g).to(dev)
+    ci, co, hw = (int(v) for v in os.environ.get("PROBE_CONV", "1024,512,8").split(","))
+    xc, wc = torch.randn((2, hw, hw, ci), device=dev), torch.randn((co, ci, 3, 3), device=dev) * 0.05
+    sa, sb = torch.cuda.Stream(), torch.cuda.Stream()
+    with torch.no_grad():
+        poh0 = W.generator(x0)
+        fp = W.generator.part2.propagator
+        first = fp.propagate_POH2AP_forward(poh0)[0].clone()
+        for _ in range(3):
+            ops.conv2d_forward_raw(xc, wc, None, 1)  # tuning / forced variant warm-up on the default stream
+        torch.cuda.synchronize()
+        events = 0
+        for k in range(steps):
+            with torch.cuda.stream(sb):
+                for _ in range(6):
+                    yc = ops.conv2d_forward_raw(xc, wc, None, 1)
+            with torch.cuda.stream(sa):
+                outs = [fp.propagate_POH2AP_forward(poh0)[0] for _ in range(8)]
+            torch.cuda.synchronize()
+            events += sum(int(not torch.equal(o, first)) for o in outs)
+    print(json.dumps({"pid": os.getpid(), "steps": steps * 8, "mode": "same_process(asm1|conv)", "events": events, "first_events": [], "env": {}}), flush=True)
+
+
 def worker(steps, mode):
     import torch
 
+    if mode == "same":
+        return same_process_worker(steps)
     if mode == "torch":
         return torch_only_worker(steps)
     if mode in ("conv", "conv1", "bn", "thin", "pool") or mode.startswith("mix"):
