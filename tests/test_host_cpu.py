@@ -64,6 +64,22 @@ def test_library_is_gfx950_code_object():
     assert b"gfx950" in blob
 
 
+def test_library_contains_no_packed_fp32_instructions():
+    """packed-fp32 VALU instructions next to MFMA workgroups of another queue made the angular-spectrum operator non-
+    repeatable on MI355X; the build switches the feature off for every kernel file (__graft_entry__.NO_PACKED_FP32).  Disassemble the
+    seven gfx950 code objects of the built library and check that none came back (and that the MFMA kernels are there)."""
+    import os
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import device_isa_scan
+
+    got = device_isa_scan.scan(r"v_pk_(fma|mul|add)_f32|v_mfma_f32_32x32x16_f16")
+    assert got["code_objects"] == 7 and got["instructions"] > 100000, got
+    assert got["matches"].get("v_mfma_f32_32x32x16_f16", 0) > 0, got
+    assert not [k for k in got["matches"] if k.startswith("v_pk_")], got
+
+
 def test_ops_refuse_cpu_tensors():
     from learned_hologram_gan_amd import hip_ops, native
     from learned_hologram_gan_amd.angular_spectrum_method import bandLimitedAngularSpectrumMethod_for_single_fixed_distance as Fx
