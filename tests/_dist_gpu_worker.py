@@ -14,6 +14,12 @@ sys.path.insert(0, REPO)
 os.environ.setdefault("LHG_TUNE_CACHE", os.path.join("/tmp", f"lhg_tune_rank{os.environ.get('RANK', '0')}_{os.getpid()}.txt"))
 
 
+def emit(text, flush=True):
+    """One write() per record: print() writes the text and the newline separately, and the ranks share the launcher's pipe."""
+    sys.stdout.write(text + "\n")
+    sys.stdout.flush()
+
+
 def rccl_world1():
     """backend="nccl" IS RCCL on ROCm: initialise it for a world of one and run the collectives the trainer uses."""
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -30,7 +36,7 @@ def rccl_world1():
     dist.barrier()
     torch.cuda.synchronize()
     ok = bool(torch.equal(t, want)) and m.item() == 3.5
-    print(json.dumps({"rccl": ok, "backend": dist.get_backend(), "nccl_version": list(torch.cuda.nccl.version())}), flush=True)
+    emit(json.dumps({"rccl": ok, "backend": dist.get_backend(), "nccl_version": list(torch.cuda.nccl.version())}), flush=True)
     dist.destroy_process_group()
 
 
@@ -161,7 +167,7 @@ def overlap():
                 out.append((names.get(id(p_), "?"), float((da - db).norm() / (db.norm() + 1e-30))))
         return sorted(out, key=lambda t: -t[1])[:6]
 
-    print(json.dumps({"rank": rank, "err": err, "launch_log": log, "contributions": total, "buckets": len(sync.ranges),
+    emit(json.dumps({"rank": rank, "err": err, "launch_log": log, "contributions": total, "buckets": len(sync.ranges),
                       "local_repeatable": bool(torch.equal(local0, local)), "ranks_agree": bool(torch.equal(both[0], both[1])),
                       "forward_repeats": fwd[0] == fwd[1] == fwd[2], "forward": fwd, "recompute_notes": notes, "asm_probe": probe,
                       "damage_vs_pass0": {f"pass{k}.{name}": dmg for k in (1, 2) for name, a, b in zip(("POH", "hat_amps", "target_amps"), kept[k], kept[0])
@@ -226,7 +232,7 @@ def critic():
                      "ranks_agree": bool(torch.equal(both[0], both[1])), "buckets": len(sync.ranges),
                      "bucket_elems": [hi - lo for lo, hi in sync.ranges],
                      "launch_log": [(b, bool(ff)) for b, _, ff in logs[name][1]]}
-    print(json.dumps(out), flush=True)
+    emit(json.dumps(out), flush=True)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -325,7 +331,7 @@ def syncbn():
         res.update(worst=worst)
         res.update(g_err=l2(grads["G"], ref_grads["G"]), d_err=l2(grads["D"], ref_grads["D"]), bn_err=l2(bn, ref_bn),
                    hat_err=l2(torch.cat(hat, 0), ref_out["hat_amps"]), losses=mean_losses.tolist(), ref_losses=ref_losses.tolist())
-    print(json.dumps(res), flush=True)
+    emit(json.dumps(res), flush=True)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -395,7 +401,7 @@ def syncops():
                         tv_reported=abs(float(out[2] - OUT[2])) / float(OUT[2]),  # every rank reports the GLOBAL TV difference
                         g_amp=l2(ga, GA[hb] * world), g_phs=l2(gp, GP[hb] * world))
     hip_ops.set_sync_batch_stats(False)
-    print(json.dumps(res), flush=True)
+    emit(json.dumps(res), flush=True)
     dist.barrier()
     dist.destroy_process_group()
 

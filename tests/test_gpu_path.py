@@ -336,8 +336,13 @@ def test_train_step_against_reference_loop(golden):
         for k, v in post.items():
             if k in ("block2.0.bias", "block3.0.bias", "block4.0.bias", "block5.0.bias", "block6.0.bias"):
                 continue
-            bad = ((sd[k].cpu() - v).abs() > 2e-4 + 1e-3 * v.abs()).float().mean().item()
-            assert bad <= max(5e-3, 3.0 / v.numel()), (k, bad)  # a sign flip of a near-zero gradient moves a weight by 2*lr
+            # Adam's first step moves every weight by lr*g/(|g|+eps) ~ lr*sign(g): a gradient within rounding noise of zero may come out
+            # with the other sign (or a different fraction of lr) and then the weight differs by AT MOST 2*lr.  Such weights are few (a
+            # handful per tensor: which ones flip changes with any change of summation order) and bounded; everything else must agree.
+            d = (sd[k].cpu() - v).abs()
+            bad = d > 2e-4 + 1e-3 * v.abs()
+            assert bad.float().mean().item() <= max(5e-3, 6.0 / v.numel()), (k, int(bad.sum()), v.numel())
+            assert not bad.any() or d[bad].max().item() <= 2.1 * 1e-3, (k, d[bad].max().item())
 
 
 def test_train_step_vs_oracle_fresh_inputs():
@@ -849,7 +854,13 @@ def _run_dist_worker(mode, nproc, env_extra=None, timeout=280):
                "--master-port", str(port), worker, mode]
     res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=timeout)
     assert res.returncode == 0, (res.stdout[-1500:], res.stderr[-2500:])
-    return [json.loads(ln) for ln in res.stdout.splitlines() if ln.startswith("{")]
+    out, dec = [], json.JSONDecoder()
+    for ln in res.stdout.splitlines():   # the ranks share the launcher's pipe: tolerate two records on one line
+        pos = 0
+        while ln.startswith("{", pos):
+            rec, pos = dec.raw_decode(ln, pos)
+            out.append(rec)
+    return out
 
 
 def test_rccl_backend_initialises_and_reduces_world1():
