@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define LHG_ABI_VERSION 4
+#define LHG_ABI_VERSION 5
 
 enum {
   LHG_OK = 0,
@@ -130,6 +130,14 @@ int lhg_absmax(const float* x, long long pixels, int C, int ld, float* out, lhg_
  * pass `out` as the `x_absmax` (Ci floats) / `gy_absmax` (Co floats) of lhg_conv2d_backward_weight / lhg_conv_transpose2x2_backward_weight.
  * Any per-channel upper bound is valid. */
 int lhg_channel_absmax(const float* x, long long pixels, int C, int ld, float* out, float* ws, lhg_stream_t s);
+/* The same maxima WITHOUT a pass of their own (ABI 5): the kernels that write most weight-gradient operands — lhg_bn_apply (a conv's
+ * input) and lhg_bn_backward (a conv's output gradient) — leave per-workgroup partial maxima of what they write in
+ * `*_chanmax_partial` (lhg_chanmax_partial_rows(pixels, C) x C floats, overwritten) through lhg_bn_apply_chanmax /
+ * lhg_bn_backward_chanmax below; lhg_channel_absmax_finish(partial, pixels, C, out) reduces them to `out` (C floats) on any stream
+ * ordered behind the producer — one small launch where lhg_channel_absmax reads the whole tensor again (a train step at 384 x 384,
+ * batch 4: 77 of the 98 operands' maxima come this way, 1.5 GB of re-reads less). */
+long long lhg_chanmax_partial_rows(long long pixels, int C);
+int lhg_channel_absmax_finish(const float* partial, long long pixels, int C, float* out, lhg_stream_t s);
 
 /* Pack a PyTorch 4-D weight w[D0][D1][KH][KW] into GEMM panels dst[KH*KW][rows_pad][k_pad],
  * K contiguous, zero padded.  rows_from_d0 = 1: rows = D0, K = D1 (Conv2d forward,
@@ -248,6 +256,10 @@ int lhg_bn_stats(const float* x, long long pixels, int C, int ld, float* stats,
 int lhg_bn_apply(const float* x, int ldx, long long pixels, int C, const float* stats,
                  const float* gamma, const float* beta, const float* res, int ldres,
                  int act, float slope, float* y, int ldy, float* y_absmax, lhg_stream_t s);
+/* lhg_bn_apply (fp32 storage) that also writes the per-channel partial maxima of y (see lhg_channel_absmax_finish). */
+int lhg_bn_apply_chanmax(const float* x, int ldx, long long pixels, int C, const float* stats,
+                         const float* gamma, const float* beta, const float* res, int ldres,
+                         int act, float slope, float* y, int ldy, float* y_absmax, float* y_chanmax_partial, lhg_stream_t s);
 /* Backward of y = act(bn(x) + res) given gy:  g = gy * act'(y);  gres = g (if non-NULL);
  * gx = gamma*invstd*(g - mean(g) - xhat*mean(g*xhat)); ggamma (+)= sum g*xhat; gbeta (+)= sum g  (accumulate != 0 adds).
  * `y` is the forward OUTPUT (sign gives the activation mask).  ws: >= 8192*C floats.
@@ -260,6 +272,13 @@ int lhg_bn_backward(const float* gy, int ldgy, const float* x, int ldx, const fl
                     int act, float slope, float* gx, int ldgx, float* gres, int ldgres,
                     float* ggamma, float* gbeta, int accumulate, float* ws, float* gx_absmax,
                     const float* beta, lhg_stream_t s);
+/* lhg_bn_backward (fp32 storage) that also writes the per-channel partial maxima of gx and, when both `gres` and
+ * `gres_chanmax_partial` are non-NULL, of gres (the gy operand of the block's shortcut conv) — see lhg_channel_absmax_finish. */
+int lhg_bn_backward_chanmax(const float* gy, int ldgy, const float* x, int ldx, const float* y, int ldy,
+                            long long pixels, int C, const float* stats, const float* gamma,
+                            int act, float slope, float* gx, int ldgx, float* gres, int ldgres,
+                            float* ggamma, float* gbeta, int accumulate, float* ws, float* gx_absmax,
+                            const float* beta, float* gx_chanmax_partial, float* gres_chanmax_partial, lhg_stream_t s);
 /* Double backward of the gx output above (WGAN-GP, ref: watermelon.py:466-473):
  * given ggx (cotangent of gx) returns ggy (cotangent of gy), gx2 (cotangent of x) and
  * ggamma2 (cotangent of gamma).  ws: >= 5*4096*C floats. */

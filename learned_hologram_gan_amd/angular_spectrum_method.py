@@ -100,7 +100,9 @@ class bandLimitedAngularSpectrumMethod:
                 self._index_cache[key] = (torch.arange(planes, dtype=torch.int32) % 3).to(self.device)
             return self._index_cache[key]
         col = torch.arange(3, dtype=torch.int32)
-        return (offsets.to(torch.int32).cpu().reshape(-1, 1) * 3 + col).reshape(-1).to(self.device)
+        idx = (offsets.to(torch.int32).cpu().reshape(-1, 1) * 3 + col).reshape(-1)
+        # a pageable host-to-device copy makes the host wait for everything queued on the stream: stage through pinned memory
+        return idx.pin_memory().to(self.device, non_blocking=True) if torch.device(self.device).type == "cuda" else idx.to(self.device)
 
     def _run(self, a, b, in_mode, out_mode, factors, phase_scale=1.0):
         if not self._geom.supported():

@@ -151,36 +151,65 @@ __device__ __forceinline__ f32x4 bn_affine(f32x4 x, f32x4 a, f32x4 b) {
   return v;
 }
 
+// Workgroup stage of a per-channel maximum: the row lanes (ty) of each channel lane (tx) are combined through LDS and lane ty == 0
+// stores the four channels' maxima.  Called by all 256 threads (two barriers).
+__device__ __forceinline__ void channel_max_commit(u32x4* red, const u32x4& mine, int tx, int ty, int lanes_c, int rows, bool live, unsigned* dst) {
+  red[ty * lanes_c + tx] = mine;
+  __syncthreads();
+  if (ty == 0 && live) {
+    u32x4 m = mine;
+    for (int r = 1; r < rows; ++r) {
+      const u32x4 o = red[r * lanes_c + tx];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) m[e] = max(m[e], o[e]);
+    }
+    *reinterpret_cast<u32x4*>(dst) = m;
+  }
+  __syncthreads();
+}
+
 // ------------------------------------------------------------------ BN apply (+residual, +activation)
+// cmax_partial (may be null): partial[blockIdx.x][c] = max over this workgroup's pixels of |y[.][c]| (magnitude bits) — the first stage of
+// lhg_channel_absmax taken on the way out (the per-channel scales of the weight-gradient GEMM that reads y), finished by
+// channel_absmax_reduce over gridDim.x rows.
 template <class T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, int ldx, long long pixels, int C,
                                                        const float* __restrict__ stats, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const T* __restrict__ res, int ldres,
                                                        int act, float slope, T* __restrict__ y, int ldy, int lanes_c, int rows,
-                                                       float* __restrict__ y_amax) {
+                                                       float* __restrict__ y_amax, unsigned* __restrict__ cmax_partial) {
+  __shared__ u32x4 cred[256];
   const int tx = threadIdx.x % lanes_c, ty = threadIdx.x / lanes_c;
   unsigned am = 0;
   const unsigned seen = amax_peek(y_amax);
-  for (int cb = (blockIdx.y * lanes_c + tx) * 4; cb < C; cb += gridDim.y * lanes_c * 4) {
-    const f32x4 mean = ld4(stats + cb), inv = ld4(stats + C + cb);
-    const f32x4 a = inv * ld4(gamma + cb);
-    const f32x4 b = ld4(beta + cb) - mean * a;
-    pixel_loop(
-        (long long)blockIdx.x * rows + ty, pixels, (long long)gridDim.x * rows,
-        [&](long long q) {
-          V2 v;
-          v.a = ld4(x + (size_t)q * ldx + cb);
-          if (res) v.b = ld4(res + (size_t)q * ldres + cb);
-          return v;
-        },
-        [&](long long q, const V2& l) {
-          f32x4 v = bn_affine(l.a, a, b);
-          if (res) v += l.b;
+  for (int cb0 = blockIdx.y * lanes_c * 4; cb0 < C; cb0 += gridDim.y * lanes_c * 4) {  // uniform trip count: barriers inside
+    const int cb = cb0 + tx * 4;
+    const bool live = cb < C;
+    f32x4 cm = {0.f, 0.f, 0.f, 0.f};  // per-channel running max|.| (v_max_f32 with |.| modifier: one instruction per element, as amax4)
+    if (live) {
+      const f32x4 mean = ld4(stats + cb), inv = ld4(stats + C + cb);
+      const f32x4 a = inv * ld4(gamma + cb);
+      const f32x4 b = ld4(beta + cb) - mean * a;
+      pixel_loop(
+          (long long)blockIdx.x * rows + ty, pixels, (long long)gridDim.x * rows,
+          [&](long long q) {
+            V2 v;
+            v.a = ld4(x + (size_t)q * ldx + cb);
+            if (res) v.b = ld4(res + (size_t)q * ldres + cb);
+            return v;
+          },
+          [&](long long q, const V2& l) {
+            f32x4 v = bn_affine(l.a, a, b);
+            if (res) v += l.b;
 #pragma unroll
-          for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act, slope);
-          st4(y + (size_t)q * ldy + cb, v);
-          am = amax4(am, v);
-        });
+            for (int e = 0; e < 4; ++e) v[e] = apply_act(v[e], act, slope);
+            st4(y + (size_t)q * ldy + cb, v);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cm[e] = fmaxf(cm[e], fabsf(v[e]));
+          });
+      am = max(am, __float_as_uint(fmaxf(fmaxf(cm[0], cm[1]), fmaxf(cm[2], cm[3]))));
+    }
+    if (cmax_partial) channel_max_commit(cred, __builtin_bit_cast(u32x4, cm), tx, ty, lanes_c, rows, live, cmax_partial + (size_t)blockIdx.x * C + cb);
   }
   if (y_amax) amax_commit(am, y_amax, seen);
 }
@@ -312,42 +341,60 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const T* __restrict__ gy, in
                                                     const float* __restrict__ sums, int act, float slope,
                                                     T* __restrict__ gx, int ldgx, T* __restrict__ gres, int ldgres,
                                                     float* __restrict__ ggamma, float* __restrict__ gbeta, int accumulate, int lanes_c,
-                                                    int rows, float* __restrict__ gx_amax, const float* __restrict__ beta, float invn) {
+                                                    int rows, float* __restrict__ gx_amax, const float* __restrict__ beta, float invn,
+                                                    unsigned* __restrict__ cmax_partial,        // as bn_apply_kernel's, of gx
+                                                    unsigned* __restrict__ cmax_partial_res) {  // the same of gres (null without gres)
+  __shared__ u32x4 cred[256];
   const int tx = threadIdx.x % lanes_c, ty = threadIdx.x / lanes_c;
   unsigned am = 0;
   const unsigned seen = amax_peek(gx_amax);
-  for (int cb = (blockIdx.y * lanes_c + tx) * 4; cb < C; cb += gridDim.y * lanes_c * 4) {
-    const f32x4 mean = ld4(stats + cb), inv = ld4(stats + C + cb), gam = ld4(gamma + cb);
-    const f32x4 sg = ld4(sums + cb), sgx = ld4(sums + C + cb);
-    if (blockIdx.x == 0 && ty == 0) {  // one writer per channel: accumulation into a gradient slot is race free and ordered by the stream
-      if (ggamma) st4(ggamma + cb, accumulate ? ld4(ggamma + cb) + sgx : sgx);
-      if (gbeta) st4(gbeta + cb, accumulate ? ld4(gbeta + cb) + sg : sg);
+  for (int cb0 = blockIdx.y * lanes_c * 4; cb0 < C; cb0 += gridDim.y * lanes_c * 4) {  // uniform trip count: barriers inside
+    const int cb = cb0 + tx * 4;
+    const bool live = cb < C;
+    f32x4 cm = {0.f, 0.f, 0.f, 0.f}, cr = {0.f, 0.f, 0.f, 0.f};
+    if (live) {
+      const f32x4 mean = ld4(stats + cb), inv = ld4(stats + C + cb), gam = ld4(gamma + cb);
+      const f32x4 sg = ld4(sums + cb), sgx = ld4(sums + C + cb);
+      if (blockIdx.x == 0 && ty == 0) {  // one writer per channel: accumulation into a gradient slot is race free and ordered by the stream
+        if (ggamma) st4(ggamma + cb, accumulate ? ld4(ggamma + cb) + sgx : sgx);
+        if (gbeta) st4(gbeta + cb, accumulate ? ld4(gbeta + cb) + sg : sg);
+      }
+      const f32x4 k = gam * inv, mg = sg * invn, mgx = sgx * invn;
+      const bool recompute = y == nullptr && act != LHG_ACT_NONE;  // mask from x: v = x * a + b as bn_apply_kernel evaluated it
+      f32x4 fa = inv, fb = inv;
+      if (recompute) {
+        fa = inv * gam;
+        fb = ld4(beta + cb) - mean * fa;
+      }
+      pixel_loop(
+          (long long)blockIdx.x * rows + ty, pixels, (long long)gridDim.x * rows,
+          [&](long long q) {
+            V3 v;
+            v.a = ld4(gy + (size_t)q * ldgy + cb);
+            v.b = ld4(x + (size_t)q * ldx + cb);
+            if (act != LHG_ACT_NONE && !recompute) v.c = ld4(y + (size_t)q * ldy + cb);
+            return v;
+          },
+          [&](long long q, const V3& v) {
+            f32x4 g = v.a;
+            if (act != LHG_ACT_NONE) g *= act_grad4(recompute ? bn_affine(v.b, fa, fb) : v.c, act, slope);
+            if (gres) {
+              st4(gres + (size_t)q * ldgres + cb, g);
+              if (cmax_partial_res) {
+#pragma unroll
+                for (int e = 0; e < 4; ++e) cr[e] = fmaxf(cr[e], fabsf(g[e]));
+              }
+            }
+            const f32x4 xh = (v.b - mean) * inv;
+            const f32x4 o = k * (g - mg - xh * mgx);
+            st4(gx + (size_t)q * ldgx + cb, o);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) cm[e] = fmaxf(cm[e], fabsf(o[e]));
+          });
+      am = max(am, __float_as_uint(fmaxf(fmaxf(cm[0], cm[1]), fmaxf(cm[2], cm[3]))));
     }
-    const f32x4 k = gam * inv, mg = sg * invn, mgx = sgx * invn;
-    const bool recompute = y == nullptr && act != LHG_ACT_NONE;  // mask from x: v = x * a + b as bn_apply_kernel evaluated it
-    f32x4 fa = inv, fb = inv;
-    if (recompute) {
-      fa = inv * gam;
-      fb = ld4(beta + cb) - mean * fa;
-    }
-    pixel_loop(
-        (long long)blockIdx.x * rows + ty, pixels, (long long)gridDim.x * rows,
-        [&](long long q) {
-          V3 v;
-          v.a = ld4(gy + (size_t)q * ldgy + cb);
-          v.b = ld4(x + (size_t)q * ldx + cb);
-          if (act != LHG_ACT_NONE && !recompute) v.c = ld4(y + (size_t)q * ldy + cb);
-          return v;
-        },
-        [&](long long q, const V3& v) {
-          f32x4 g = v.a;
-          if (act != LHG_ACT_NONE) g *= act_grad4(recompute ? bn_affine(v.b, fa, fb) : v.c, act, slope);
-          if (gres) st4(gres + (size_t)q * ldgres + cb, g);
-          const f32x4 xh = (v.b - mean) * inv;
-          const f32x4 o = k * (g - mg - xh * mgx);
-          st4(gx + (size_t)q * ldgx + cb, o);
-          am = amax4(am, o);
-        });
+    if (cmax_partial) channel_max_commit(cred, __builtin_bit_cast(u32x4, cm), tx, ty, lanes_c, rows, live, cmax_partial + (size_t)blockIdx.x * C + cb);
+    if (cmax_partial_res) channel_max_commit(cred, __builtin_bit_cast(u32x4, cr), tx, ty, lanes_c, rows, live, cmax_partial_res + (size_t)blockIdx.x * C + cb);
   }
   if (gx_amax) amax_commit(am, gx_amax, seen);
 }
@@ -611,6 +658,9 @@ static inline int partial_blocks(long long pixels, int gy = 1) {
   return (int)std::min<long long>(std::max(1, 2048 / gy), std::max<long long>(1, pixels / 64));
 }
 
+// workgroups along the pixel axis of the apply kernels (bn_apply_kernel, bn_bwd_apply) = rows of their per-channel partial maxima
+static inline int apply_blocks(long long pixels, const ColMap& cm) { return grid_for((size_t)pixels, cm.rows * 4, std::max(1, 2048 / cm.gy)); }
+
 static bool aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; }
 
 }  // namespace lhg
@@ -674,14 +724,15 @@ static int bn_stats_impl(const float* x, long long pixels, int C, int ld, float*
 
 template <class T>
 static int bn_apply_impl(const float* x, int ldx, long long pixels, int C, const float* stats, const float* gamma, const float* beta,
-                         const float* res, int ldres, int act, float slope, float* y, int ldy, float* y_absmax, lhg_stream_t s) {
+                         const float* res, int ldres, int act, float slope, float* y, int ldy, float* y_absmax, lhg_stream_t s,
+                         float* cmax_partial = nullptr) {
   LHG_NHWC_OK(x, C, ldx, "bn_apply(x)");
   LHG_NHWC_OK(y, C, ldy, "bn_apply(y)");
   if (res) LHG_NHWC_OK(res, C, ldres, "bn_apply(res)");
   const ColMap cm = col_map(C);
-  const int nblk = grid_for((size_t)pixels, cm.rows * 4, std::max(1, 2048 / cm.gy));
+  const int nblk = apply_blocks(pixels, cm);
   hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(nblk, cm.gy), dim3(256), 0, as_stream(s), as_act<T>(x), ldx, pixels, C, stats, gamma, beta, as_act<T>(res),
-                     ldres, act, slope, as_act<T>(y), ldy, cm.lanes_c, cm.rows, y_absmax);
+                     ldres, act, slope, as_act<T>(y), ldy, cm.lanes_c, cm.rows, y_absmax, reinterpret_cast<unsigned*>(cmax_partial));
   return check_launch("bn_apply");
 }
 
@@ -691,7 +742,8 @@ template <class T>
 static int bn_backward_impl(const float* gy, int ldgy, const float* x, int ldx, const float* y, int ldy, long long pixels, int C,
                             const float* stats, const float* gamma, int act, float slope, float* gx, int ldgx, float* gres, int ldgres,
                             float* ggamma, float* gbeta, int accumulate, float* ws, float* gx_absmax, const float* beta, lhg_stream_t s,
-                            int phase = 0, float* sums_io = nullptr, float inv_count = 0.f) {
+                            int phase = 0, float* sums_io = nullptr, float inv_count = 0.f, float* cmax_partial = nullptr,
+                            float* cmax_partial_res = nullptr) {
   LHG_NHWC_OK(gy, C, ldgy, "bn_backward(gy)");
   LHG_NHWC_OK(x, C, ldx, "bn_backward(x)");
   if (phase != 1) LHG_NHWC_OK(gx, C, ldgx, "bn_backward(gx)");
@@ -710,10 +762,11 @@ static int bn_backward_impl(const float* gy, int ldgy, const float* x, int ldx, 
     hipLaunchKernelGGL(reduce_partials<2>, dim3((C + 31) / 32, 2), dim3(1024), 0, as_stream(s), ws, nblk, C, sums, 0);
   }
   if (phase != 1) {
-    const int nb2 = grid_for((size_t)pixels, cm.rows * 4, std::max(1, 2048 / cm.gy));
+    const int nb2 = apply_blocks(pixels, cm);
     const float invn = phase == 2 ? inv_count : 1.f / (float)pixels;
     hipLaunchKernelGGL((bn_bwd_apply<T>), dim3(nb2, cm.gy), dim3(256), 0, as_stream(s), as_act<T>(gy), ldgy, as_act<T>(x), ldx, as_act<T>(y), ldy, pixels, C, stats,
-                       gamma, sums, act, slope, as_act<T>(gx), ldgx, as_act<T>(gres), ldgres, ggamma, gbeta, accumulate, cm.lanes_c, cm.rows, gx_absmax, beta, invn);
+                       gamma, sums, act, slope, as_act<T>(gx), ldgx, as_act<T>(gres), ldgres, ggamma, gbeta, accumulate, cm.lanes_c, cm.rows, gx_absmax, beta, invn,
+                       reinterpret_cast<unsigned*>(cmax_partial), reinterpret_cast<unsigned*>(gres ? cmax_partial_res : nullptr));
   }
   return check_launch("bn_backward");
 }
@@ -803,6 +856,27 @@ int lhg_channel_absmax(const float* x, long long pixels, int C, int ld, float* o
   hipLaunchKernelGGL(channel_absmax_reduce, dim3((C + 31) / 32), dim3(1024), 0, as_stream(s), reinterpret_cast<const unsigned*>(ws), nblk, C,
                      reinterpret_cast<unsigned*>(out));
   return check_launch("channel_absmax");
+}
+long long lhg_chanmax_partial_rows(long long pixels, int C) { return pixels > 0 && C > 0 ? apply_blocks(pixels, col_map(C)) : 0; }
+int lhg_channel_absmax_finish(const float* partial, long long pixels, int C, float* out, lhg_stream_t s) {
+  LHG_REQUIRE(partial != nullptr && out != nullptr && pixels > 0 && C > 0 && C % 4 == 0, "channel_absmax_finish: missing buffer or bad shape");
+  hipLaunchKernelGGL(channel_absmax_reduce, dim3((C + 31) / 32), dim3(1024), 0, as_stream(s), reinterpret_cast<const unsigned*>(partial),
+                     apply_blocks(pixels, col_map(C)), C, reinterpret_cast<unsigned*>(out));
+  return check_launch("channel_absmax_finish");
+}
+int lhg_bn_apply_chanmax(const float* x, int ldx, long long pixels, int C, const float* stats, const float* gamma, const float* beta,
+                         const float* res, int ldres, int act, float slope, float* y, int ldy, float* y_absmax, float* y_chanmax_partial,
+                         lhg_stream_t s) {
+  LHG_REQUIRE(y_chanmax_partial != nullptr && !act_is_bf16(), "bn_apply_chanmax: fp32 tensors and a partial buffer (lhg_chanmax_partial_rows x C floats)");
+  return bn_apply_impl<float>(x, ldx, pixels, C, stats, gamma, beta, res, ldres, act, slope, y, ldy, y_absmax, s, y_chanmax_partial);
+}
+int lhg_bn_backward_chanmax(const float* gy, int ldgy, const float* x, int ldx, const float* y, int ldy, long long pixels, int C,
+                            const float* stats, const float* gamma, int act, float slope, float* gx, int ldgx, float* gres, int ldgres,
+                            float* ggamma, float* gbeta, int accumulate, float* ws, float* gx_absmax, const float* beta,
+                            float* gx_chanmax_partial, float* gres_chanmax_partial, lhg_stream_t s) {
+  LHG_REQUIRE(gx_chanmax_partial != nullptr && !act_is_bf16(), "bn_backward_chanmax: fp32 tensors and a partial buffer (lhg_chanmax_partial_rows x C floats)");
+  return bn_backward_impl<float>(gy, ldgy, x, ldx, y, ldy, pixels, C, stats, gamma, act, slope, gx, ldgx, gres, ldgres, ggamma, gbeta, accumulate, ws,
+                                 gx_absmax, beta, s, 0, nullptr, 0.f, gx_chanmax_partial, gres_chanmax_partial);
 }
 int lhg_bn_stats(const float* x, long long pixels, int C, int ld, float* stats, float* running_mean, float* running_var,
                  float momentum, float eps, float* ws, lhg_stream_t s) {

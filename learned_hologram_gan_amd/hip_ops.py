@@ -126,11 +126,12 @@ class AmaxShare:
     measures its output max-accumulates into ``slot`` and counts itself in; the buffer may be tagged with the slot only when all of
     its ``parts`` producers did (a producer that cannot measure — thin convolution, another GEMM mode — simply does not count)."""
 
-    __slots__ = ("slot", "parts", "writers")
+    __slots__ = ("slot", "parts", "writers", "cparts")
 
     def __init__(self, device, parts=2):
         self.slot = fused_absmax_slot(device)
         self.parts, self.writers = parts, 0
+        self.cparts = []  # (data_ptr of the slice, channels, partial maxima, pixels): producers that also left per-channel partials
 
     def writer(self):
         """The slot for a producer about to measure into it (None when the mode has no use for it)."""
@@ -141,6 +142,8 @@ class AmaxShare:
     def tag(self, buf):
         if self.slot is not None and self.writers >= self.parts:
             tag_absmax(buf, self.slot)
+        if self.cparts:  # the channels no producer covered are measured by a pass over that slice only (operand_chanmax)
+            tag_chanmax_source(buf, [((p - buf.data_ptr()) // 4, cc, part, px) for p, cc, part, px in self.cparts])
         return buf
 
 
@@ -467,23 +470,95 @@ def operand_absmax(t):
     return out
 
 
+_TIMING_FAKE_CHANMAX = os.environ.get("LHG_TIMING_FAKE_CHANMAX", "0") == "1"
+_FAKE_CMAX = {}
+
+
 def operand_chanmax(t):
-    """Per-channel max|t| of an NHWC fp32 operand of a WEIGHT-GRADIENT GEMM as a (C,) device tensor (lhg_channel_absmax on the current
-    stream) — the per-channel scales of the "fp32_split_f16" mode (the contraction runs over pixels, so a scale per channel factors
-    out of the sum exactly); None in every other mode.  Cached on the tensor for the stream it was measured on (the input of a
-    ResidualBlock feeds two convolutions, whose weight gradients run on the same stream)."""
+    """Per-channel max|t| (or an upper bound) of an NHWC fp32 operand of a WEIGHT-GRADIENT GEMM as a (C,) device tensor — the
+    per-channel scales of the "fp32_split_f16" mode (the contraction runs over pixels, so a scale per channel factors out of the sum
+    exactly); None in every other mode.  Sources, cheapest first: the value cached on the tensor (or on the tensor it aliases) for this
+    stream; per-workgroup partial maxima left by the kernel that wrote the tensor (tag_chanmax_source: one small launch per part);
+    lhg_channel_absmax, a pass over the tensor, for whatever channels no producer covered."""
     if _mode() != _F16_SPLIT:
         return None
+    if _TIMING_FAKE_CHANMAX:  # timing experiments only: what the step costs without the per-channel maxima passes
+        key = (t.shape[-1], t.device)
+        if key not in _FAKE_CMAX:
+            _FAKE_CMAX[key] = torch.full((t.shape[-1],), 64.0, dtype=torch.float32, device=t.device)
+        return _FAKE_CMAX[key]
     st = stream_ptr()
-    known = t.__dict__.get("_lhg_cmax")
+    root = t.__dict__.get("_lhg_root", t)  # the tensor t is an alias of (Conv2dSharedInputFn's second output): one cache for both
+    if root is not t and not (root.data_ptr() == t.data_ptr() and root.shape == t.shape and root.stride() == t.stride() and root._version == t._version):
+        root = t
+    known = root.__dict__.get("_lhg_cmax")
     if known is not None and known[0] == t._version and known[1] == st:
         return known[2]
     p, N, H, W, Cc, ld = nhwc(t)
+    pixels = N * H * W
     out = torch.empty((Cc,), dtype=torch.float32, device=t.device)
-    ws = torch.empty((2048 * Cc,), dtype=torch.float32, device=t.device)
-    call("lhg_channel_absmax", p, N * H * W, Cc, ld, ptr(out), ptr(ws), st)
-    t.__dict__["_lhg_cmax"] = (t._version, st, out)
+    src = root.__dict__.get("_lhg_cmax_src")
+    parts = sorted(src[1], key=lambda q: q[0]) if (src is not None and src[0] == t._version and _FUSED_CHANMAX) else []
+    cur = torch.cuda.current_stream(t.device)
+
+    def measure(c0, c1):  # a pass over channels [c0, c1) of t
+        CHANMAX_STATS["pass"] += 1
+        CHANMAX_STATS["pass_bytes"] += pixels * min(ld, 32 * ((c1 - c0 + 31) // 32 + 1)) * 4
+        if CHANMAX_PASS_LOG is not None:  # diagnostics (tools/chanmax_sites.py): who still pays a pass
+            import traceback
+            CHANMAX_PASS_LOG.append(((N, H, W, c1 - c0, ld), [f"{f.name}:{f.lineno}" for f in traceback.extract_stack(limit=8)[:-2]], type(t.grad_fn).__name__))
+        ws = torch.empty((2048 * (c1 - c0),), dtype=torch.float32, device=t.device)
+        call("lhg_channel_absmax", p + 4 * c0, pixels, c1 - c0, ld, out.data_ptr() + 4 * c0, ptr(ws), st)
+
+    at = 0
+    for off, cc, partial, grid_pixels in parts:
+        if off < at or off + cc > Cc or off % 4:
+            continue
+        if off > at:
+            measure(at, off)
+        # the kernel that wrote these channels left per-workgroup partial maxima: one small launch instead of a pass.  The caller's
+        # stream is ordered behind that kernel (it reads t).
+        CHANMAX_STATS["fused"] += 1
+        partial.record_stream(cur)
+        call("lhg_channel_absmax_finish", ptr(partial), grid_pixels, cc, out.data_ptr() + 4 * off, st)
+        at = off + cc
+    if at < Cc:
+        measure(at, Cc)
+    root.__dict__["_lhg_cmax"] = (t._version, st, out)
     return out
+
+
+CHANMAX_PASS_LOG = None
+CHANMAX_STATS = {"fused": 0, "pass": 0, "pass_bytes": 0}  # parts finished from a producer's partials / measured by a pass of their own
+_FUSED_CHANMAX = os.environ.get("LHG_FUSED_CHANMAX", "1") != "0"
+
+
+def chanmax_partial_for(pixels, Cc, device):
+    """Buffer for the per-workgroup partial maxima a BatchNorm kernel leaves of what it writes (None when nobody will ask: not the
+    fp16-split mode, bf16 storage)."""
+    if _mode() != _F16_SPLIT or _ACT_DTYPE != torch.float32 or not _FUSED_CHANMAX or Cc % 4:
+        return None
+    rows = int(native.load().lhg_chanmax_partial_rows(pixels, Cc))
+    return torch.empty((rows * Cc,), dtype=torch.float32, device=device)
+
+
+def tag_chanmax_source(t, parts):
+    """Remember where per-channel bounds of t come from: parts = [(first channel, channels, partial buffer, pixels of the producer's
+    grid)], each finished by lhg_channel_absmax_finish(partial, pixels, channels) when a weight-gradient GEMM asks (operand_chanmax)."""
+    if parts:
+        t.__dict__["_lhg_cmax_src"] = (t._version, list(parts))
+    return t
+
+
+def _inherit_chanmax(dst, src, alias=False):
+    """dst's elements are a subset of src's per channel (max-pooling, an alias): src's per-channel bounds hold for dst.  ``alias``: dst IS
+    src (same memory): they also share the finished values."""
+    known = src.__dict__.get("_lhg_cmax_src")
+    if known is not None and known[0] == src._version:
+        dst.__dict__["_lhg_cmax_src"] = (dst._version, known[1])
+    if alias:
+        dst.__dict__["_lhg_root"] = src.__dict__.get("_lhg_root", src)
+    return dst
 
 
 def fused_absmax_slot(device):
@@ -817,7 +892,7 @@ def conv2d_shared_input(x, w, bias, stride, out):
     if not FUSE_SKIP_GRAD or not (torch.is_grad_enabled() and x.requires_grad):
         return Conv2dFn.apply(x, w, bias, stride, out), x
     y, xs = Conv2dSharedInputFn.apply(x, w, bias, stride, out)
-    return y, _inherit_absmax(xs, x)
+    return y, _inherit_chanmax(_inherit_absmax(xs, x), x, alias=True)
 
 
 class Conv2dInputGradFn(TrackedFunction):
@@ -875,6 +950,9 @@ class Conv2dInputGradFn(TrackedFunction):
         return grads[:n]
 
 
+_TIMING_SKIP_WGRAD = os.environ.get("LHG_TIMING_SKIP_WGRAD", "0") == "1"
+
+
 def conv2d_weight_grad_raw(x, gy, wshape, stride, slot=None, x_amax=None, gy_amax=None):
     """gw (OIHW) = sum over pixels of x (gathered) outer gy; no autograd.  With ``slot`` the slab reduction accumulates straight into
     it (the parameter's view of the flat gradient buffer) and nothing is returned."""
@@ -891,6 +969,8 @@ def conv2d_weight_grad_raw(x, gy, wshape, stride, slot=None, x_amax=None, gy_ama
             return gw
         slot.add_(gw)
         return None
+    if _TIMING_SKIP_WGRAD:  # timing experiments only (tools/cpu_slack.py): what the step costs without the MFMA weight gradients
+        return None if slot is not None else torch.zeros(tuple(wshape), dtype=torch.float32, device=x.device)
     gyp = _padded_gy(gy, 4)
     px, N, H, W, Cx, ldx = nhwc(x)
     pg, _, _, _, Cg, ldg = nhwc(gyp)
@@ -1177,9 +1257,19 @@ class BatchNormTrainFn(TrackedFunction):
         if res is not None:
             pres, _, _, _, _, ldres = nhwc(res)
         y_amax = _out_amax(out, x.device)  # max|y| measured by the kernel that writes y: the next conv's GEMMs need no pass of their own
-        call("lhg_bn_apply", px, ldx, pixels, Cc, ptr(stats), ptr(gamma), ptr(beta), pres, ldres, act, float(slope), py, ldy, ptr(y_amax),
-             stream_ptr())
+        # the weight gradient of the conv that reads y wants per-channel maxima of it: partials on the way out (training passes only)
+        part = chanmax_partial_for(pixels, Cc, x.device) if any(ctx.needs_input_grad) else None
+        if part is not None:
+            call("lhg_bn_apply_chanmax", px, ldx, pixels, Cc, ptr(stats), ptr(gamma), ptr(beta), pres, ldres, act, float(slope), py, ldy,
+                 ptr(y_amax), ptr(part), stream_ptr())
+        else:
+            call("lhg_bn_apply", px, ldx, pixels, Cc, ptr(stats), ptr(gamma), ptr(beta), pres, ldres, act, float(slope), py, ldy, ptr(y_amax),
+                 stream_ptr())
         tag_absmax(y, y_amax)
+        if part is not None:
+            tag_chanmax_source(y, [(0, Cc, part, pixels)])
+            if isinstance(out, OutSlot) and out.share is not None:
+                out.share.cparts.append((y.data_ptr(), Cc, part, pixels))
         ctx.save_for_backward(x, y, gamma, stats)
         ctx.act, ctx.slope, ctx.has_res = act, slope, res is not None
         ctx.beta = beta if ctx.needs_input_grad[2] else None
@@ -1228,10 +1318,21 @@ def bn_backward_raw(gy, x, y, gamma, stats, act, slope, want_res, ggamma, gbeta,
              act, float(slope), ptr(gx), Cc, ptr(gres), Cc, ptr(gx_amax), ptr(beta), stream_ptr())
         tag_absmax(gx, gx_amax)
         return gx, gres
-    call("lhg_bn_backward", pg, ldg, px, ldx, py, ldy, N * H * W, Cc, ptr(stats), ptr(gamma), act, float(slope),
-         ptr(gx), Cc, ptr(gres), Cc, ptr(ggamma), ptr(gbeta), int(accumulate), ptr(_bn_ws(Cc, gy.device)), ptr(gx_amax), ptr(beta),
-         stream_ptr())
+    part = chanmax_partial_for(N * H * W, Cc, gy.device)  # gx is the gy operand of the preceding conv's weight gradient
+    part_res = chanmax_partial_for(N * H * W, Cc, gy.device) if (want_res and part is not None) else None  # gres: of the shortcut conv's
+    if part is not None:
+        call("lhg_bn_backward_chanmax", pg, ldg, px, ldx, py, ldy, N * H * W, Cc, ptr(stats), ptr(gamma), act, float(slope),
+             ptr(gx), Cc, ptr(gres), Cc, ptr(ggamma), ptr(gbeta), int(accumulate), ptr(_bn_ws(Cc, gy.device)), ptr(gx_amax), ptr(beta),
+             ptr(part), ptr(part_res), stream_ptr())
+    else:
+        call("lhg_bn_backward", pg, ldg, px, ldx, py, ldy, N * H * W, Cc, ptr(stats), ptr(gamma), act, float(slope),
+             ptr(gx), Cc, ptr(gres), Cc, ptr(ggamma), ptr(gbeta), int(accumulate), ptr(_bn_ws(Cc, gy.device)), ptr(gx_amax), ptr(beta),
+             stream_ptr())
     tag_absmax(gx, gx_amax)
+    if part is not None:
+        tag_chanmax_source(gx, [(0, Cc, part, N * H * W)])
+    if part_res is not None:
+        tag_chanmax_source(gres, [(0, Cc, part_res, N * H * W)])
     return gx, gres
 
 
@@ -1314,7 +1415,7 @@ class MaxPool2x2Fn(Function):
         y = new_nhwc(N, H // 2, W // 2, Cc, x.device)
         call("lhg_maxpool2x2_forward", px, N, H, W, Cc, ldx, ptr(y), Cc, stream_ptr())
         ctx.save_for_backward(x)
-        return _inherit_absmax(y, x)  # max|pool(x)| <= max|x|: any upper bound is a valid tensor scale
+        return _inherit_chanmax(_inherit_absmax(y, x), x)  # max|pool(x)| <= max|x|, per channel too: any upper bound is a valid scale
 
     @staticmethod
     def backward(ctx, gy):

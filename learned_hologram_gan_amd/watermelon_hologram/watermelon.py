@@ -142,7 +142,9 @@ class watermelon:
     def compute_gradient_penalty(self, real_samples, fake_samples, alpha=None):
         """ref: watermelon.py:458-477."""
         if alpha is None:
-            alpha = torch.rand(real_samples.size(0), 1, 1, 1).to(self.device)
+            alpha = torch.rand(real_samples.size(0), 1, 1, 1)  # the reference's draw: CPU generator
+            # (pinned staging: a pageable copy would make the host wait for everything queued on the stream)
+            alpha = alpha.pin_memory().to(self.device, non_blocking=True) if real_samples.is_cuda else alpha.to(self.device)
         interpolates = (alpha * real_samples + ((1 - alpha) * fake_samples)).requires_grad_(True)
         d_interpolates = self.discriminator(interpolates)
         # only d D / d x^ is asked for: the critic's parameter gradients of THIS pass would be computed and dropped by the engine

@@ -207,6 +207,45 @@ def test_channel_absmax_matches_torch(ops):
         assert torch.equal(out, t[:, :C].abs().amax(dim=0)), (C, ld, pixels)
 
 
+def test_bn_kernels_leave_the_per_channel_maxima_of_what_they_write(ops):
+    """lhg_bn_apply_chanmax / lhg_bn_backward_chanmax + lhg_channel_absmax_finish (ABI 5): the per-channel maxima of y / gx, bit for bit
+    those of a pass over the tensor, and y / gx / the parameter gradients bit-identical to the plain calls'."""
+    from learned_hologram_gan_amd.native import call, load, ptr, stream_ptr
+
+    lib = load()
+    for C, pixels, act in ((64, 4 * 96 * 96, 1), (256, 4 * 24 * 24, 2), (1024, 4 * 6 * 6, 1), (32, 1000, 0), (2048, 37, 2)):
+        torch.manual_seed(C)
+        x = torch.randn((pixels, C), device=DEV) * torch.logspace(-3, 2, C, device=DEV)
+        gamma, beta = torch.randn(C, device=DEV), torch.randn(C, device=DEV)
+        stats = torch.cat((x.mean(0), (x.var(0, unbiased=False) + 1e-5).rsqrt()))
+        rows = int(lib.lhg_chanmax_partial_rows(pixels, C))
+        assert 1 <= rows <= 2048
+        y0, y1 = torch.empty_like(x), torch.empty_like(x)
+        part = torch.full((rows * C,), float("nan"), device=DEV)
+        call("lhg_bn_apply", ptr(x), C, pixels, C, ptr(stats), ptr(gamma), ptr(beta), None, 0, act, 0.2, ptr(y0), C, None, stream_ptr())
+        call("lhg_bn_apply_chanmax", ptr(x), C, pixels, C, ptr(stats), ptr(gamma), ptr(beta), None, 0, act, 0.2, ptr(y1), C, None, ptr(part), stream_ptr())
+        out = torch.full((C,), 123.0, device=DEV)
+        call("lhg_channel_absmax_finish", ptr(part), pixels, C, ptr(out), stream_ptr())
+        assert torch.equal(y0, y1) and torch.equal(out, y0.abs().amax(dim=0)), (C, pixels)
+        gy = torch.randn((pixels, C), device=DEV) * torch.logspace(2, -4, C, device=DEV)
+        res = []
+        for fused in (False, True):
+            gx, gr, gg, gb = torch.empty_like(x), torch.empty_like(x), torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+            ws = torch.empty((8192 * C,), device=DEV)
+            args = [ptr(gy), C, ptr(x), C, ptr(y0), C, pixels, C, ptr(stats), ptr(gamma), act, 0.2, ptr(gx), C, ptr(gr), C, ptr(gg), ptr(gb), 0, ptr(ws), None, ptr(beta)]
+            if fused:
+                part.fill_(float("nan"))
+                part_res = torch.full_like(part, float("nan"))
+                call("lhg_bn_backward_chanmax", *args, ptr(part), ptr(part_res), stream_ptr())
+                for p_, t_ in ((part, gx), (part_res, gr)):
+                    call("lhg_channel_absmax_finish", ptr(p_), pixels, C, ptr(out), stream_ptr())
+                    assert torch.equal(out, t_.abs().amax(dim=0)), (C, pixels)
+            else:
+                call("lhg_bn_backward", *args, stream_ptr())
+            res.append((gx, gr, gg, gb))
+        assert all(torch.equal(a, b) for a, b in zip(*res)), (C, pixels)
+
+
 def test_default_gemm_mode_and_env_override():
     """The library starts in the fp32-faithful two-term fp16 split mode unless LHG_CONV_PRECISION names another one (read at load time)."""
     import os
