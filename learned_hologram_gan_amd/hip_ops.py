@@ -485,7 +485,7 @@ def operand_chanmax(t):
     if _TIMING_FAKE_CHANMAX:  # timing experiments only: what the step costs without the per-channel maxima passes
         key = (t.shape[-1], t.device)
         if key not in _FAKE_CMAX:
-            _FAKE_CMAX[key] = torch.full((t.shape[-1],), 64.0, dtype=torch.float32, device=t.device)
+            _FAKE_CMAX[key] = torch.full((t.shape[-1],), float(os.environ.get("LHG_TIMING_FAKE_CHANMAX_VALUE", "64")), dtype=torch.float32, device=t.device)
         return _FAKE_CMAX[key]
     st = stream_ptr()
     root = t.__dict__.get("_lhg_root", t)  # the tensor t is an alias of (Conv2dSharedInputFn's second output): one cache for both
