@@ -540,6 +540,48 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const PackBatch b) {  /
   }
 }
 
+// The same panels from 32 x 32 (row, k) tiles staged through LDS: the source w[d0][d1][t] is contiguous over (d1, t), so a tile is 32
+// runs of 32 * T floats — every byte of every line used once — where pack_batch_kernel above reads with a stride of T floats (row-major
+// panels) or D1 * T floats (input-gradient panels), once per tap: 9 passes over a weight that does not fit an XCD's L2.  The stores are
+// 64-byte runs per (tap, row, plane).  Same values as pack_batch_kernel (one multiply, two roundings per element).
+constexpr int PACK_TILE_TMAX = 9;
+__global__ __launch_bounds__(256) void pack_batch_tiled_kernel(const PackBatch b) {
+  __shared__ float tile[32][32 * PACK_TILE_TMAX + 1];
+  const int i = pack_batch_find(b, blockIdx.x, false);
+  const PackItem& it = b.it[i];
+  const unsigned nblk = (i + 1 < b.n ? b.it[i + 1].blk0 : b.blocks) - it.blk0;
+  const int T = it.T, kt = it.k_pad / 32, rt = it.rows_pad / 32, kch = it.k_pad / 32;
+  const float sc = split_scale(__uint_as_float(*it.amax));
+  const int run = 32 * T;  // floats per contiguous source run
+  for (unsigned tl = blockIdx.x - it.blk0; tl < (unsigned)(kt * rt); tl += nblk) {
+    const int row0 = (int)(tl / kt) * 32, k0 = (int)(tl % kt) * 32;
+    // segment g: row-major panels: row row0 + g, its k0 .. k0 + 31 (d1) and all taps; input-gradient panels: k = k0 + g, rows row0 .. + 31 (d1)
+    for (int e = threadIdx.x; e < 32 * run; e += 256) {
+      const int g = e / run, o = e - g * run;
+      const int d0 = it.rows_from_d0 ? row0 + g : k0 + g;
+      const int d1 = (it.rows_from_d0 ? k0 : row0) + o / T;
+      tile[g][o] = (d0 < it.D0 && d1 < it.D1) ? it.w[((size_t)d0 * it.D1 + (it.rows_from_d0 ? k0 : row0)) * T + o] * sc : 0.f;
+    }
+    __syncthreads();
+    // outputs: (t, row, k pair): 16 lanes cover the 32 k of one (t, row): two 64-byte runs (plane 0 / plane 1)
+    for (int e = threadIdx.x; e < T * 32 * 16; e += 256) {
+      const int kp = e & 15, r = (e >> 4) & 31, t = e >> 9;
+      float v[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const int kl = 2 * kp + q;
+        v[q] = it.rows_from_d0 ? tile[r][kl * T + t] : tile[kl][r * T + t];
+      }
+      const _Float16 h00 = (_Float16)v[0], h01 = (_Float16)v[1];
+      typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+      _Float16* out = it.dst + ((((size_t)t * it.rows_pad + row0 + r) * kch + k0 / 32) * 2) * 32 + 2 * kp;
+      *reinterpret_cast<f16x2*>(out) = f16x2{h00, h01};
+      *reinterpret_cast<f16x2*>(out + 32) = f16x2{(_Float16)(v[0] - (float)h00), (_Float16)(v[1] - (float)h01)};
+    }
+    __syncthreads();
+  }
+}
+
 // grad[d0][d1][t] = sum_s slabs[s][t][m][n].  Block = 64 consecutive outputs (n fastest: coalesced slab reads) x 4 slab
 // slices; each thread sums every 4th slab, then the slices are combined through LDS.
 template <int LANES>  // outputs per block; 256 / LANES slab slices
@@ -1274,6 +1316,8 @@ int lhg_pack_weights(const lhg_pack_item* items, int n, lhg_stream_t s) {
     PackBatch b;
     b.n = std::min(PACK_BATCH, n - first);
     unsigned blk = 0, ablk = 0;
+    bool tiled = true;  // every weight of the batch has at most PACK_TILE_TMAX taps (3 x 3): the LDS-tiled pack
+    for (int i = 0; i < b.n; ++i) tiled = tiled && items[first + i].KH * items[first + i].KW <= PACK_TILE_TMAX;
     for (int i = 0; i < b.n; ++i) {
       const lhg_pack_item& q = items[first + i];
       const int rows = q.rows_from_d0 ? q.D0 : q.D1, K = q.rows_from_d0 ? q.D1 : q.D0;
@@ -1288,14 +1332,16 @@ int lhg_pack_weights(const lhg_pack_item* items, int n, lhg_stream_t s) {
       it.D0 = q.D0; it.D1 = q.D1; it.T = q.KH * q.KW; it.rows_from_d0 = q.rows_from_d0; it.rows_pad = q.rows_pad; it.k_pad = q.k_pad;
       it.blk0 = blk;
       it.ablk0 = ablk;
-      blk += (unsigned)std::min<size_t>((total + 1023) / 1024, 16384);  // 4 elements per thread (the largest weight sets the launch's duration)
+      blk += tiled ? (unsigned)std::min<size_t>((size_t)(q.rows_pad / 32) * (q.k_pad / 32), 16384)  // one 32 x 32 tile (all taps) per workgroup
+                   : (unsigned)std::min<size_t>((total + 1023) / 1024, 16384);                    // 4 elements per thread
       ablk += (unsigned)std::min<size_t>((elems + 2047) / 2048, 2048);
     }
     b.blocks = blk;
     b.ablocks = ablk;
     hipLaunchKernelGGL(pack_batch_zero_kernel, dim3(1), dim3(PACK_BATCH), 0, as_stream(s), b);
     hipLaunchKernelGGL(pack_batch_absmax_kernel, dim3(ablk), dim3(256), 0, as_stream(s), b);
-    hipLaunchKernelGGL(pack_batch_kernel, dim3(blk), dim3(256), 0, as_stream(s), b);
+    if (tiled) hipLaunchKernelGGL(pack_batch_tiled_kernel, dim3(blk), dim3(256), 0, as_stream(s), b);
+    else hipLaunchKernelGGL(pack_batch_kernel, dim3(blk), dim3(256), 0, as_stream(s), b);
   }
   return check_launch("pack_weights");
 }
