@@ -20,6 +20,8 @@ Prints ONE JSON line (rank 0).
   the GPU); `roofline.isolated` repeats it with the second stream off (the kernel's own duration — what rocprofv3 --kernel-trace
   shows, since the profiler serialises dispatches).
 * `secondary` carries north_star's second target: 4K (3840x2160) batch-1 inference + propagation of the hologram to 8 planes.
+* `reference_cli_default_step` (informational, N = 1): the same data through the step as the reference's trainingModel.py configures it
+  (five critic updates per generator update, perceptual term 0.1) — not the configuration BASELINE.json's metric is quoted on.
 * `cpu_baseline` times the CPU oracle (a port of the reference step, oracle/step.py) on the host cores: 1 warm-up + median of 3
   runs of a bounded sample.
 """
@@ -66,6 +68,7 @@ def parse():
     ap.add_argument("--cpu-batch", type=int, default=0, help="frames per CPU step (0 = same as --batch)")
     ap.add_argument("--secondary", type=int, default=1, help="0 skips the 4K inference leg (north_star's second target)")
     ap.add_argument("--profile-steps", type=int, default=5, help="steps of each instrumented pass behind `roofline`")
+    ap.add_argument("--cli-default", type=int, default=1, help="0 skips the informational timing of the reference CLI's default step (d_ratio 5, perceptual 0.1)")
     ap.add_argument("--other-modes", type=int, default=1, help="0 skips the informational timing of the other GEMM formulations")
     ap.add_argument("--graph", type=int, default=0, help="infer mode: replay a captured hipGraph instead of eager launches")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
@@ -444,6 +447,28 @@ def main():
                                               "three MFMA products (max-rel error ~5e-6 per op instead of ~1e-6).  bf16_storage: bf16 NHWC activations "
                                               "and bf16 GEMM operands, fp32 accumulation/BN statistics/FFT/Adam (`--dtype bf16`).  None is the headline mode")
 
+    # ---- informational: the step the reference's training CLI runs by default (trainingModel.py:77-95: five critic updates per generator
+    # update, perceptual term 0.1 on VGG19 features — random-init weights here: no download), same data shape.  Not the headline config.
+    cli = None
+    if args.mode == "train" and not bf16 and world == 1 and args.cli_default:
+        del W
+        torch.cuda.empty_cache()
+        keep = (args.perceptual, args.d_ratio)
+        args.perceptual, args.d_ratio = 0.1, 5
+        W = build_trainer()
+        args.perceptual, args.d_ratio = keep
+        for _ in range(2):
+            W.train_step(rgbd, tamp, tphs)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(3):
+            W.train_step(rgbd, tamp, tphs)
+        sync()
+        ms = (time.perf_counter() - t0) / 3 * 1e3
+        cli = {"ms_per_step": round(ms, 3), "value": round(B / (ms / 1e3), 3), "unit": "frames/s",
+               "config": {"workload": f"{args.rows}x{args.cols}x3 bs={B} train step as trainingModel.py configures it: d_ratio=5, perceptual_loss_weight=0.1 "
+                                      "(VGG19 features, random-init weights), lambda_gp=10; informational"}}
+
     # ---- free the trainer, then north_star's second target (4K bs=1 inference + 8 planes), replicas only
     sec = None
     if args.secondary and not bf16:
@@ -451,6 +476,8 @@ def main():
         torch.cuda.empty_cache()
         sec = secondary_4k(native, dev, world, sync, mfma_peak, peak_note)
     if rank == 0:
+        if cli is not None:
+            out["reference_cli_default_step"] = cli
         if sec is not None:
             out["secondary"] = sec
         if world == 1 and args.cpu_baseline:

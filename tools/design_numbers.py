@@ -89,6 +89,9 @@ def main():
         if b.get("secondary"):
             s = b["secondary"]
             out.append(f"| 4K (configs[3]) | {s['ms_per_frame']:.1f} ms/frame = {s['value']:.1f} frames/s; gather-GEMM {s['roofline']['achieved']:.0f} TFLOP/s = {s['roofline']['frac']:.3f} |")
+        if b.get("reference_cli_default_step"):
+            c = b["reference_cli_default_step"]
+            out.append(f"| reference CLI's default step (d_ratio 5, perceptual 0.1; informational) | {c['ms_per_step']:.1f} ms/step = {c['value']:.1f} frames/s |")
         if b.get("cpu_baseline"):
             c = b["cpu_baseline"]
             out.append(f"| CPU baseline ({c['kind']}, {c['cores']} threads) | {c['value']:.3f} frames/s — {c['sample']} |")

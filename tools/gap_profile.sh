@@ -2,7 +2,7 @@
 # GPU box: idle time between consecutive kernels of each HIP queue over the steady steps of the bench (rocprofv3 kernel trace).
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/gaps; rm -rf $out; mkdir -p $out
-rocprofv3 --kernel-trace --output-format csv -d $out/kt -o trace -- python3 bench.py --steps 6 --warmup 3 --cpu-baseline 0 --secondary 0 --other-modes 0 --profile-steps 0 > $out/kt.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $out/kt -o trace -- python3 bench.py --steps 6 --warmup 3 --cpu-baseline 0 --secondary 0 --other-modes 0 --cli-default 0 --profile-steps 0 > $out/kt.log 2>&1
 python3 - <<'PY'
 import csv, glob, collections
 f = glob.glob("gpurun_out/gaps/kt/**/*kernel_trace.csv", recursive=True)[0]

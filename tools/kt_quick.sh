@@ -4,7 +4,7 @@ name=$1; shift
 cd /tmp && export TMPDIR=/tmp && cd $GRAFT_REPO_ROOT
 out=gpurun_out/kt_$name
 rm -rf $out; mkdir -p $out
-rocprofv3 --kernel-trace --output-format csv -d $out/kt -o trace -- python3 bench.py --steps 6 --warmup 3 --cpu-baseline 0 --secondary 0 --other-modes 0 --profile-steps 1 "$@" > $out/kt.log 2>&1
+rocprofv3 --kernel-trace --output-format csv -d $out/kt -o trace -- python3 bench.py --steps 6 --warmup 3 --cpu-baseline 0 --secondary 0 --other-modes 0 --cli-default 0 --profile-steps 1 "$@" > $out/kt.log 2>&1
 python3 tools/steady_profile.py $(find $out/kt -name "*kernel_trace.csv" | head -1) 4 $out/steady.csv > $out/steady.txt
 t=$(find $out/kt -name "*kernel_trace.csv" | head -1)
 head -1 $t > $out/bn_trace.csv
