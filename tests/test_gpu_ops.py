@@ -246,6 +246,37 @@ def test_bn_kernels_leave_the_per_channel_maxima_of_what_they_write(ops):
         assert all(torch.equal(a, b) for a, b in zip(*res)), (C, pixels)
 
 
+def test_wgrad_slab_reduce_is_the_documented_sum_bit_for_bit(ops):
+    """lhg_wgrad_reduce on nine-tap slabs:
+    grad[d0][d1][t] (+)= the four (small weights: sixteen) interleaved slab slices summed in ascending order and combined in order — emulated here with fp32 torch
+    adds, so the comparison is bit for bit; both orientations (conv weights: m is d1), ragged extents, accumulate on and off."""
+    from learned_hologram_gan_amd.native import call, ptr, stream_ptr
+
+    for (D0, D1, m_is_d1, S) in ((128, 64, 1, 7), (96, 80, 1, 4), (100, 90, 0, 3), (256, 128, 1, 1), (72, 130, 0, 9), (32, 16, 1, 5)):
+        M, Nn = (D1, D0) if m_is_d1 else (D0, D1)
+        m_pad, n_pad = (M + 63) // 64 * 64, (Nn + 63) // 64 * 64
+        torch.manual_seed(D0 + S)
+        slabs = torch.randn((S, 9, m_pad, n_pad), device=DEV) * torch.logspace(-3, 3, S, device=DEV).view(S, 1, 1, 1)
+        total = 9 * D0 * D1
+        slices = 16 if (total * 4 < S * 64 or total < 65536) else 4   # the small-weight kernel spends 16 threads per output on the slab axis
+        parts = []
+        for k in range(slices):
+            a = torch.zeros((9, m_pad, n_pad), device=DEV)
+            for s_ in range(k, S, slices):
+                a = a + slabs[s_]
+            parts.append(a)
+        v = torch.zeros_like(parts[0])
+        for a in parts:
+            v = v + a
+        v = v[:, :M, :Nn]                                           # [t][m][n]
+        want = (v.permute(2, 1, 0) if m_is_d1 else v.permute(1, 2, 0)).contiguous()  # [d0][d1][t]
+        for accumulate in (0, 1):
+            grad = torch.full((D0, D1, 3, 3), 0.5, device=DEV)
+            call("lhg_wgrad_reduce", ptr(slabs), S, 9, m_pad, n_pad, ptr(grad), D0, D1, m_is_d1, accumulate, stream_ptr())
+            expect = want.reshape(D0, D1, 3, 3) + (0.5 if accumulate else 0.0)
+            assert torch.equal(grad, expect), (D0, D1, m_is_d1, S, accumulate, (grad - expect).abs().max().item())
+
+
 def test_default_gemm_mode_and_env_override():
     """The library starts in the fp32-faithful two-term fp16 split mode unless LHG_CONV_PRECISION names another one (read at load time)."""
     import os
