@@ -994,6 +994,37 @@ def test_train_step_repeats_bit_for_bit():
             assert torch.equal(a, b)
 
 
+def test_bench_size_training_repeats_bit_for_bit():
+    """The headline workload (384 x 384, batch 4, 1024-point transforms): ten optimiser steps from the same state, twice — every step's seven
+    losses and the final weights of both models are bit-identical.  This is the configuration in which the angular-spectrum kernels run
+    beside MFMA weight-gradient workgroups of the second stream in ONE process, the condition of DESIGN.md §5's non-repeat."""
+    from learned_hologram_gan_amd.watermelon_hologram.watermelon import watermelon
+
+    def run():
+        torch.manual_seed(11)
+        W = watermelon(filter_radius_coefficient=0.45, pad_size=320, distance_stack=torch.linspace(-4e-4, 0.0, 21)[:-1], input_shape=(1, 4, 384, 384))
+        W.generator.to(DEV).train()
+        W.discriminator.to(DEV).train()
+        W.configure(1, 0.0, 1, 1e-3, 1e-1, 1e-3, 1e-3, 1, 10)
+        g = torch.Generator().manual_seed(5)
+        rgbd, tamp, tphs = (torch.rand((4, c, 384, 384), generator=g).to(DEV) for c in (4, 3, 3))
+        alphas = [torch.rand((4, 1, 1, 1), generator=g).to(DEV)]
+        losses = []
+        for k in range(10):
+            W.train_step(rgbd, tamp, tphs, plane_indices=torch.tensor([(3 * k) % 20, (7 * k + 1) % 20, 5, 11]), gp_alphas=alphas)
+            losses.append(W.train_losses_tensor.clone())
+        torch.cuda.synchronize()
+        flat = [torch.cat([p.detach().reshape(-1) for p in m.parameters()]).clone() for m in (W.generator, W.discriminator)]
+        del W
+        return torch.stack(losses), flat
+
+    la, fa = run()
+    lb, fb = run()
+    assert torch.isfinite(la).all()
+    assert torch.equal(la, lb), (la - lb).abs().max(dim=1).values
+    assert torch.equal(fa[0], fb[0]) and torch.equal(fa[1], fb[1])
+
+
 # ----------------------------------------------------------------------------- second stream for the weight gradients
 def test_side_stream_weight_gradients_match_single_stream():
     """Gradients of a training step with the weight-gradient GEMMs on the second stream (accumulated straight into the flat gradient
