@@ -352,7 +352,7 @@ int lhg_asm_from_spectrum(const float* spectrum, int planes, int rows0, int cols
 /* The `twiddle_rows` / `twiddle_cols` table of a transform length n: lhg_fft_table_floats(n) floats, filled by lhg_fft_twiddles.
  * n a product of 2, 3, 5, 7, 11, 13 in [16, 4096] (and <= 256 x the per-thread budget of its largest radix: 3072 with a factor 3,
  * 3328 with 13, ...): twiddle[k] = exp(-2 pi i k / n), k < n (2n floats), computed in double on the device; the transform runs on
- * radix-4 / 2 / 3 / 5 / 7 / 11 / 13 Stockham stages.  Any other n in [16, 8192] runs as a Bluestein (chirp-z) convolution of power-of-two length m >= 2n - 1 inside the same
+ * radix-4 / 2 / 3 / 5 / 7 / 11 / 13 Stockham stages.  Any other n in [16, 8192] runs as a Bluestein (chirp-z) convolution of length m >= 2n - 1 (a power of two up to 4096, the shortest 2^a 3^b length above) inside the same
  * kernels; its table is [m twiddles of length m][n chirp values exp(i pi j^2 / n)][FFT_m(wrapped chirp) / m].
  * ref: torch.fft.fft2 / ifft2 accept any extent, angular_spectrum_method.py:382-383 (e.g. 192 + 2*320 = 832 = 2^6 * 13). */
 long long lhg_fft_table_floats(int n);

@@ -7,9 +7,8 @@ fp32 in the reference's operation order and uploaded once; the 
 into the uploaded transfer functions (it is 0/1, so H*mask is exact).
 
 Every padded extent in [16, 8192] runs on that operator: products of the primes up to 13 directly (1024, 2304 x 4096, 832 =
-192 + 2*320), anything else as a Bluestein convolution (2800 x 4976: a 4K frame with the CLI's pad 320).  Larger non-smooth
-extents — or all non-direct ones with LHG_ASM_ROCFFT=1 — take the ``torch.fft`` route on the same device (rocFFT): still
-GPU-only, never a CPU fallback.
+192 + 2*320), anything else as a Bluestein convolution (2800 x 4976: a 4K frame with the CLI's pad 320).  Only larger non-smooth
+extents take the ``torch.fft`` route on the same device (rocFFT): still GPU-only, never a CPU fallback.
 """
 
 from __future__ import annotations

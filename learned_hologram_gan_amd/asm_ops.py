@@ -52,8 +52,8 @@ def smooth_extent(n: int) -> bool:
 
 def supported_extent(n: int) -> bool:
     """Lengths the fused operator handles: the direct ones, and ANY length in [16, 8192] through a Bluestein convolution of
-    power-of-two length >= 2n - 1 (at most 16384) inside the same kernels: 832 = 192 + 2*320 (the CLI's default pad on the 192^2
-    frames), 2800 x 4976 (a 4K frame with that pad)."""
+    length m >= 2n - 1 (a power of two up to 4096, the shortest 2^a 3^b length above: at most 16384) inside the same kernels; 832 = 192 + 2*320
+    (the CLI's default pad on the 192^2 frames) is direct, 2800 x 4976 (a 4K frame with that pad) has direct rows and 10368-point columns."""
     return smooth_extent(n) or 16 <= n <= 8192
 
 
@@ -85,10 +85,8 @@ class Geometry:
         return self.cols0 + 2 * self.pad_c
 
     def supported(self):
-        """True: the fused HIP operator runs this geometry.  LHG_ASM_ROCFFT=1 sends every extent outside the direct lengths to the
-        torch.fft (rocFFT) route instead — measured 1.6-2x faster than the Bluestein / radix-13 stages at 832^2 and 2800 x 4976."""
-        if os.environ.get("LHG_ASM_ROCFFT", "0") == "1" and not (smooth_extent(self.rows) and smooth_extent(self.cols)):
-            return False
+        """True: the fused HIP operator runs this geometry (every padded extent in [16, 8192]; round 3 dropped the LHG_ASM_ROCFFT switch
+        that sent the non-direct extents to torch.fft: the operator is faster than that route on them now, tools/bench_bluestein.py)."""
         return supported_extent(self.rows) and supported_extent(self.cols)
 
 

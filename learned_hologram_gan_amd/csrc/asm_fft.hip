@@ -17,7 +17,7 @@
 // every other product of the primes up to 13 (<= 4096: 2304 x 4096 for 4K, 832 = 2^6 13, 2800 = 2^4 5^2 7) uses the Stockham
 // autosort radix-4 / 2 / 3 / 5 / 7 / 11 / 13 stages below (in LDS, host-exact twiddle table computed in double, in place with
 // register staging: read-all / barrier / write-all); any other length up to 8192 (4976 = 2^4 311) runs as a Bluestein convolution
-// of power-of-two length on the same stages.
+// on the same stages (length: bluestein_len — a power of two up to 4096, the shortest 2^a 3^b length above).
 #include <algorithm>
 #include <cstdlib>
 #include <type_traits>
@@ -279,14 +279,29 @@ __device__ __forceinline__ void lds_fft(float2* buf, int n, int nf, int stride, 
     const int twstep = n / (p * R);
     const bool t_pow2 = (T & (T - 1)) == 0;  // wave-uniform: butterfly -> (transform, index) by shift instead of an integer division
     const int lt = __ffs(T) - 1;
+    // butterfly b -> (line f, index i): nothing to divide for the one-line workgroups of the long (Bluestein) lines
+    auto line_of = [&](int b_, int& f_, int& i_) {
+      if (nf == 1) { f_ = 0; i_ = b_; }
+      else { f_ = t_pow2 ? b_ >> lt : b_ / T; i_ = b_ - f_ * T; }
+    };
+    // i mod p without the integer division when p is not a power of two (radix-3 stages): float reciprocal and one correction (i < 2^24)
+    const float inv_p = 1.f / (float)p;
+    auto mod_p = [&](int i_) {
+      if (p_pow2) return i_ & (p - 1);
+      int k_ = i_ - (int)((float)i_ * inv_p) * p;
+      if (k_ < 0) k_ += p;
+      else if (k_ >= p) k_ -= p;
+      return k_;
+    };
     float2 u[MAX_IT][4];
     if (R == 4) {
 #pragma unroll
       for (int it = 0; it < MAX_IT; ++it) {
         const int b = tid + it * nthreads;
         if (b < total) {
-          const int f = t_pow2 ? b >> lt : b / T, i = b - f * T;
-          const int k = p_pow2 ? (i & (p - 1)) : (i % p);
+          int f, i;
+          line_of(b, f, i);
+          const int k = mod_p(i);
           const float2* x = buf + f * stride + i;
           float2 u0 = x[0], u1 = x[T], u2 = x[2 * T], u3 = x[3 * T];
           if (p > 1) {
@@ -304,8 +319,9 @@ __device__ __forceinline__ void lds_fft(float2* buf, int n, int nf, int stride, 
       for (int it = 0; it < MAX_IT; ++it) {
         const int b = tid + it * nthreads;
         if (b < total) {
-          const int f = t_pow2 ? b >> lt : b / T, i = b - f * T;
-          const int k = p_pow2 ? (i & (p - 1)) : (i % p);
+          int f, i;
+          line_of(b, f, i);
+          const int k = mod_p(i);
           float2* y = buf + f * stride + ((i - k) << 2) + k;
           y[0] = u[it][0]; y[p] = u[it][1]; y[2 * p] = u[it][2]; y[3 * p] = u[it][3];
         }
@@ -317,8 +333,9 @@ __device__ __forceinline__ void lds_fft(float2* buf, int n, int nf, int stride, 
       for (int it = 0; it < 2 * MAX_IT; ++it) {
         const int b = tid + it * nthreads;
         if (b < total) {
-          const int f = t_pow2 ? b >> lt : b / T, i = b - f * T;
-          const int k = p_pow2 ? (i & (p - 1)) : (i % p);
+          int f, i;
+          line_of(b, f, i);
+          const int k = mod_p(i);
           const float2* x = buf + f * stride + i;
           float2 u0 = x[0], u1 = x[T];
           float2 w = tw[k * twstep];
@@ -333,8 +350,9 @@ __device__ __forceinline__ void lds_fft(float2* buf, int n, int nf, int stride, 
       for (int it = 0; it < 2 * MAX_IT; ++it) {
         const int b = tid + it * nthreads;
         if (b < total) {
-          const int f = t_pow2 ? b >> lt : b / T, i = b - f * T;
-          const int k = p_pow2 ? (i & (p - 1)) : (i % p);
+          int f, i;
+          line_of(b, f, i);
+          const int k = mod_p(i);
           float2* y = buf + f * stride + ((i - k) << 1) + k;
           y[0] = u[it >> 1][(it & 1) * 2];
           y[p] = u[it >> 1][(it & 1) * 2 + 1];
@@ -348,8 +366,9 @@ __device__ __forceinline__ void lds_fft(float2* buf, int n, int nf, int stride, 
       for (int it = 0; it < MAX_IT; ++it) {
         const int b = tid + it * nthreads;
         if (b < total) {
-          const int f = t_pow2 ? b >> lt : b / T, i = b - f * T;
-          const int k = i % p;
+          int f, i;
+          line_of(b, f, i);
+          const int k = mod_p(i);
           const float2* x = buf + f * stride + i;
           float2 u0 = x[0], u1 = x[T], u2 = x[2 * T];
           if (p > 1) {
@@ -369,8 +388,9 @@ __device__ __forceinline__ void lds_fft(float2* buf, int n, int nf, int stride, 
       for (int it = 0; it < MAX_IT; ++it) {
         const int b = tid + it * nthreads;
         if (b < total) {
-          const int f = t_pow2 ? b >> lt : b / T, i = b - f * T;
-          const int k = i % p;
+          int f, i;
+          line_of(b, f, i);
+          const int k = mod_p(i);
           float2* y = buf + f * stride + (i - k) * 3 + k;
           y[0] = u[it][0]; y[p] = u[it][1]; y[2 * p] = u[it][2];
         }
@@ -401,7 +421,7 @@ __device__ __forceinline__ float2 apply_filter(float2 z, float2 f, int op) {
 
 // ---------------------------------------------------------------------------------------- Bluestein (chirp-z) lengths
 // A length n outside 2^a 3^b (832 = 2^6 13: the 192^2 frame with the CLI's default pad 320) is transformed as a circular convolution of
-// power-of-two length m >= 2n - 1 with the chirp c[j] = exp(i pi j^2 / n):
+// length m >= 2n - 1 (bluestein_len: a power of two, or 2^a 3^b above 4096) with the chirp c[j] = exp(i pi j^2 / n):
 //     X[k] = conj(c[k]) * sum_j (x[j] conj(c[j])) c[k - j]            (n k = (j^2 + k^2 - (k - j)^2) / 2)
 // = conj(c) . IFFT_m( FFT_m(x conj(c), zero-extended) . FFT_m(c wrapped) ): two Stockham transforms of length m on the same LDS line plus
 // three pointwise passes.  The table lhg_fft_twiddles builds for such an n is [m twiddles of length m][n chirp values][m values of
@@ -645,14 +665,26 @@ static bool smooth_in_range(int n) {
     while (n % q == 0) n /= q;
   return n == 1;
 }
-// Bluestein convolution length for an extent the Stockham stages do not cover directly: the power of two >= 2n - 1, at most 16384
-// (so n <= 8192: 2800 x 4976, the 4K frame with the CLI's pad 320, is 8192 / 16384); 0 = direct transform (or unsupported: check with
-// length_supported)
+// threads of a row-pass workgroup: 256, more only for lines longer than 16 butterfly inputs per thread (Bluestein lengths above 4096)
+static int rows_threads(int L) { return L <= 4096 ? 256 : (L <= 8192 ? 512 : 1024); }
+// Bluestein convolution length m for an extent n the Stockham stages do not cover directly (0 = direct transform, or unsupported: check
+// with length_supported): any m >= 2n - 1 the stages can transform.  Up to 4096 the power of two (specialised stages); above, the
+// SHORTEST 2^a 3^b length one workgroup's threads can hold (12 butterfly inputs per thread) — 4976 columns of the 4K frame with the
+// CLI's pad 320: 10368 = 2^7 3^4 instead of 16384 (83 KB of LDS instead of 128, 0.6 of the butterflies): 4.9 ms per A5 call against
+// 6.1, and against 5.3 on the rocFFT route (tools/bench_bluestein.py).  LHG_BLUESTEIN_SMOOTH=0: powers of two only (measurements).
 static int bluestein_len(int n) {
   if (smooth_in_range(n) || n < 16 || 2 * n - 1 > 16384) return 0;
   int m = 64;
   while (m < 2 * n - 1) m <<= 1;
-  return m;  // (a 2^a 3^b length in between was measured: the generic stages cost more than the shorter line saves)
+  static const bool smooth = [] { const char* e = getenv("LHG_BLUESTEIN_SMOOTH"); return !e || atoi(e) != 0; }();
+  if (smooth && m > 4096) {
+    int best = m;
+    for (int t = 3; t <= 243; t *= 3)
+      for (int c = t; c < best; c <<= 1)
+        if (c >= 2 * n - 1 && c % 64 == 0 && c <= 12 * rows_threads(c)) { best = c; break; }
+    m = best;
+  }
+  return m;
 }
 static bool length_supported(int n) { return smooth_in_range(n) || bluestein_len(n) != 0; }
 
@@ -660,8 +692,6 @@ static int rows_nf(int n) {
   const int cap = fft_budget(n) * 256;
   return std::max(1, std::min(64, cap / n));
 }
-// threads of a row-pass workgroup: 256, more only for lines longer than 16 butterfly inputs per thread (Bluestein lengths 8192 / 16384)
-static int rows_threads(int L) { return L <= 4096 ? 256 : (L <= 8192 ? 512 : 1024); }
 // twiddles go to LDS next to the lines when both fit
 static bool tw_fits(size_t line_bytes, int L) { return line_bytes + (size_t)L * sizeof(float2) <= 150 * 1024; }
 

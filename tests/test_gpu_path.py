@@ -437,13 +437,16 @@ def test_asm_4k_geometry_radix3():
     assert rel_err(torch.cat((ha, ta)).cpu(), a) < PARITY
 
 
-@pytest.mark.parametrize("r0,c0,pad", [(192, 192, 320), (100, 140, 21), (77, 90, 5), (64, 2100, 4), (64, 4848, 1)], ids=lambda v: str(v))
+# the last five: columns on either side of every rule of the convolution-length choice — 2049 -> 4608 = 2^9 3^2, 3073 -> 8192 (6912 does not
+# fit 512 threads), 4097 -> 9216 = 2^10 3^2, 6000 -> 12288 = 2^12 3, 6200 -> 16384, 8190 -> 16384
+@pytest.mark.parametrize("r0,c0,pad", [(192, 192, 320), (100, 140, 21), (77, 90, 5), (64, 2100, 4), (64, 4848, 1), (32, 2049, 0), (32, 3073, 0),
+                                       (32, 4097, 0), (32, 6000, 0), (32, 6200, 0), (32, 8190, 0)], ids=lambda v: str(v))
 def test_extents_outside_2a3b_run_on_the_hip_operator(r0, c0, pad):
     """192 + 2*320 = 832 = 2^6 * 13 (the reference CLI default for 192^2 frames; torch.fft takes any extent,
     angular_spectrum_method.py:382-392) and other lengths outside 2^a 3^b stay on the fused HIP operator: products of primes up to 13
-    through radix-5 / 7 / 11 / 13 Stockham stages (832; 198 = 2 3^2 11; 100 = 2^2 5^2), everything else as a Bluestein convolution of
-    power-of-two length inside the same three passes (142 = 2 71, 87 = 3 29, 2362 columns -> length 8192, 4998 -> 16384: the sizes a 4K
-    frame with that pad needs).  Forward values against the oracle, gradients against the oracle's autograd."""
+    through radix-5 / 7 / 11 / 13 Stockham stages (832; 198 = 2 3^2 11; 100 = 2^2 5^2), everything else as a Bluestein convolution
+    inside the same three passes (142 = 2 71 -> length 512, 87 = 3 29 -> 256, 2108 columns -> 4608 = 2^9 3^2, 4850 -> 10368 = 2^7 3^4: the
+    sizes a 4K frame with that pad needs).  Forward values against the oracle, gradients against the oracle's autograd."""
     from learned_hologram_gan_amd import asm_ops
 
     fx = _fixed(r0, c0, pad, 0.45)
@@ -476,7 +479,7 @@ def test_extents_outside_2a3b_run_on_the_hip_operator(r0, c0, pad):
 
 def test_asm_4k_frame_with_the_cli_default_pad():
     """A 2160 x 3840 frame with the reference CLI's default pad_size 320 (generatePOH.py:96): 2800 x 4976 = (2^4 5^2 7) x (2^4 311)
-    transforms, Bluestein lengths 8192 / 16384 on the HIP operator."""
+    transforms: the rows direct, the columns a Bluestein convolution of length 10368 = 2^7 3^4 on the HIP operator."""
     import time
 
     r0, c0, pad = 2160, 3840, 320

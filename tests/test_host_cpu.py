@@ -30,7 +30,7 @@ def test_library_exports_declared_abi():
 
 def test_host_side_size_functions_and_supported_lengths():
     """Pure host functions of the ABI (no kernel launch): FFT table sizes follow the transform route (direct: 2n floats; Bluestein:
-    m twiddles + n chirp values + m filter values, m the power of two >= 2n - 1) and agree with the Python mirror of the supported
+    m twiddles + n chirp values + m filter values, m the convolution length >= 2n - 1) and agree with the Python mirror of the supported
     lengths; packed-weight sizes follow the precision mode (the fp16-split panels carry max|w| in 16 bytes behind them)."""
     from learned_hologram_gan_amd import asm_ops, native
 
@@ -45,7 +45,12 @@ def test_host_side_size_functions_and_supported_lengths():
             m = 64
             while m < 2 * n - 1:
                 m *= 2
-            assert floats == 2 * (2 * m + n)
+            if m > 4096:  # above 4096: the shortest 2^a 3^b length (a multiple of 64) that fits 12 inputs per thread of the line's workgroup
+                threads = lambda L: 256 if L <= 4096 else (512 if L <= 8192 else 1024)  # noqa: E731
+                smooth = [c for c in (t << a for t in (3, 9, 27, 81, 243) for a in range(20)) if 2 * n - 1 <= c < m and c % 64 == 0 and c <= 12 * threads(c)]
+                m = min(smooth + [m])
+            assert floats == 2 * (2 * m + n), (n, m, floats)
+    assert int(lib.lhg_fft_table_floats(4976)) == 2 * (2 * 10368 + 4976)  # the 4K frame with the CLI's pad: 2^7 3^4, not 16384
     assert not asm_ops.supported_extent(9350) and not asm_ops.supported_extent(8)
     assert lib.lhg_default_conv_precision() == 4 or "LHG_CONV_PRECISION" in __import__("os").environ
     mode = lib.lhg_get_conv_precision()
