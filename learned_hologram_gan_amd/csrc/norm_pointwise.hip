@@ -546,6 +546,24 @@ __global__ void nchw_to_nhwc_kernel(const float* __restrict__ src, T* __restrict
   }
 }
 
+// Narrow tensors (the step's inputs: 3, 4 or 6 planes into 4 .. 32 channels): one thread per PIXEL — every plane is read along hw by
+// consecutive lanes (whole lines), the pixel's ld channels leave as 16-byte stores; no integer division per element.
+template <int LD4>  // ld / 4
+__global__ __launch_bounds__(256) void nchw_to_nhwc_pixel_kernel(const float* __restrict__ src, float* __restrict__ dst, int N, int C, int HW) {
+  const size_t pixels = (size_t)N * HW;
+  for (size_t pix = blockIdx.x * (size_t)blockDim.x + threadIdx.x; pix < pixels; pix += (size_t)gridDim.x * blockDim.x) {
+    const size_t n = pix / HW, hw = pix - n * HW;
+    const float* s0 = src + n * (size_t)C * HW + hw;
+    f32x4 v[LD4];
+#pragma unroll
+    for (int q = 0; q < LD4; ++q)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) v[q][e] = (4 * q + e) < C ? s0[(size_t)(4 * q + e) * HW] : 0.f;
+#pragma unroll
+    for (int q = 0; q < LD4; ++q) *reinterpret_cast<f32x4*>(dst + pix * (4 * LD4) + 4 * q) = v[q];
+  }
+}
+
 template <class T>
 __global__ void nhwc_to_nchw_kernel(const T* __restrict__ src, int ld, float* __restrict__ dst, int N, int C, int HW) {
   const size_t total = (size_t)N * C * HW;
@@ -687,6 +705,18 @@ template <class T>
 static int nchw_to_nhwc_impl(const float* src, float* dst, int N, int C, int H, int W, int ld, lhg_stream_t s) {
   LHG_REQUIRE(ld >= C, "nchw_to_nhwc: ld %d < C %d", ld, C);
   const size_t total = (size_t)N * H * W * ld;
+  if (sizeof(T) == 4 && ld % 4 == 0 && ld <= 32 && (reinterpret_cast<uintptr_t>(dst) & 15) == 0) {
+    const int g = grid_for((size_t)N * H * W, 256, 16384);
+    float* d = reinterpret_cast<float*>(dst);
+    switch (ld / 4) {
+      case 1: hipLaunchKernelGGL(nchw_to_nhwc_pixel_kernel<1>, dim3(g), dim3(256), 0, as_stream(s), src, d, N, C, H * W); break;
+      case 2: hipLaunchKernelGGL(nchw_to_nhwc_pixel_kernel<2>, dim3(g), dim3(256), 0, as_stream(s), src, d, N, C, H * W); break;
+      case 4: hipLaunchKernelGGL(nchw_to_nhwc_pixel_kernel<4>, dim3(g), dim3(256), 0, as_stream(s), src, d, N, C, H * W); break;
+      case 8: hipLaunchKernelGGL(nchw_to_nhwc_pixel_kernel<8>, dim3(g), dim3(256), 0, as_stream(s), src, d, N, C, H * W); break;
+      default: hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3(grid_for(total, 256, 16384)), dim3(256), 0, as_stream(s), src, as_act<T>(dst), N, C, H * W, ld);
+    }
+    return check_launch("nchw_to_nhwc");
+  }
   hipLaunchKernelGGL((nchw_to_nhwc_kernel<T>), dim3(grid_for(total, 256, 16384)), dim3(256), 0, as_stream(s), src, as_act<T>(dst), N, C, H * W, ld);
   return check_launch("nchw_to_nhwc");
 }

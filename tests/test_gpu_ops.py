@@ -277,6 +277,20 @@ def test_wgrad_slab_reduce_is_the_documented_sum_bit_for_bit(ops):
             assert torch.equal(grad, expect), (D0, D1, m_is_d1, S, accumulate, (grad - expect).abs().max().item())
 
 
+def test_nchw_to_nhwc_layout_kernels(ops):
+    """lhg_nchw_to_nhwc: the pixel-per-thread form (ld <= 32) and the element-per-thread form, zero-filled padding channels."""
+    from learned_hologram_gan_amd.native import call, ptr, stream_ptr
+
+    torch.manual_seed(0)
+    for (N, C, H, W, ld) in ((4, 4, 96, 96, 4), (2, 3, 64, 48, 4), (2, 6, 40, 40, 8), (2, 5, 33, 17, 32), (1, 1, 7, 9, 4), (2, 13, 20, 20, 16), (2, 40, 8, 8, 64)):
+        x = torch.randn(N, C, H, W, device=DEV)
+        y = torch.full((N, H, W, ld), 7.0, device=DEV)
+        call("lhg_nchw_to_nhwc", ptr(x), ptr(y), N, C, H, W, ld, stream_ptr())
+        want = torch.zeros((N, H, W, ld), device=DEV)
+        want[..., :C] = x.permute(0, 2, 3, 1)
+        assert torch.equal(y, want), (N, C, H, W, ld)
+
+
 def test_default_gemm_mode_and_env_override():
     """The library starts in the fp32-faithful two-term fp16 split mode unless LHG_CONV_PRECISION names another one (read at load time)."""
     import os
