@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define LHG_ABI_VERSION 5
+#define LHG_ABI_VERSION 6
 
 enum {
   LHG_OK = 0,
@@ -399,6 +399,13 @@ int lhg_psnr_ssim(const float* hat, const float* tgt, int planes, int H, int W, 
  * torch.optim.Adam (no weight decay, no amsgrad) on one flat tensor.  ref: watermelon.py:137-138. */
 int lhg_adam_step(float* p, const float* g, float* m, float* v, long long n,
                   float lr, float beta1, float beta2, float eps, int step, lhg_stream_t s);
+/* ABI 6: the same step on g * grad_scale (data-parallel runs hand over the all-reduced SUM and 1 / world: the division costs no pass of
+ * its own; 1.0 is exact) and, with consts4 != NULL, with {1 - beta1^t, sqrt(1 - beta2^t), grad_scale, lr} read from DEVICE memory at
+ * execution time instead of the by-value arguments (`step`, `grad_scale`, `lr` are then ignored): a launch captured into a hipGraph
+ * follows the step count and a learning-rate schedule through that buffer. */
+int lhg_adam_step_scaled(float* p, const float* g, float* m, float* v, long long n,
+                         float lr, float beta1, float beta2, float eps, int step,
+                         float grad_scale, const float* consts4, lhg_stream_t s);
 
 #ifdef __cplusplus
 }

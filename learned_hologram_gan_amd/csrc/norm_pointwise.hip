@@ -646,14 +646,17 @@ __global__ __launch_bounds__(256) void act_bwd_kernel(const T* __restrict__ g, i
 }
 
 // ------------------------------------------------------------------ Adam
+// consts (optional, device): {1 - b1^t, sqrt(1 - b2^t), gradient scale, lr} read by the kernel instead of the by-value arguments, so that a
+// captured launch (hipGraph) follows the step count and a schedule's learning rate without being re-recorded.
 __global__ __launch_bounds__(256) void adam_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                    float* __restrict__ v, long long n, float lr, float b1, float b2, float eps,
-                                                   float bc1, float bc2_sqrt) {
+                                                   float bc1, float bc2_sqrt, float gscale, const float* __restrict__ consts) {
   // torch.optim.Adam single-tensor path: m = b1 m + (1-b1) g; v = b2 v + (1-b2) g^2;
   // denom = sqrt(v)/sqrt(1-b2^t) + eps; p -= (lr/(1-b1^t)) * m/denom
+  if (consts) { bc1 = consts[0]; bc2_sqrt = consts[1]; gscale = consts[2]; lr = consts[3]; }
   const float step_size = lr / bc1;
   for (long long i = blockIdx.x * (long long)blockDim.x + threadIdx.x; i < n; i += (long long)gridDim.x * blockDim.x) {
-    const float gi = g[i];
+    const float gi = g[i] * gscale;  // gscale = 1 / world: the data-parallel mean of the all-reduced sum (1.0 is exact: single process)
     const float mi = m[i] + (gi - m[i]) * (1.f - b1);  // lerp form used by torch
     const float vi = b2 * v[i] + (1.f - b2) * gi * gi;
     m[i] = mi;
@@ -966,10 +969,15 @@ int lhg_act_backward(const float* g, int ldg, const float* y, int ldy, long long
 
 int lhg_adam_step(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps, int step,
                   lhg_stream_t s) {
-  LHG_REQUIRE(step >= 1, "adam_step: step must be >= 1");
+  return lhg_adam_step_scaled(p, g, m, v, n, lr, beta1, beta2, eps, step, 1.0f, nullptr, s);
+}
+
+int lhg_adam_step_scaled(float* p, const float* g, float* m, float* v, long long n, float lr, float beta1, float beta2, float eps, int step,
+                         float grad_scale, const float* consts4, lhg_stream_t s) {
+  LHG_REQUIRE(consts4 != nullptr || step >= 1, "adam_step: step must be >= 1");
   const double bc1 = 1.0 - pow((double)beta1, step), bc2 = 1.0 - pow((double)beta2, step);
   hipLaunchKernelGGL(adam_kernel, dim3(grid_for((size_t)n, 256, 4096)), dim3(256), 0, as_stream(s), p, g, m, v, n, lr, beta1, beta2, eps,
-                     (float)bc1, (float)sqrt(bc2));
+                     (float)bc1, (float)sqrt(bc2), grad_scale, consts4);
   return check_launch("adam_step");
 }
 

@@ -33,6 +33,64 @@ def init_from_env(backend: str | None = None):
     return rank, world, local
 
 
+def spawn_local_ranks(argv, n: int, env_extra: dict | None = None, timeout: float | None = None):
+    """Start ``n`` rank processes of ``argv`` on this node (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / a free MASTER_PORT in
+    their environment: the torchrun contract init_from_env reads), wait for all of them and return (exit code, rank 0's stdout).
+
+    Children are plain child processes (never os.exec*), and the caller must not have touched the GPU: a process that has initialised
+    HIP cannot be the parent of ranks that each own a GPU on this pool.  Rank 0's stdout is captured and returned (the caller relays the
+    one JSON line); the other ranks' stdout goes to stderr of the parent so that nothing but rank 0's line reaches stdout.  If any rank
+    exits non-zero the rest are terminated and that code is returned."""
+    import socket
+    import subprocess
+    import sys
+    import time
+
+    if n < 1:
+        raise ValueError("spawn_local_ranks: n must be >= 1")
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), HSA_ENABLE_IPC_MODE_LEGACY=os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY", "0"), **(env_extra or {}))
+        procs.append(subprocess.Popen(list(argv), env=env, stdout=subprocess.PIPE if r == 0 else sys.stderr, text=True))
+    import threading
+
+    chunks = []
+    reader = threading.Thread(target=lambda: chunks.append(procs[0].stdout.read()), daemon=True)  # keeps rank 0's pipe drained
+    reader.start()
+    deadline = None if timeout is None else time.monotonic() + timeout
+    code = 0
+    try:
+        pending = set(range(n))
+        while pending and code == 0:
+            for r in sorted(pending):
+                rc = procs[r].poll()
+                if rc is not None:
+                    pending.discard(r)
+                    if rc != 0 and code == 0:
+                        code = rc
+            if pending and code == 0:
+                if deadline is not None and time.monotonic() > deadline:
+                    code = 124  # timed out
+                else:
+                    time.sleep(0.1)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        for p in procs:
+            try:
+                p.wait(timeout=10)
+            except subprocess.TimeoutExpired:
+                p.kill()
+    reader.join(timeout=10)
+    out0 = "".join(c for c in chunks if c)
+    return code, out0
+
+
 def world_size() -> int:
     return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
 
@@ -73,8 +131,16 @@ class GradSynchronizer:
     Every rank records the same graph, so buckets complete — and collectives are issued — in the same order everywhere.
     """
 
-    def __init__(self, params, offsets, flat_grad: torch.Tensor, n_buckets: int = 4, group=None, first_bucket_elems: int = 1 << 18):
+    def __init__(self, params, offsets, flat_grad: torch.Tensor, n_buckets: int = 4, group=None, first_bucket_elems: int = 1 << 18,
+                 payload: str = "fp32", defer_scale: bool = False):
+        """``payload="bf16"`` (the bf16 data-parallel configs, BASELINE configs[2] / [4]): a bucket travels as bf16 — half the bytes per
+        xGMI link — and comes back into the fp32 flat buffer (the fp32 master gradient Adam reads); rounding: 2^-9 relative per element
+        and per partial sum of the ring.  ``defer_scale``: finish() leaves the SUM in the buffer and ``grad_scale`` = 1 / world for the
+        optimiser kernel to apply (FusedAdam.step(grad_scale=...)): one pass over the buffer less per step."""
+        if payload not in ("fp32", "bf16"):
+            raise ValueError("payload must be 'fp32' or 'bf16'")
         self.params, self.flat_grad, self.group = list(params), flat_grad, group
+        self.payload, self.defer_scale, self.grad_scale = payload, defer_scale, 1.0
         self.world = dist.get_world_size(group) if dist.is_initialized() else 1
         n = len(self.params)
         total = flat_grad.numel()
@@ -104,6 +170,7 @@ class GradSynchronizer:
         self._real = [False] * n
         self._launched = [False] * len(self.ranges)
         self._work = []
+        self._wire = []  # (lo, hi, bf16 copy) of the buckets in flight (payload "bf16")
         self._hooks = []
         self.launch_log = []  # (bucket, hip_ops.CONTRIBUTIONS at launch, launched from finish()?) of the last pass: read by the tests
         self.enabled = self.world > 1
@@ -152,12 +219,20 @@ class GradSynchronizer:
         from . import hip_ops
 
         side = hip_ops.side_stream(self.flat_grad.device) if self.flat_grad.is_cuda else None
+
+        def reduce():
+            if self.payload == "bf16":
+                wire = self.flat_grad[lo:hi].to(torch.bfloat16)  # on the stream the collective is issued on
+                self._wire.append((lo, hi, wire))
+                return dist.all_reduce(wire, op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            return dist.all_reduce(self.flat_grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+
         if side is not None:
             side.wait_stream(torch.cuda.current_stream(self.flat_grad.device))  # gradients accumulated by autograd on the main stream
             with torch.cuda.stream(side):  # the collective queues behind this bucket's last weight-gradient GEMM
-                work = dist.all_reduce(self.flat_grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+                work = reduce()
         else:
-            work = dist.all_reduce(self.flat_grad[lo:hi], op=dist.ReduceOp.SUM, group=self.group, async_op=True)
+            work = reduce()
         self._work.append(work)
         self._launched[b] = True
         self.launch_log.append((b, hip_ops.CONTRIBUTIONS, from_finish))
@@ -169,6 +244,7 @@ class GradSynchronizer:
         self._real = [False] * len(self.params)
         self._launched = [False] * len(self.ranges)
         self._work = []
+        self._wire = []
         self.launch_log = []
         self._armed = self.enabled
         if self.flat_grad.is_cuda:
@@ -192,7 +268,15 @@ class GradSynchronizer:
             w.wait()  # the current stream waits for the collective
         if self.flat_grad.is_cuda:
             hip_ops.join_side_stream(self.flat_grad.device)  # weight gradients of buckets that autograd never completed
-        self.flat_grad.div_(self.world)
+        for lo, hi, wire in self._wire:  # reduced bf16 sums back into the fp32 master gradient
+            if wire.is_cuda:
+                wire.record_stream(torch.cuda.current_stream(wire.device))
+            self.flat_grad[lo:hi].copy_(wire)
+        self._wire = []
+        if self.defer_scale:
+            self.grad_scale = 1.0 / self.world  # applied by the optimiser kernel (lhg_adam_step_scaled)
+        else:
+            self.flat_grad.div_(self.world)
 
     def remove(self):
         from . import hip_ops

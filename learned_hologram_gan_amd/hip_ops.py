@@ -1455,8 +1455,12 @@ class SigmoidHeadFn(TrackedFunction):
 
 
 # --------------------------------------------------------------------------- optimiser
-def adam_step_(p, g, m, v, lr, beta1, beta2, eps, step):
-    call("lhg_adam_step", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps), int(step), stream_ptr())
+def adam_step_(p, g, m, v, lr, beta1, beta2, eps, step, grad_scale=1.0, consts=None):
+    """torch.optim.Adam on the flat buffers; ``grad_scale`` multiplies g on the fly (1 / world after a summing all-reduce); ``consts``:
+    a 4-float DEVICE tensor {1 - beta1^t, sqrt(1 - beta2^t), grad_scale, lr} the kernel reads instead of step / grad_scale / lr (a
+    captured launch then follows the step count: graph.GraphedTrainStep)."""
+    call("lhg_adam_step_scaled", ptr(p), ptr(g), ptr(m), ptr(v), p.numel(), float(lr), float(beta1), float(beta2), float(eps), int(step),
+         float(grad_scale), ptr(consts), stream_ptr())
     bump_version(p)
 
 

@@ -36,7 +36,7 @@ class PackItem(C.Structure):
 
 
 # name -> argtypes (restype is int unless listed in _RESTYPE)
-ABI_VERSION = 5  # LHG_ABI_VERSION of include/lhg_hip.h this binding was written against
+ABI_VERSION = 6  # LHG_ABI_VERSION of include/lhg_hip.h this binding was written against
 
 _SIGNATURES = {
     "lhg_abi_version": [],
@@ -103,6 +103,7 @@ _SIGNATURES = {
     "lhg_psnr_ssim_workspace": [_i, _i, _i],
     "lhg_psnr_ssim": [_p, _p, _i, _i, _i, _p, _p, _sz, _p],
     "lhg_adam_step": [_p, _p, _p, _p, _ll, _f, _f, _f, _f, _i, _p],
+    "lhg_adam_step_scaled": [_p, _p, _p, _p, _ll, _f, _f, _f, _f, _i, _f, _p, _p],
 }
 _RESTYPE = {"lhg_last_error": C.c_char_p, "lhg_packed_weight_floats": C.c_longlong, "lhg_fft_table_floats": C.c_longlong, "lhg_chanmax_partial_rows": C.c_longlong, "lhg_conv2d_thin_wgrad_workspace": C.c_size_t, "lhg_psnr_ssim_workspace": C.c_size_t}
 

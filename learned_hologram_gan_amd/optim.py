@@ -70,12 +70,14 @@ class FusedAdam:
     def zero_grad(self, set_to_none: bool = False):
         self.flat.zero_grad()
 
-    def step(self):
+    def step(self, grad_scale: float = 1.0):
+        """``grad_scale``: the gradient buffer holds grad / grad_scale (a data-parallel SUM with grad_scale = 1 / world,
+        GradSynchronizer(defer_scale=True)): the kernel multiplies on the fly."""
         self.step_count += 1
         if self.flat.grad.is_cuda:
             hip_ops.join_side_stream(self.flat.grad.device)  # weight gradients accumulated on the side stream
         hip_ops.adam_step_(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1],
-                           self.eps, self.step_count)
+                           self.eps, self.step_count, grad_scale)
         for p in self.flat.params:
             hip_ops.bump_version(p)
         if self.flat.data.is_cuda and _BATCHED_REPACK:

@@ -108,8 +108,11 @@ class watermelon:
     # ------------------------------------------------------------------ configuration of one run
     def configure(self, phs_gradient_loss_weight=1, perceptual_loss_weight=1.0, pixel_loss_weight=1.0, TV_loss_weight=1e-3,
                   discriminator_loss_weight=1.0, lr_G=1e-3, lr_D=1e-3, discriminator_train_ratio=2, discriminator_lambda=10,
-                  grad_buckets=4, sync_batch_stats=False):
-        """``sync_batch_stats`` (data-parallel runs): normalise every train-mode BatchNorm, the focal loss's max normalisers and the TV
+                  grad_buckets=4, sync_batch_stats=False, grad_payload=None):
+        """``grad_payload`` (data-parallel runs): "fp32" or "bf16" wire format of the gradient buckets' all-reduce; default: bf16 when the
+        activations are stored as bf16 (hip_ops.activation_storage(): the bf16 configs of BASELINE.json), fp32 otherwise.  The reduced
+        sums land in the fp32 flat buffer either way and the division by the world size is done by the Adam kernel.
+        ``sync_batch_stats`` (data-parallel runs): normalise every train-mode BatchNorm, the focal loss's max normalisers and the TV
         means over the GLOBAL batch (all-reduced statistics, hip_ops.set_sync_batch_stats) — W replicas of B samples then reproduce the
         reference's single-device step at batch W x B (ref: neural_network_components.py:23-24, loss_func.py:94-98, 152-157).  Off
         (default): those statistics are per replica, which at one sample per replica (BASELINE configs[4]: bs=8 over 8 GPUs) is a
@@ -126,13 +129,16 @@ class watermelon:
         flat_G = FlatParams(self.generator)
         broadcast_module_state(self.generator, flat_G.data)  # data-parallel replicas start from rank 0's weights
         self._opt_G = FusedAdam(flat_G, lr=lr_G)
-        self._sync_G = GradSynchronizer(flat_G.params, flat_G.offsets, flat_G.grad, grad_buckets)
+        if grad_payload is None:
+            grad_payload = "bf16" if hip_ops.activation_storage() == "bf16" else "fp32"
+        self._sync_G = GradSynchronizer(flat_G.params, flat_G.offsets, flat_G.grad, grad_buckets, payload=grad_payload, defer_scale=True)
         trainable_D = [p for p in self.discriminator.parameters() if p.requires_grad]
         if discriminator_train_ratio > 0 and trainable_D and isinstance(self.discriminator, WGANGPDiscriminator192):
             flat_D = FlatParams(self.discriminator)
             broadcast_module_state(self.discriminator, flat_D.data)
             self._opt_D = FusedAdam(flat_D, lr=lr_D)
-            self._sync_D = GradSynchronizer(flat_D.params, flat_D.offsets, flat_D.grad, max(1, grad_buckets // 2))
+            self._sync_D = GradSynchronizer(flat_D.params, flat_D.offsets, flat_D.grad, max(1, grad_buckets // 2), payload=grad_payload,
+                                            defer_scale=True)
         else:
             self._opt_D = self._sync_D = None
         self.train_losses_tensor = torch.zeros(7, device=self.device)
@@ -210,7 +216,7 @@ class watermelon:
             self._sync_D.start()
             d_loss.backward(retain_graph=True)
             self._sync_D.finish()
-            self._opt_D.step()
+            self._opt_D.step(grad_scale=self._sync_D.grad_scale)
             d_total = d_total + d_loss.detach() / ratio
         # The critic's weight gradients of this pass are never read: the reference zeroes them (watermelon.py:252) before the
         # next critic backward and optimizer_G does not own them.  Recording the pass with frozen critic weights drops those
@@ -222,7 +228,7 @@ class watermelon:
         self._sync_G.start()
         g_loss.backward()
         self._sync_G.finish()
-        self._opt_G.step()
+        self._opt_G.step(grad_scale=self._sync_G.grad_scale)
         self.train_losses_tensor[-1] += d_total
         return dict(POH=POH.detach(), hat_amps=hat_amps.detach(), target_amps=target_amps.detach(), G_loss=g_loss.detach(), D_loss=d_total)
 

@@ -61,10 +61,10 @@ def overlap():
     idx = torch.tensor([5, 2])
     grabbed = []
 
-    def no_update():  # capture instead of Adam: both passes see the same weights
+    def no_update(grad_scale=1.0):  # capture instead of Adam: both passes see the same weights (the buffer holds the SUM, Adam would scale it)
         hip_ops.join_side_stream()
         torch.cuda.synchronize()
-        grabbed.append(W._opt_G.flat.grad.detach().clone())
+        grabbed.append(W._opt_G.flat.grad.detach().clone() * grad_scale)
 
     W._opt_G.step = no_update
     sync = W._sync_G
@@ -205,10 +205,10 @@ def critic():
     grabbed = {"D": [], "G": []}
     logs = {"D": [], "G": []}
     for name, opt, sync in (("D", W._opt_D, W._sync_D), ("G", W._opt_G, W._sync_G)):
-        def no_update(name=name, opt=opt, sync=sync):  # capture instead of Adam: every pass sees the same weights
+        def no_update(grad_scale=1.0, name=name, opt=opt, sync=sync):  # capture instead of Adam: every pass sees the same weights
             hip_ops.join_side_stream()
             torch.cuda.synchronize()
-            grabbed[name].append(opt.flat.grad.detach().clone())
+            grabbed[name].append(opt.flat.grad.detach().clone() * grad_scale)
             logs[name].append(list(sync.launch_log))
         opt.step = no_update
     x = (rgbd.to(dev), tamp.to(dev), tphs.to(dev), idx, alphas)
@@ -266,10 +266,10 @@ def syncbn():
             W._sync_G.enabled = W._sync_D.enabled = False
         grads = {}
         for name, opt in (("D", W._opt_D), ("G", W._opt_G)):
-            def no_update(name=name, opt=opt):
+            def no_update(grad_scale=1.0, name=name, opt=opt):
                 hip_ops.join_side_stream()
                 torch.cuda.synchronize()
-                grads[name] = opt.flat.grad.detach().clone()
+                grads[name] = opt.flat.grad.detach().clone() * grad_scale
             opt.step = no_update
         out = W.train_step(*(t.to(dev) for t in batch), idx, [alpha.view(-1, 1, 1, 1).to(dev)])
         torch.cuda.synchronize()

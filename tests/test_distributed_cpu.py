@@ -248,6 +248,104 @@ def test_bucketed_grad_allreduce_world2():
     assert sorted(results) == [(0, True), (1, True)]
 
 
+def _payload_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from learned_hologram_gan_amd import distributed
+    from learned_hologram_gan_amd.optim import FlatParams
+
+    distributed.init_from_env("gloo")
+    data = [torch.randn(5, 8, generator=torch.Generator().manual_seed(100 + k)) for k in range(world)]
+    got = {}
+    for payload, defer in (("fp32", False), ("fp32", True), ("bf16", True)):
+        torch.manual_seed(100)
+        net = _Net()
+        flat = FlatParams(net)
+        sync = distributed.GradSynchronizer(flat.params, flat.offsets, flat.grad, n_buckets=3, payload=payload, defer_scale=defer)
+        flat.zero_grad()
+        sync.start()
+        (net(data[rank]) ** 2).mean().backward()
+        sync.finish()
+        got[(payload, defer)] = (flat.grad.clone(), sync.grad_scale)
+        sync.remove()
+    mean, one = got[("fp32", False)]
+    summed, scale = got[("fp32", True)]
+    wire, scale16 = got[("bf16", True)]
+    ok = one == 1.0 and scale == scale16 == 1.0 / world
+    ok = ok and torch.equal(summed * scale, mean)  # the deferred form: the buffer holds the SUM, 1 / world goes to the optimiser kernel
+    # the bf16 wire: each rank's share is rounded to bf16 once and so is the ring's sum — relative error <= 2 * 2^-9 per element of the
+    # sum's magnitude scale; the result is fp32 in the flat buffer and identical on every rank
+    torch.manual_seed(100)
+    net = _Net()
+    (net(data[rank]) ** 2).mean().backward()
+    local = torch.zeros_like(summed)
+    for ref, o in zip(net.parameters(), flat.offsets):  # FlatParams keeps module.parameters() order
+        if ref.grad is not None:
+            local[o:o + ref.numel()] = ref.grad.reshape(-1)
+    mags = [torch.empty_like(local) for _ in range(world)]
+    dist.all_gather(mags, local.abs())
+    tol = 2.0 ** -8 * (sum(mags) + summed.abs()) + 1e-12
+    ok = ok and bool(((wire - summed).abs() <= tol).all()) and wire.dtype == torch.float32 and not torch.equal(wire, summed)
+    both = [torch.empty_like(wire) for _ in range(world)]
+    dist.all_gather(both, wire)
+    ok = ok and torch.equal(both[0], both[1])
+    dist.barrier()
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_bf16_gradient_payload_and_deferred_scale_world2():
+    """GradSynchronizer(payload="bf16", defer_scale=True) — the bf16 data-parallel configs' wire format — equals the fp32 reduce within
+    bf16 rounding, lands in the fp32 flat buffer, and leaves the division by the world size to the optimiser kernel (grad_scale)."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_payload_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(results) == [(0, True), (1, True)]
+
+
+@pytest.mark.timeout(300)
+def test_bench_gpus_n_starts_n_ranks_by_itself():
+    """`python bench.py --gpus 2` launched PLAINLY (no torchrun, WORLD_SIZE unset) must start two ranks itself — child processes, before
+    anything touches a GPU — relay rank 0's line and fail loudly otherwise (it used to run one rank and report n_gpus 1).
+    --spawn-check keeps the ranks to the rendezvous + one all-reduce (gloo here: no GPU in this container)."""
+    import json
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--spawn-check", "1"], cwd=root, env=env,
+                         capture_output=True, text=True, timeout=240)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rank_sum"] == 1.0 and out["rccl_ranks"] is None  # gloo: not RCCL ranks
+    # a mismatch between --gpus and the ranks that exist is refused, never reported as a smaller run
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--spawn-check", "1"], cwd=root,
+                         env=dict(env, WORLD_SIZE="1", RANK="0"), capture_output=True, text=True, timeout=240)
+    assert res.returncode != 0 and "WORLD_SIZE=1" in (res.stderr + res.stdout)
+
+
+def test_spawn_local_ranks_reports_a_failing_rank():
+    import sys
+
+    from learned_hologram_gan_amd.distributed import spawn_local_ranks
+
+    code, out0 = spawn_local_ranks([sys.executable, "-c", "import os, sys; print('r' + os.environ['RANK'] + '/' + os.environ['WORLD_SIZE']); "
+                                    "sys.exit(3 if os.environ['RANK'] == '1' else 0)"], 2, timeout=60)
+    assert code == 3 and out0.strip() in ("r0/2", "")  # rank 0 may have been terminated before printing
+    code, out0 = spawn_local_ranks([sys.executable, "-c", "import os; print(os.environ['MASTER_ADDR'], os.environ['LOCAL_RANK'])"], 1, timeout=60)
+    assert code == 0 and out0.split() == ["127.0.0.1", "0"]
+
+
 def test_single_process_sync_is_a_noop():
     from learned_hologram_gan_amd.distributed import GradSynchronizer
     from learned_hologram_gan_amd.optim import FlatParams

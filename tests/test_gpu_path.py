@@ -977,7 +977,7 @@ def test_train_step_repeats_bit_for_bit():
     x = (rgbd.to(DEV), tamp.to(DEV), tphs.to(DEV), torch.tensor([5, 2]), [torch.tensor([0.3, 0.8]).view(2, 1, 1, 1).to(DEV)])
     grabbed = []
     for opt in (W._opt_D, W._opt_G):
-        def step(opt=opt):  # capture instead of Adam: every pass sees the same weights
+        def step(grad_scale=1.0, opt=opt):  # capture instead of Adam: every pass sees the same weights
             hip_ops.join_side_stream()
             torch.cuda.synchronize()
             grabbed.append(opt.flat.grad.detach().clone())
@@ -1055,11 +1055,11 @@ def test_side_stream_weight_gradients_match_single_stream():
         for name, opt in (("D", W._opt_D), ("G", W._opt_G)):
             real_step = opt.step
 
-            def step(name=name, opt=opt, real_step=real_step):
+            def step(grad_scale=1.0, name=name, opt=opt, real_step=real_step):
                 hip_ops.join_side_stream()
                 torch.cuda.synchronize()
                 grads[name] = opt.flat.grad.detach().cpu().clone()
-                real_step()
+                real_step(grad_scale=grad_scale)
 
             opt.step = step
         W.train_step(rgbd.to(DEV), tamp.to(DEV), tphs.to(DEV), idx, alphas)

@@ -21,7 +21,7 @@ idx = torch.tensor([5, 2]); alphas = [torch.tensor([0.3, 0.8]).view(2, 1, 1, 1).
 x = (rgbd.to(dev), tamp.to(dev), tphs.to(dev), idx, alphas)
 grabbed = {}
 def grab(name, opt):
-    def step():
+    def step(grad_scale=1.0):
         hip_ops.join_side_stream(); torch.cuda.synchronize()
         grabbed.setdefault(name, []).append(opt.flat.grad.detach().clone())
     return step

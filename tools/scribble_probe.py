@@ -47,7 +47,7 @@ x = (torch.rand((2, 4, rows, cols), generator=g).to(dev), torch.rand((2, 3, rows
      torch.tensor([5, 2]), [torch.tensor([0.3, 0.8]).view(2, 1, 1, 1).to(dev)])
 grabbed = []
 for opt in (W._opt_D, W._opt_G):
-    def step(opt=opt):
+    def step(grad_scale=1.0, opt=opt):
         hip_ops.join_side_stream(); torch.cuda.synchronize(); grabbed.append(opt.flat.grad.detach().clone())
     opt.step = step
 

@@ -180,7 +180,7 @@ def worker(steps, mode):
         if opt is None:
             continue
 
-        def no_update(name=name, opt=opt):  # capture instead of Adam: every step sees the same weights
+        def no_update(grad_scale=1.0, name=name, opt=opt):  # capture instead of Adam: every step sees the same weights
             hip_ops.join_side_stream()
             grads[name] = opt.flat.grad.detach().clone()
         opt.step = no_update
