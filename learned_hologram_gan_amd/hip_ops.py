@@ -470,7 +470,7 @@ def operand_absmax(t):
     return out
 
 
-_TIMING_FAKE_CHANMAX = os.environ.get("LHG_TIMING_FAKE_CHANMAX", "0") == "1"
+_TIMING_FAKE_CHANMAX = False  # set by _timing_switch("LHG_TIMING_FAKE_CHANMAX") once it is defined (below)
 _FAKE_CMAX = {}
 
 
@@ -839,8 +839,7 @@ class Conv2dFn(TrackedFunction):
         ctx.bias = bias if (bias is not None and ctx.needs_input_grad[2]) else None  # its gradient never passes through autograd
         note_use(ctx.bias)
         gemm = not (w.shape[2] == w.shape[3] and thin_mode(w.shape[1], w.shape[0], w.shape[2], stride))
-        ctx.x_amax = operand_absmax(x) if gemm else None  # measured once: the forward GEMM and the weight-gradient GEMM both scale x by it
-        return conv2d_forward_raw(x, w, bias, stride, out=out, x_amax=ctx.x_amax)
+        return conv2d_forward_raw(x, w, bias, stride, out=out, x_amax=operand_absmax(x) if gemm else None)
 
     @staticmethod
     def backward(ctx, gy):
@@ -855,14 +854,14 @@ class Conv2dFn(TrackedFunction):
             return g_shared, None, None, None, None
         gy = _as_nhwc_view(gy)  # autograd may hand out an expanded (zero-stride) gradient, e.g. from .sum()
         gemm = not (w.shape[2] == w.shape[3] and thin_mode(w.shape[1], w.shape[0], w.shape[2], ctx.stride))
-        gy_amax = operand_absmax(gy) if gemm and gy.shape[-1] % 32 == 0 else None  # one measurement for both backward GEMMs
         if ctx.needs_input_grad[0]:
+            # the tensor scale of gy for the input-gradient GEMM (the weight gradient scales per channel: operand_chanmax)
+            gy_amax = operand_absmax(gy) if gemm and gy.shape[-1] % 32 == 0 else None
             gx = Conv2dInputGradFn.apply(gy, w, ctx.stride, x.shape[1], x.shape[2], x.shape[3], gy_amax, g_shared)
         if not param_grads_wanted():  # inside only_input_gradients(): the caller differentiates with respect to activations only
             return gx, None, None, None, None
         if ctx.needs_input_grad[1]:
-            xa = ctx.x_amax
-            gw = _weight_grad(w, (x, gy), lambda slot: conv2d_weight_grad(x, gy, w.shape, ctx.stride, slot, xa, gy_amax))
+            gw = _weight_grad(w, (x, gy), lambda slot: conv2d_weight_grad(x, gy, w.shape, ctx.stride, slot))
         if ctx.has_bias and ctx.needs_input_grad[2]:
             gb = _bias_grad(ctx.bias, gy, ctx.bias_grad_is_zero, w.shape[0])
         return gx, gw, gb, None, None
@@ -950,10 +949,24 @@ class Conv2dInputGradFn(TrackedFunction):
         return grads[:n]
 
 
-_TIMING_SKIP_WGRAD = os.environ.get("LHG_TIMING_SKIP_WGRAD", "0") == "1"
+def _timing_switch(name: str) -> bool:
+    """LHG_TIMING_* switches make the step compute WRONG gradients on purpose (what would it cost without ...): honoured only when the
+    process also sets LHG_ALLOW_WRONG_RESULTS=1 (tools/cpu_slack.py, tools/time_wgrad.py do), refused loudly otherwise."""
+    if os.environ.get(name, "0") != "1":
+        return False
+    if os.environ.get("LHG_ALLOW_WRONG_RESULTS", "0") != "1":
+        raise RuntimeError(f"{name}=1 produces wrong gradients (a timing experiment): set LHG_ALLOW_WRONG_RESULTS=1 as well, or unset it")
+    import warnings
+
+    warnings.warn(f"{name}=1: gradients of this process are WRONG on purpose (timing experiment)")
+    return True
 
 
-def conv2d_weight_grad_raw(x, gy, wshape, stride, slot=None, x_amax=None, gy_amax=None):
+_TIMING_SKIP_WGRAD = _timing_switch("LHG_TIMING_SKIP_WGRAD")
+_TIMING_FAKE_CHANMAX = _timing_switch("LHG_TIMING_FAKE_CHANMAX")
+
+
+def conv2d_weight_grad_raw(x, gy, wshape, stride, slot=None):
     """gw (OIHW) = sum over pixels of x (gathered) outer gy; no autograd.  With ``slot`` the slab reduction accumulates straight into
     it (the parameter's view of the flat gradient buffer) and nothing is returned."""
     Co, Ci, KH, KW = wshape
@@ -979,8 +992,7 @@ def conv2d_weight_grad_raw(x, gy, wshape, stride, slot=None, x_amax=None, gy_ama
     ci_pad, co_pad = pad_to(Cx, 64), pad_to(Cg, 64)
     slabs = torch.empty((S, KH * KW, ci_pad, co_pad), dtype=torch.float32, device=x.device)
     native.count_flops(1, 2.0 * N * gy.shape[1] * gy.shape[2] * Co * Ci * KH * KW)
-    # fp16-split mode: per-CHANNEL max|.| of both operands (the scalar tensor maxima the forward / input-gradient GEMMs use are not
-    # what this GEMM scales by: x_amax / gy_amax are accepted for the callers' convenience and ignored)
+    # fp16-split mode: per-CHANNEL max|.| of both operands (not the scalar tensor maxima the forward / input-gradient GEMMs scale by)
     x_cmax, gy_cmax = operand_chanmax(x), operand_chanmax(gyp)
     call("lhg_conv2d_backward_weight", px, N, H, W, Cx, ldx, pg, Cg, ldg, KH, KW, stride, ptr(slabs), S, ci_pad, co_pad,
          ptr(x_cmax), ptr(gy_cmax), stream_ptr())
@@ -991,11 +1003,11 @@ def conv2d_weight_grad_raw(x, gy, wshape, stride, slot=None, x_amax=None, gy_ama
     return None if slot is not None else gw
 
 
-def conv2d_weight_grad(x, gy, wshape, stride, slot, x_amax=None, gy_amax=None):
+def conv2d_weight_grad(x, gy, wshape, stride, slot):
     """Differentiable op without a slot, raw accumulation with one."""
     if slot is None:
         return Conv2dWeightGradFn.apply(x, gy, wshape, stride)
-    return conv2d_weight_grad_raw(x, gy, wshape, stride, slot, x_amax, gy_amax)
+    return conv2d_weight_grad_raw(x, gy, wshape, stride, slot)
 
 
 def _bias_grad(bias, gy, is_zero, Co):

@@ -159,7 +159,8 @@ def test_config4_per_rank_bs1_three_plane_reconstruction_loss_384(precision):
              "part1.part1.encoder1.0.0.convolution_layer_1.weight", "part2.part1.conv_g.params")
     assert rel_err(amps[n:].cpu(), a_ref[n:]) < PARITY  # the target planes never see a conv GEMM
     if precision == "fp32":
-        assert rel_err(amps[:n].detach().cpu(), a_ref[:n].detach()) < 1e-3
+        e_amp = rel_err(amps[:n].detach().cpu(), a_ref[:n].detach())
+        assert e_amp < PARITY, e_amp  # north_star's 1e-4 against the CPU oracle, asserted directly (round 4; was 1e-3)
         for got, ref in zip((focal, mse, tv), terms_ref):
             assert abs(got.item() - ref.item()) <= 1e-3 * abs(ref.item()) + 1e-7
         for k in probe:

@@ -532,8 +532,11 @@ def test_full_size_train_step_vs_oracle(oracle_full_step):
     out = W.train_step(rgbd.to(DEV), tamp.to(DEV), tphs.to(DEV), idx, [a.to(DEV) for a in alphas])
     # angle() is ill-conditioned where |field| is small: bound the bulk tightly and the worst pixel loosely
     perr = (torch.exp(1j * out["POH"].cpu()) - torch.exp(1j * ref["POH"])).abs().flatten()
-    assert torch.quantile(perr[::7], 0.999) < 1e-3 and perr.max() < 5e-2, (torch.quantile(perr[::7], 0.999).item(), perr.max().item())
-    assert rel_err(out["hat_amps"].cpu(), ref["hat_amps"]) < 1e-3
+    # north_star's 1e-4 asserted DIRECTLY against the CPU oracle (round 4): the default mode's distance to a float64 evaluation is
+    # 2.5e-5 (hat_amps, max norm) / 3.6e-5 (hologram, 99.9 % quantile), the CPU's own 3.3e-5 / 2.3e-5 (profiles/r03_truth_tests.jsonl),
+    # so the two fp32 evaluations are at most 5.9e-5 apart
+    assert torch.quantile(perr[::7], 0.999) < PARITY and perr.max() < 5e-2, (torch.quantile(perr[::7], 0.999).item(), perr.max().item())
+    assert rel_err(out["hat_amps"].cpu(), ref["hat_amps"]) < PARITY
     assert rel_err(out["target_amps"].cpu(), ref["target_amps"]) < PARITY
     got = dict(zip(("focal_phase_gradient_loss", "perceptual_loss", "pixel_loss", "TV_loss", "gan_loss", "G_loss", "D_loss"),
                    W.train_losses_tensor.tolist()))
@@ -813,27 +816,26 @@ def test_training_and_generation_clis_end_to_end(tmp_path):
 
 # ----------------------------------------------------------------------------- data-parallel bench path, two ranks on one GPU
 def test_two_rank_bench_rehearsal():
-    """`bench.py --gpus 2` as the driver launches it (torch.distributed.run, one process per rank), rehearsed on ONE GPU with the gloo
-    backend (RCCL needs one GPU per rank): every rank must issue the same collectives — a rank-conditional train step deadlocks here."""
+    """`python bench.py --gpus 2` launched PLAINLY, as the driver launches `--gpus 1` (no torchrun, WORLD_SIZE unset): the parent starts
+    the two ranks itself before touching the GPU and relays rank 0's line.  Rehearsed on ONE GPU with the gloo backend (RCCL needs one
+    GPU per rank): every rank must issue the same collectives — a rank-conditional train step deadlocks here."""
     import json
     import os
-    import socket
     import subprocess
     import sys
 
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, LHG_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
-    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
-           "--master-port", str(port), os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rows", "64",
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    env.update(LHG_DIST_BACKEND="gloo", HSA_ENABLE_IPC_MODE_LEGACY="0")
+    cmd = [sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "2", "--warmup", "1", "--rows", "64",
            "--cols", "64", "--pad", "32", "--cpu-baseline", "0", "--secondary", "0", "--other-modes", "0"]
     res = subprocess.run(cmd, cwd=root, env=env, capture_output=True, text=True, timeout=280)
     assert res.returncode == 0, res.stderr[-2000:]
-    line = [ln for ln in res.stdout.splitlines() if ln.startswith("{")][-1]
-    out = json.loads(line)
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 2 and out["value"] > 0 and out["config"]["global_batch"] == 8
+    assert out["rccl_ranks"] is None  # gloo rehearsal: the line must not claim RCCL ranks it did not have
     assert set(out["roofline"]) >= {"bound", "achieved", "peak", "unit", "frac", "traffic"}
 
 

@@ -36,16 +36,19 @@ KMAX = 8.0
 KGRAD = 5.0
 KPAR = 12.0
 MODES = ("fp32_split_f16", "fp32", "fp32_split")
-RECORD = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r03_truth_tests.jsonl")
+# written by the tests themselves; gpurun_out/ is what travels back from the GPU box, tools/collect_records.py stamps the file with the
+# revision and moves it to profiles/ (no hand copy)
+RECORD = os.path.join(os.environ.get("LHG_RECORD_DIR") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"),
+                      "r04_truth_tests.jsonl")
 
 
-def _record(test, mode, **values):
-    """Every measured (e_gpu, e_cpu) pair of these tests is kept: one JSON line per test and mode (copied to profiles/ by hand)."""
+def _record(test, mode, notes=None, **values):
+    """Every measured (e_gpu, e_cpu) pair of these tests is kept: one JSON line per test and mode; ``notes``: names (the worst parameter)."""
     import json
 
     os.makedirs(os.path.dirname(RECORD), exist_ok=True)
     with open(RECORD, "a") as f:
-        f.write(json.dumps({"test": test, "mode": mode, **{k: [float(a), float(b)] for k, (a, b) in values.items()}}) + "\n")
+        f.write(json.dumps({"test": test, "mode": mode, **(notes or {}), **{k: [float(a), float(b)] for k, (a, b) in values.items()}}) + "\n")
 
 
 @pytest.fixture(params=MODES)
@@ -119,7 +122,10 @@ def test_generator_tail_vs_fp64_truth(rows, pad, batch, gemm_mode):
         if e_g / max(e_c, 1e-12) > worst:
             worst, worst_key, worst_name = e_g / max(e_c, 1e-12), (e_g, e_c), k
     rec["param_grad_l2_worst_ratio"] = worst_key
-    _record(f"generator_tail[{rows}]", gemm_mode, **rec)
+    # the three parameters furthest from the truth relative to the CPU, by NAME (the record kept only the ratio)
+    ranked = sorted(((_l2(named[k].grad.cpu(), g64) / max(_l2(gw32[k], g64), 1e-12), k, _l2(named[k].grad.cpu(), g64), _l2(gw32[k], g64), float(g64.norm()))
+                     for k, g64 in gw64.items() if not k.endswith(("convolution_layer_1.bias", "convolution_layer_2.bias")) and g64.norm() != 0), reverse=True)[:3]
+    _record(f"generator_tail[{rows}]", gemm_mode, notes={"worst_parameters": [{"name": k, "ratio": r, "e_gpu": eg, "e_cpu": ec, "norm": nn} for r, k, eg, ec, nn in ranked]}, **rec)
     assert worst > 0
     assert worst_key[0] <= KPAR * worst_key[1] + 1e-4, (worst_name, worst_key)
     assert rec["poh_q999"][0] <= K * rec["poh_q999"][1] + 1e-5, rec

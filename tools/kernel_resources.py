@@ -13,8 +13,12 @@ if match in args:
 files = args or [os.path.join(REPO, "learned_hologram_gan_amd", "csrc", "conv_engine.hip")]
 keys = ("VGPRs", "AGPRs", "ScratchSize", "Occupancy", "LDS Size", "VGPRs Spill")
 for f in files:
+    # the SAME device flags as the shipped build (__graft_entry__.NO_PACKED_FP32): the table must describe the binary that runs
+    sys.path.insert(0, REPO)
+    from __graft_entry__ import NO_PACKED_FP32
+
     out = subprocess.run(["/opt/rocm/bin/hipcc", "--offload-arch=gfx950", "-O3", "-std=c++17", "-fPIC", "-fno-gpu-rdc", "-c", f, "-o", "/dev/null",
-                          "-Rpass-analysis=kernel-resource-usage"], capture_output=True, text=True).stderr
+                          "-Rpass-analysis=kernel-resource-usage"] + NO_PACKED_FP32, capture_output=True, text=True).stderr
     cur, rows = None, {}
     for ln in out.splitlines():
         m = re.search(r"remark: Function Name: (\S+)", ln)
