@@ -240,6 +240,31 @@ int lhg_conv_transpose2x2_backward_weight(const float* x, int N, int H, int W, i
 int lhg_wgrad_reduce(const float* slabs, int S, int T, int m_pad, int n_pad,
                      float* grad, int D0, int D1, int m_is_d1, int accumulate, lhg_stream_t s);
 
+/* ABI 6 — the weight gradient straight into the gradient tensor: grad (OIHW for Conv2d, IOHW for ConvTranspose2d) (+)= dW, GEMM and
+ * reduction behind ONE call.  ref: the weight gradients of F.conv2d / ConvTranspose2d (neural_network_components.py:9-30, 270-286,
+ * discriminator.py:16-41) as loss.backward() produces them (watermelon.py:256, 275).  In LHG_PRECISION_F32_SPLIT_F16 with fp32 storage
+ * the GEMM is the tap-fused kernel (csrc/wg6_kernel.inc): the taps of a kernel row (or the whole 3x3 kernel) share one staged tile of
+ * each operand, K is split just far enough to fill the chip, and the LAST workgroup of an output tile to finish sums the partial slabs
+ * in split order inside the same launch (deterministic; for many splits a reduce launch follows instead); every other mode runs the
+ * per-tap GEMM + lhg_wgrad_reduce.  `ws`: 256-byte aligned scratch of >= ..._workspace(...) bytes (partial slabs and the tickets of
+ * the in-launch reduction, zeroed by the call); `x_absmax` / `gy_absmax`: per-channel maxima as for lhg_conv2d_backward_weight. */
+size_t lhg_conv2d_backward_weight_workspace(int N, int H, int W, int Ci, int Co, int KH, int KW, int stride);
+int lhg_conv2d_backward_weight_into(const float* x, int N, int H, int W, int Ci, int ldx,
+                                    const float* gy, int Co, int ldgy, int KH, int KW, int stride,
+                                    float* grad, int accumulate, void* ws, size_t ws_bytes,
+                                    const float* x_absmax, const float* gy_absmax, lhg_stream_t s);
+size_t lhg_conv_transpose2x2_backward_weight_workspace(int N, int H, int W, int Ci, int Co);
+int lhg_conv_transpose2x2_backward_weight_into(const float* x, int N, int H, int W, int Ci, int ldx,
+                                               const float* gy, int Co, int ldgy,
+                                               float* grad, int accumulate, void* ws, size_t ws_bytes,
+                                               const float* x_absmax, const float* gy_absmax, lhg_stream_t s);
+/* Debugging aid of the tap-fused kernel (tools/wg6_sweep.py, tests): force its tile variant (0 .. lhg_wg6_variants() - 1), split count
+ * and reduction form (1 in-launch, 0 separate launch) for the following calls; -1 = the library's deterministic plan. */
+int lhg_wg6_force(int variant, int splits, int fused);
+int lhg_wg6_last_plan(int* variant, int* splits, int* fused); /* what the last tap-fused launch of this process ran with */
+int lhg_wg6_variants(void);
+const char* lhg_wg6_variant_name(int variant);
+
 /* out[c] (+)= sum over pixels of x[pixel][c]  (bias gradients).  ws: >= 2048*C floats. */
 int lhg_channel_sum(const float* x, long long pixels, int C, int ld, float* out, int accumulate, float* ws, lhg_stream_t s);
 

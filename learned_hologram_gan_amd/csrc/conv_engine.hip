@@ -32,6 +32,7 @@
 #include <vector>
 
 #include "common.h"
+#include "wg6_api.h"
 
 namespace lhg {
 
@@ -1526,6 +1527,112 @@ int lhg_conv_transpose2x2_backward_weight(const float* x, int N, int H, int W, i
       if (rc) return rc;
     }
   return LHG_OK;
+}
+
+// ---- weight gradient straight into the gradient tensor (ABI 6): tap-fused GEMM (wgrad6.hip) where it applies, the per-tap kernels
+// + lhg_wgrad_reduce otherwise.  Workspace: [tickets, 256-byte aligned][partial slabs].
+static bool wg6_mode() { return split_f16() && !act_is_bf16(); }
+
+static void wg6_conv_problem(Wg6Problem& q, const float* x, int N, int H, int W, int Ci, int ldx, const float* gy, int Co, int ldgy, int KH, int KW,
+                             int stride, const float* x_cmax, const float* gy_cmax) {
+  q.strip = x; q.point = gy; q.strip_cmax = x_cmax; q.point_cmax = gy_cmax;
+  q.N = N; q.Hs = H; q.Ws = W; q.Cm = Ci; q.lds = ldx;
+  q.gh = (H + 2 * (KH / 2) - KH) / stride + 1; q.gw = (W + 2 * (KW / 2) - KW) / stride + 1; q.Cn = Co; q.ldp = ldgy;
+  q.krows = KH; q.nt = KW; q.stride = stride; q.dy0 = -(KH / 2); q.dx0 = -(KW / 2);
+  q.m_pad = pad64(Ci); q.n_pad = pad64(Co);
+}
+
+static void wg6_convt_problem(Wg6Problem& q, const float* x, int N, int H, int W, int Ci, int ldx, const float* gy, int Co, int ldgy,
+                              const float* x_cmax, const float* gy_cmax) {
+  // dW[ci][co][py][px] = sum_p x[p][ci] gy[2p + (py, px)][co]: the STRIP operand is gy (twice the extent, stride 2), the point operand x
+  q.strip = gy; q.point = x; q.strip_cmax = gy_cmax; q.point_cmax = x_cmax;
+  q.N = N; q.Hs = 2 * H; q.Ws = 2 * W; q.Cm = Co; q.lds = ldgy;
+  q.gh = H; q.gw = W; q.Cn = Ci; q.ldp = ldx;
+  q.krows = 2; q.nt = 2; q.stride = 2; q.dy0 = 0; q.dx0 = 0;
+  q.m_pad = pad64(Co); q.n_pad = pad64(Ci);
+}
+
+static size_t wg6_workspace_bytes(const Wg6Problem& q) {
+  const Wg6Plan plan = wg6_plan(q);
+  if (plan.variant < 0) return 0;
+  return 256 * (((size_t)wg6_tickets(q, plan) * 4 + 255) / 256) + wg6_slab_floats(q, plan) * 4;
+}
+
+static int wg6_run(const Wg6Problem& q, float* grad, int accumulate, void* ws, size_t ws_bytes, hipStream_t st, bool& handled) {
+  handled = false;
+  if (!wg6_mode()) return LHG_OK;
+  const Wg6Plan plan = wg6_plan(q);
+  if (plan.variant < 0) return LHG_OK;
+  handled = true;
+  const size_t tk_bytes = 256 * (((size_t)wg6_tickets(q, plan) * 4 + 255) / 256);
+  const size_t need = tk_bytes + wg6_slab_floats(q, plan) * 4;
+  if (need > ws_bytes) return fail(LHG_E_WORKSPACE, "backward_weight: workspace %zu < %zu bytes", ws_bytes, need);
+  LHG_REQUIRE(need == 0 || (reinterpret_cast<uintptr_t>(ws) & 255) == 0, "backward_weight: workspace must be 256-byte aligned");
+  unsigned* tickets = tk_bytes ? static_cast<unsigned*>(ws) : nullptr;
+  float* slabs = reinterpret_cast<float*>(static_cast<char*>(ws) + tk_bytes);
+  if (tk_bytes && hipMemsetAsync(tickets, 0, tk_bytes, st) != hipSuccess) return fail(LHG_E_LAUNCH, "backward_weight: hipMemsetAsync failed");
+  const int T = q.krows * q.nt;
+  const double flops = 2.0 * q.N * q.gh * (double)q.gw * q.m_pad * q.n_pad * T;
+  {
+    ScopedKernelTime timed(1, st, flops);
+    Geom g{};
+    g.M = q.N * q.gh * q.gw; g.Ci = q.Cm; g.Co = q.Cn; g.T = T; g.istep = q.stride; g.ostep = 1; g.Hi = q.Hs;
+    timed.tag(g, q.m_pad, q.n_pad, 1000 + plan.variant + 100 * 1000 * plan.S + (plan.fused ? 100 * 1000 * 1000 : 0), flops);
+    const int rc = wg6_launch(q, plan, slabs, tickets, grad, accumulate, st);
+    if (rc) return rc;
+  }
+  if (!plan.fused) return wg6_reduce(slabs, plan.S, T, q.m_pad, q.n_pad, grad, q.Cn, q.Cm, accumulate, st);
+  return LHG_OK;
+}
+
+size_t lhg_conv2d_backward_weight_workspace(int N, int H, int W, int Ci, int Co, int KH, int KW, int stride) {
+  if (!conv_args_ok(KH, KW, stride)) return 0;
+  const size_t per_tap = (size_t)lhg_conv2d_wgrad_splits(N, H, W, Ci, Co, KH, KW, stride) * KH * KW * pad64(Ci) * pad64(Co) * 4;
+  Wg6Problem q{};
+  wg6_conv_problem(q, nullptr, N, H, W, Ci, Ci, nullptr, Co, Co, KH, KW, stride, nullptr, nullptr);
+  return std::max(per_tap, wg6_mode() ? wg6_workspace_bytes(q) : 0);
+}
+
+int lhg_conv2d_backward_weight_into(const float* x, int N, int H, int W, int Ci, int ldx, const float* gy, int Co, int ldgy, int KH, int KW,
+                                    int stride, float* grad, int accumulate, void* ws, size_t ws_bytes, const float* x_absmax,
+                                    const float* gy_absmax, lhg_stream_t s) {
+  LHG_REQUIRE(conv_args_ok(KH, KW, stride), "conv2d_backward_weight: unsupported kernel %dx%d stride %d", KH, KW, stride);
+  Wg6Problem q{};
+  wg6_conv_problem(q, x, N, H, W, Ci, ldx, gy, Co, ldgy, KH, KW, stride, x_absmax, gy_absmax);
+  bool handled = false;
+  int rc = wg6_run(q, grad, accumulate, ws, ws_bytes, as_stream(s), handled);
+  if (rc || handled) return rc;
+  const int S = lhg_conv2d_wgrad_splits(N, H, W, Ci, Co, KH, KW, stride);
+  const int ci_pad = pad64(Ci), co_pad = pad64(Co);
+  const size_t need = (size_t)S * KH * KW * ci_pad * co_pad * 4;
+  if (need > ws_bytes) return fail(LHG_E_WORKSPACE, "conv2d_backward_weight: workspace %zu < %zu bytes", ws_bytes, need);
+  rc = lhg_conv2d_backward_weight(x, N, H, W, Ci, ldx, gy, Co, ldgy, KH, KW, stride, static_cast<float*>(ws), S, ci_pad, co_pad, x_absmax, gy_absmax, s);
+  if (rc) return rc;
+  return lhg_wgrad_reduce(static_cast<float*>(ws), S, KH * KW, ci_pad, co_pad, grad, Co, Ci, 1, accumulate, s);
+}
+
+size_t lhg_conv_transpose2x2_backward_weight_workspace(int N, int H, int W, int Ci, int Co) {
+  const size_t per_tap = (size_t)lhg_conv_transpose2x2_wgrad_splits(N, H, W, Ci, Co) * 4 * pad64(Ci) * pad64(Co) * 4;
+  Wg6Problem q{};
+  wg6_convt_problem(q, nullptr, N, H, W, Ci, Ci, nullptr, Co, Co, nullptr, nullptr);
+  return std::max(per_tap, wg6_mode() ? wg6_workspace_bytes(q) : 0);
+}
+
+int lhg_conv_transpose2x2_backward_weight_into(const float* x, int N, int H, int W, int Ci, int ldx, const float* gy, int Co, int ldgy,
+                                               float* grad, int accumulate, void* ws, size_t ws_bytes, const float* x_absmax,
+                                               const float* gy_absmax, lhg_stream_t s) {
+  Wg6Problem q{};
+  wg6_convt_problem(q, x, N, H, W, Ci, ldx, gy, Co, ldgy, x_absmax, gy_absmax);
+  bool handled = false;
+  int rc = wg6_run(q, grad, accumulate, ws, ws_bytes, as_stream(s), handled);
+  if (rc || handled) return rc;
+  const int S = lhg_conv_transpose2x2_wgrad_splits(N, H, W, Ci, Co);
+  const int ci_pad = pad64(Ci), co_pad = pad64(Co);
+  const size_t need = (size_t)S * 4 * ci_pad * co_pad * 4;
+  if (need > ws_bytes) return fail(LHG_E_WORKSPACE, "conv_transpose2x2_backward_weight: workspace %zu < %zu bytes", ws_bytes, need);
+  rc = lhg_conv_transpose2x2_backward_weight(x, N, H, W, Ci, ldx, gy, Co, ldgy, static_cast<float*>(ws), S, ci_pad, co_pad, x_absmax, gy_absmax, s);
+  if (rc) return rc;
+  return lhg_wgrad_reduce(static_cast<float*>(ws), S, 4, ci_pad, co_pad, grad, Ci, Co, 0, accumulate, s);
 }
 
 int lhg_absmax(const float* x, long long pixels, int C, int ld, float* out, lhg_stream_t s) {

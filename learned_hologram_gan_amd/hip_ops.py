@@ -988,19 +988,34 @@ def conv2d_weight_grad_raw(x, gy, wshape, stride, slot=None):
     px, N, H, W, Cx, ldx = nhwc(x)
     pg, _, _, _, Cg, ldg = nhwc(gyp)
     lib = native.load()
-    S = lib.lhg_conv2d_wgrad_splits(N, H, W, Cx, Cg, KH, KW, stride)
-    ci_pad, co_pad = pad_to(Cx, 64), pad_to(Cg, 64)
-    slabs = torch.empty((S, KH * KW, ci_pad, co_pad), dtype=torch.float32, device=x.device)
     native.count_flops(1, 2.0 * N * gy.shape[1] * gy.shape[2] * Co * Ci * KH * KW)
     # fp16-split mode: per-CHANNEL max|.| of both operands (not the scalar tensor maxima the forward / input-gradient GEMMs scale by)
     x_cmax, gy_cmax = operand_chanmax(x), operand_chanmax(gyp)
-    call("lhg_conv2d_backward_weight", px, N, H, W, Cx, ldx, pg, Cg, ldg, KH, KW, stride, ptr(slabs), S, ci_pad, co_pad,
-         ptr(x_cmax), ptr(gy_cmax), stream_ptr())
     gw = slot if slot is not None else torch.empty(tuple(wshape), dtype=torch.float32, device=x.device)
     if not gw.is_contiguous():
         raise ValueError("weight-gradient slot must be contiguous")
+    if Ci % 4 == 0 and Co % 4 == 0:
+        # GEMM + reduction of the K splits behind one call (in one launch where the tap-fused kernel reduces its slabs itself); the
+        # operands may carry padding channels behind the weight's (their pixel strides say so)
+        nbytes = int(lib.lhg_conv2d_backward_weight_workspace(N, H, W, Ci, Co, KH, KW, stride))
+        ws = _wgrad_workspace(nbytes, x.device)
+        call("lhg_conv2d_backward_weight_into", px, N, H, W, Ci, ldx, pg, Co, ldg, KH, KW, stride, ptr(gw), int(slot is not None), ptr(ws), nbytes,
+             ptr(x_cmax), ptr(gy_cmax), stream_ptr())
+        return None if slot is not None else gw
+    # channel counts that are not multiples of four: the operands' padded counts through the per-tap GEMM, the true ones in the reduction
+    S = lib.lhg_conv2d_wgrad_splits(N, H, W, Cx, Cg, KH, KW, stride)
+    ci_pad, co_pad = pad_to(Cx, 64), pad_to(Cg, 64)
+    slabs = torch.empty((S, KH * KW, ci_pad, co_pad), dtype=torch.float32, device=x.device)
+    call("lhg_conv2d_backward_weight", px, N, H, W, Cx, ldx, pg, Cg, ldg, KH, KW, stride, ptr(slabs), S, ci_pad, co_pad,
+         ptr(x_cmax), ptr(gy_cmax), stream_ptr())
     call("lhg_wgrad_reduce", ptr(slabs), S, KH * KW, ci_pad, co_pad, ptr(gw), Co, Ci, 1, int(slot is not None), stream_ptr())
     return None if slot is not None else gw
+
+
+def _wgrad_workspace(nbytes, device):
+    """Scratch of a weight-gradient call (partial slabs + tickets): a fresh allocation per call — the caching allocator hands the block
+    back to the stream that used it (the weight-gradient stream), 256-byte aligned like every block it returns."""
+    return torch.empty((max(nbytes, 256) // 4 + 1,), dtype=torch.float32, device=device)
 
 
 def conv2d_weight_grad(x, gy, wshape, stride, slot):
@@ -1096,14 +1111,12 @@ class ConvTranspose2x2Fn(TrackedFunction):
             def wgrad(slot):
                 px, N, H, W, Cx, ldx = nhwc(x)
                 pg, _, _, _, Cg, ldg = nhwc(gy)
-                S = native.load().lhg_conv_transpose2x2_wgrad_splits(N, H, W, Cx, Cg)
-                ci_pad, co_pad = pad_to(Cx, 64), pad_to(Cg, 64)
-                slabs = torch.empty((S, 4, ci_pad, co_pad), dtype=torch.float32, device=x.device)
+                nbytes = int(native.load().lhg_conv_transpose2x2_backward_weight_workspace(N, H, W, Cx, Cg))
+                ws = _wgrad_workspace(nbytes, x.device)
                 native.count_flops(1, 2.0 * N * H * W * 4 * Ci * Co)
-                call("lhg_conv_transpose2x2_backward_weight", px, N, H, W, Cx, ldx, pg, Cg, ldg, ptr(slabs), S, ci_pad, co_pad,
-                     ptr(operand_chanmax(x)), ptr(operand_chanmax(gy)), stream_ptr())
                 out = slot if slot is not None else torch.empty(w.shape, dtype=torch.float32, device=x.device)
-                call("lhg_wgrad_reduce", ptr(slabs), S, 4, ci_pad, co_pad, ptr(out), Ci, Co, 0, int(slot is not None), stream_ptr())
+                call("lhg_conv_transpose2x2_backward_weight_into", px, N, H, W, Cx, ldx, pg, Cg, ldg, ptr(out), int(slot is not None), ptr(ws), nbytes,
+                     ptr(operand_chanmax(x)), ptr(operand_chanmax(gy)), stream_ptr())
                 return None if slot is not None else out
 
             gw = _weight_grad(w, (x, gy), wgrad)

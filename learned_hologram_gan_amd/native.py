@@ -104,8 +104,17 @@ _SIGNATURES = {
     "lhg_psnr_ssim": [_p, _p, _i, _i, _i, _p, _p, _sz, _p],
     "lhg_adam_step": [_p, _p, _p, _p, _ll, _f, _f, _f, _f, _i, _p],
     "lhg_adam_step_scaled": [_p, _p, _p, _p, _ll, _f, _f, _f, _f, _i, _f, _p, _p],
+    "lhg_conv2d_backward_weight_workspace": [_i, _i, _i, _i, _i, _i, _i, _i],
+    "lhg_conv2d_backward_weight_into": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _p, _i, _p, _sz, _p, _p, _p],
+    "lhg_conv_transpose2x2_backward_weight_workspace": [_i, _i, _i, _i, _i],
+    "lhg_conv_transpose2x2_backward_weight_into": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _i, _p, _sz, _p, _p, _p],
+    "lhg_wg6_force": [_i, _i, _i],
+    "lhg_wg6_last_plan": [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)],
+    "lhg_wg6_variants": [],
+    "lhg_wg6_variant_name": [_i],
 }
-_RESTYPE = {"lhg_last_error": C.c_char_p, "lhg_packed_weight_floats": C.c_longlong, "lhg_fft_table_floats": C.c_longlong, "lhg_chanmax_partial_rows": C.c_longlong, "lhg_conv2d_thin_wgrad_workspace": C.c_size_t, "lhg_psnr_ssim_workspace": C.c_size_t}
+_RESTYPE = {"lhg_last_error": C.c_char_p, "lhg_packed_weight_floats": C.c_longlong, "lhg_fft_table_floats": C.c_longlong, "lhg_chanmax_partial_rows": C.c_longlong, "lhg_conv2d_thin_wgrad_workspace": C.c_size_t, "lhg_psnr_ssim_workspace": C.c_size_t,
+            "lhg_conv2d_backward_weight_workspace": C.c_size_t, "lhg_conv_transpose2x2_backward_weight_workspace": C.c_size_t, "lhg_wg6_variant_name": C.c_char_p}
 
 _lib = None
 
