@@ -256,6 +256,7 @@ class GradSynchronizer:
         """Call after backward: launches buckets whose parameters got no gradient this pass,
         waits for all reductions and turns sums into means."""
         if not self.enabled:
+            self.grad_scale = 1.0  # a local pass: the buffer holds this rank's own gradient
             return
         self._armed = False
         from . import hip_ops
