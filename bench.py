@@ -48,9 +48,9 @@ BF16_MFMA_PEAK_TFLOPS = 2500.0  # dense bf16 MFMA peak (same table)
 
 
 def kernel_sources():
-    """Every kernel source of the conv engine (conv_engine.hip and the .inc files it includes): a glob, so a new include cannot be forgotten."""
+    """Every kernel source of the conv engine (conv_engine.hip, wgrad6.hip, the .inc and wg6_*.h files they include): globs, so a new include cannot be forgotten."""
     d = os.path.join(REPO, "learned_hologram_gan_amd", "csrc")
-    return sorted(glob.glob(os.path.join(d, "*.inc")) + [os.path.join(d, "conv_engine.hip"), os.path.join(d, "common.h")])
+    return sorted(glob.glob(os.path.join(d, "*.inc")) + glob.glob(os.path.join(d, "wg6_*.h")) + [os.path.join(d, "conv_engine.hip"), os.path.join(d, "wgrad6.hip"), os.path.join(d, "common.h")])
 
 
 def parse():

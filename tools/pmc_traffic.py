@@ -12,10 +12,10 @@ REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
 def kernel_source_sha16():
-    """= bench.kernel_source_sha16(): every .inc of csrc/ plus conv_engine.hip and common.h."""
+    """= bench.kernel_source_sha16(): every .inc / wg6_*.h of csrc/ plus conv_engine.hip, wgrad6.hip and common.h."""
     d = os.path.join(REPO, "learned_hologram_gan_amd", "csrc")
     h = hashlib.sha256()
-    for path in sorted(glob.glob(os.path.join(d, "*.inc")) + [os.path.join(d, "conv_engine.hip"), os.path.join(d, "common.h")]):
+    for path in sorted(glob.glob(os.path.join(d, "*.inc")) + glob.glob(os.path.join(d, "wg6_*.h")) + [os.path.join(d, "conv_engine.hip"), os.path.join(d, "wgrad6.hip"), os.path.join(d, "common.h")]):
         with open(path, "rb") as f:
             h.update(f.read())
     return h.hexdigest()[:16]
