@@ -70,7 +70,9 @@ def parse():
     ap.add_argument("--profile-steps", type=int, default=5, help="steps of each instrumented pass behind `roofline`")
     ap.add_argument("--cli-default", type=int, default=1, help="0 skips the informational timing of the reference CLI's default step (d_ratio 5, perceptual 0.1)")
     ap.add_argument("--other-modes", type=int, default=1, help="0 skips the informational timing of the other GEMM formulations")
-    ap.add_argument("--graph", type=int, default=0, help="infer mode: replay a captured hipGraph instead of eager launches")
+    ap.add_argument("--graph", type=int, default=-1,
+                    help="replay a captured hipGraph instead of eager launches.  train mode: the whole step as one replay (graph.GraphedTrainStep), "
+                         "default on for a single process (collectives are not captured); infer mode: default off")
     ap.add_argument("--dtype", choices=("f32", "bf16"), default="f32",
                     help="f32 (the benchmark metric): fp32 tensors, conv GEMMs in the library's default fp32-faithful mode.  bf16 (BASELINE configs[2]/[4], informational): bf16 conv-GEMM operands, "
                          "fp32 accumulation")
@@ -306,7 +308,10 @@ def main():
                     discriminator_loss_weight=1e-1, lr_G=1e-3, lr_D=1e-3, discriminator_train_ratio=args.d_ratio, discriminator_lambda=10)
         return T
 
+    train_graph = world == 1 and (args.graph != 0)
+
     W = build_trainer()
+    W.use_graph = train_graph
     g = torch.Generator().manual_seed(122731 + rank)
     B = args.batch
     rgbd = torch.rand((B, 4, args.rows, args.cols), generator=g).to(dev)
@@ -332,7 +337,7 @@ def main():
             def run(x):  # noqa: F811
                 poh = gen(x)
                 return prop(torch.ones_like(poh), poh, dist_p)
-        if args.graph:
+        if args.graph > 0:
             from learned_hologram_gan_amd.graph import GraphedGenerator
 
             graphed = GraphedGenerator(W.generator, rgbd)
@@ -353,7 +358,7 @@ def main():
                               "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
                               "config": {"workload": f"{args.rows}x{args.cols}x3 bs={B} generator forward (UNet + ASM back-propagation + POH encode)"
                                                      + (f" + propagation to {args.planes} planes" if args.planes > 0 else "")
-                                                     + (", hipGraph replay" if args.graph else "")}}))
+                                                     + (", hipGraph replay" if args.graph > 0 else "")}}))
         return
 
     # LHG_MAIN_PRIORITY=high (A/B measurements): the step's main chain of kernels on a high-priority stream
@@ -367,6 +372,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         W.train_step(rgbd, tamp, tphs)
+    host_enqueue = time.perf_counter() - t0  # the host's share: it has handed every launch / replay of the K steps to the stream
     sync()
     elapsed = time.perf_counter() - t0
     t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
@@ -376,6 +382,9 @@ def main():
 
     # ---- roofline passes (every rank: the steps contain collectives).  Pass 1: the timed region's conditions.  Pass 2: second stream off.
     P = max(1, min(args.steps, args.profile_steps))
+    W.use_graph = False  # the per-launch HIP events of the roofline passes need eager launches
+    W.train_step(rgbd, tamp, tphs)
+    torch.cuda.synchronize()
     with native.kernel_profile() as prof:
         for _ in range(P):
             W.train_step(rgbd, tamp, tphs)
@@ -423,6 +432,8 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": round(elapsed / args.steps * 1e3, 3),
+            "host_ms_per_step": round(host_enqueue / args.steps * 1e3, 3),  # host time to enqueue a step (eager: ~900 launches; graph: one replay)
+            "graph": bool(train_graph),
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -475,6 +486,7 @@ def main():
         hip_ops.set_conv_precision("default")
         hip_ops.set_activation_storage("bf16")
         W = build_trainer()
+        W.use_graph = train_graph  # this mode is launch-bound when launched eagerly (round 3: 21.7 ms of host work for a 23 ms step)
         for _ in range(12):  # the first ~10 steps after the switch are slower (allocator pool of the new tensor sizes, autotune)
             W.train_step(rgbd, tamp, tphs)
         sync()
@@ -483,6 +495,8 @@ def main():
             W.train_step(rgbd, tamp, tphs)
         sync()
         other["bf16_storage"] = round((time.perf_counter() - t0) / 8 * 1e3, 3)
+        W.use_graph = False
+        W.train_step(rgbd, tamp, tphs)
         by_mode["bf16_storage"] = dict(mode_roofline(BF16_MFMA_PEAK_TFLOPS, "dense bf16 MFMA peak, one product per multiply-add (bf16 operands AND bf16 activation storage: "
                                                      "informational, not the reference's precision)"), ms_per_step=other["bf16_storage"])
         hip_ops.set_activation_storage("fp32")

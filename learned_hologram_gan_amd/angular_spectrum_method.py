@@ -98,6 +98,8 @@ class bandLimitedAngularSpectrumMethod:
             if key not in self._index_cache:
                 self._index_cache[key] = (torch.arange(planes, dtype=torch.int32) % 3).to(self.device)
             return self._index_cache[key]
+        if offsets.is_cuda:  # device-resident plane indices (a captured train step reads them from a static buffer): no host round trip
+            return (offsets.to(torch.int32).reshape(-1, 1) * 3 + self._colour_index(3)).reshape(-1).contiguous()
         col = torch.arange(3, dtype=torch.int32)
         idx = (offsets.to(torch.int32).cpu().reshape(-1, 1) * 3 + col).reshape(-1)
         # a pageable host-to-device copy makes the host wait for everything queued on the stream: stage through pinned memory

@@ -66,6 +66,10 @@ class FusedAdam:
         self.exp_avg = torch.zeros_like(flat.data)
         self.exp_avg_sq = torch.zeros_like(flat.data)
         self.step_count = 0
+        # device-resident constants (graph.GraphedTrainStep): row k = {1 - b1^t, sqrt(1 - b2^t), grad scale, lr} of the k-th step() call of
+        # a captured train step; the kernel reads them at execution time, so a replayed launch follows the step count and the schedule
+        self.device_consts = None
+        self._consts_cursor = 0
 
     def zero_grad(self, set_to_none: bool = False):
         self.flat.zero_grad()
@@ -76,12 +80,30 @@ class FusedAdam:
         self.step_count += 1
         if self.flat.grad.is_cuda:
             hip_ops.join_side_stream(self.flat.grad.device)  # weight gradients accumulated on the side stream
+        consts = None
+        if self.device_consts is not None:
+            consts = self.device_consts[self._consts_cursor % self.device_consts.shape[0]]
+            self._consts_cursor += 1
         hip_ops.adam_step_(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1],
-                           self.eps, self.step_count, grad_scale)
+                           self.eps, self.step_count, grad_scale, consts)
         for p in self.flat.params:
             hip_ops.bump_version(p)
         if self.flat.data.is_cuda and _BATCHED_REPACK:
             hip_ops.repack_weights(self.flat.params)  # every packed form the convs hold, in one batched call
+
+    def consts_rows(self, first_step: int, calls: int, grad_scale: float = 1.0) -> torch.Tensor:
+        """Host values of ``calls`` rows of device constants for steps first_step, first_step + 1, ..."""
+        rows = torch.empty((calls, 4), dtype=torch.float32)
+        # the library's arithmetic (lhg_adam_step_scaled): the betas as the floats they are passed as, powers and the root in double,
+        # results rounded to float — bit-identical constants whether the host or the device supplies them
+        b1, b2 = (float(torch.tensor(b, dtype=torch.float32)) for b in self.betas)
+        for k in range(calls):
+            t = first_step + k
+            rows[k, 0] = 1.0 - b1 ** t
+            rows[k, 1] = (1.0 - b2 ** t) ** 0.5
+            rows[k, 2] = grad_scale
+            rows[k, 3] = self.lr
+        return rows
 
     def state_dict(self):
         return dict(step=self.step_count, exp_avg=self.exp_avg, exp_avg_sq=self.exp_avg_sq, lr=self.lr, betas=self.betas, eps=self.eps)

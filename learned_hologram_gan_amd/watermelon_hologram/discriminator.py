@@ -69,4 +69,4 @@ class fakeDiscriminator(nn.Module):
         self._requires_grad = False
 
     def forward(self, _):
-        return torch.tensor([0.0], device=self.device)
+        return torch.zeros(1, device=self.device)

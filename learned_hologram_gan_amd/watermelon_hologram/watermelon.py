@@ -15,6 +15,7 @@ file, so the trainer takes it as a constructor argument and ``perceptual_loss_we
 from __future__ import annotations
 
 import contextlib
+import os
 import json
 
 import torch
@@ -101,6 +102,9 @@ class watermelon:
             print(f"Discriminator loaded from {pretrained_model_path_D}")
         self._opt_G = self._opt_D = self._sync_G = self._sync_D = None
         self.skip_unused_critic_grads = True  # see train_step: critic weight gradients of the generator pass are dead values
+        # train_step as one hipGraph replay per batch (single process; static batch shape): LHG_TRAIN_GRAPH=1, or set the attribute
+        self.use_graph = os.environ.get("LHG_TRAIN_GRAPH", "0") == "1"
+        self._graphed = None
 
     def _make_discriminator(self, path):
         return WGANGPDiscriminator192(pretrained_model_path=path, cuda=True)
@@ -143,6 +147,7 @@ class watermelon:
             self._opt_D = self._sync_D = None
         self.train_losses_tensor = torch.zeros(7, device=self.device)
         self.train_metrics_tensor = torch.zeros(2, device=self.device)
+        self._graphed = None  # a captured step belongs to the optimisers / buffers it was recorded with
 
     # ------------------------------------------------------------------ pieces of the step
     def compute_gradient_penalty(self, real_samples, fake_samples, alpha=None):
@@ -200,6 +205,13 @@ class watermelon:
         if self._opt_G is None:
             raise RuntimeError("call configure(...) (or train(...)) before train_step")
         with hip_ops.deferred_gc():  # no collector pauses while the host thread is feeding the GPU
+            if self.use_graph and RGBD.is_cuda and self._sync_G.world == 1:
+                # the whole batch as ONE hipGraph replay (graph.GraphedTrainStep): ~900 launches per step leave the host
+                if self._graphed is None or self._graphed.rgbd.shape != RGBD.shape:
+                    from ..graph import GraphedTrainStep
+
+                    self._graphed = GraphedTrainStep(self, RGBD, target_amp, target_phs)
+                return self._graphed(RGBD, target_amp, target_phs, plane_indices, gp_alphas)
             return self._train_step(RGBD, target_amp, target_phs, plane_indices, gp_alphas)
 
     def _train_step(self, RGBD, target_amp, target_phs, plane_indices, gp_alphas):

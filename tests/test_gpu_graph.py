@@ -1,0 +1,79 @@
+"""The train step as ONE hipGraph replay (graph.GraphedTrainStep, watermelon.use_graph): same kernels, same order, same bits as the eager
+step — outputs, losses, both models' weights, Adam moments, BatchNorm buffers and step counts after several batches, with explicit and with
+drawn plane indices / gradient-penalty alphas; building the graph must not train."""
+
+import pytest
+import torch
+
+from oracle import seeded  # seeded weights / inputs only (test infrastructure)
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda:0"
+
+
+def _trainer(ratio, graph):
+    from learned_hologram_gan_amd.watermelon_hologram.watermelon import watermelon
+
+    rows = cols = 64
+    stack = torch.linspace(-4e-4, 0.0, 21)[:-1][:8]
+    W = watermelon(filter_radius_coefficient=0.45, pad_size=32, distance_stack=stack, input_shape=(1, 4, rows, cols))
+    W.generator.load_state_dict(seeded.generator_state_dict())
+    W.discriminator.load_state_dict(seeded.critic_state_dict())
+    W.generator.to(DEV).train()
+    W.discriminator.to(DEV).train()
+    W.configure(1, 0.0, 1, 1e-3, 0.1, 1e-3, 1e-3, ratio, 10)
+    W.use_graph = graph
+    return W
+
+
+def _state(W):
+    out = {"G": W._opt_G.flat.data.clone(), "Gm": W._opt_G.exp_avg.clone(), "Gv": W._opt_G.exp_avg_sq.clone(),
+           "D": W._opt_D.flat.data.clone(), "Dm": W._opt_D.exp_avg.clone(), "Dv": W._opt_D.exp_avg_sq.clone(),
+           "losses": W.train_losses_tensor.clone()}
+    for name, mod in (("Gb", W.generator), ("Db", W.discriminator)):
+        out[name] = torch.cat([b.detach().flatten().double() for b in mod.buffers()])
+    return out, (W._opt_G.step_count, W._opt_D.step_count)
+
+
+@pytest.mark.parametrize("ratio", [1, 2])
+def test_graphed_train_step_equals_the_eager_step_bit_for_bit(ratio):
+    B = 2
+    batches = [seeded.smooth_batch(B, 64, 64, seed=70 + k) for k in range(3)]
+    idxs = [torch.tensor([5, 2]), torch.tensor([0, 7]), torch.tensor([3, 3])]
+    alphas = [[torch.tensor([0.3 + 0.1 * k + 0.05 * r, 0.8 - 0.1 * k]).view(B, 1, 1, 1) for r in range(ratio)] for k in range(3)]
+    results = {}
+    for graph in (False, True):
+        W = _trainer(ratio, graph)
+        outs = []
+        for (rgbd, tamp, tphs), idx, al in zip(batches, idxs, alphas):
+            out = W.train_step(rgbd.to(DEV), tamp.to(DEV), tphs.to(DEV), idx, [a.to(DEV) for a in al])
+            outs.append({k: v.detach().clone() for k, v in out.items()})
+        torch.cuda.synchronize()
+        results[graph] = (outs, *_state(W))
+        if graph:
+            assert W._graphed is not None, "the graphed path did not run"
+    (eo, es, ec), (go, gs, gc) = results[False], results[True]
+    assert ec == gc == (3, 3 * ratio), (ec, gc)
+    for k, (a, b) in enumerate(zip(eo, go)):
+        for key in a:
+            assert torch.equal(a[key], b[key]), (k, key, (a[key].double() - b[key].double()).abs().max().item())
+    for key in es:
+        assert torch.equal(es[key], gs[key]), (key, (es[key].double() - gs[key].double()).abs().max().item())
+
+
+def test_graphed_step_draws_like_the_eager_step():
+    """Without explicit indices / alphas both paths draw from the CPU generator in the same order (randperm, then one rand per critic
+    update): same seed, same batches -> same bits; and building the graph consumes no draws."""
+    rgbd, tamp, tphs = (t.to(DEV) for t in seeded.smooth_batch(2, 64, 64, seed=81))
+    finals = []
+    for graph in (False, True):
+        W = _trainer(1, graph)
+        torch.manual_seed(1234)
+        for _ in range(3):
+            W.train_step(rgbd, tamp, tphs)
+        torch.cuda.synchronize()
+        finals.append((_state(W)[0], torch.get_rng_state()))
+    for key in finals[0][0]:
+        assert torch.equal(finals[0][0][key], finals[1][0][key]), key
+    assert torch.equal(finals[0][1], finals[1][1])
