@@ -12,8 +12,9 @@ namespace lhg {
 
 #include "wg6_kernel.inc"
 
-// grad[n][m][tap] (+)= sum_s slabs[s][tap][m][n], s ascending.  One thread per (tap, m, four consecutive n): 16-byte slab loads, four
-// splits in flight per thread, four 4-byte stores (tap-strided rows of the OIHW / IOHW gradient: L2 merges them).
+// grad[n][m][tap] (+)= sum_s slabs[s][tap][m][n], s ascending.  One thread per (tap, m, four consecutive n): 16-byte slab loads, EIGHT
+// splits in flight per thread (the pass is latency-bound: a launch reads S x dW bytes that the GEMM has just written, mostly from
+// L2 / Infinity Cache), four 4-byte stores (tap-strided rows of the OIHW / IOHW gradient: L2 merges them).
 __global__ __launch_bounds__(256) void wg6_reduce_kernel(const float* __restrict__ slabs, int S, int T, int m_pad, int n_pad, float* __restrict__ grad,
                                                          int Cn, int Cm, int accumulate) {
   const int n4 = n_pad / 4;
@@ -26,12 +27,12 @@ __global__ __launch_bounds__(256) void wg6_reduce_kernel(const float* __restrict
     const float* src = slabs + ((size_t)tap * m_pad + m) * n_pad + c4 * 4;
     f32x4 v = *reinterpret_cast<const f32x4*>(src);
     int s = 1;
-    for (; s + 4 <= S; s += 4) {
-      const f32x4 a = *reinterpret_cast<const f32x4*>(src + (size_t)s * slab_stride);
-      const f32x4 b = *reinterpret_cast<const f32x4*>(src + (size_t)(s + 1) * slab_stride);
-      const f32x4 c = *reinterpret_cast<const f32x4*>(src + (size_t)(s + 2) * slab_stride);
-      const f32x4 d = *reinterpret_cast<const f32x4*>(src + (size_t)(s + 3) * slab_stride);
-      v += a; v += b; v += c; v += d;   // split order: the same sum as the in-launch reduction
+    for (; s + 8 <= S; s += 8) {
+      f32x4 q[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) q[u] = *reinterpret_cast<const f32x4*>(src + (size_t)(s + u) * slab_stride);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += q[u];   // split order: the same sum as the in-launch reduction
     }
     for (; s < S; ++s) v += *reinterpret_cast<const f32x4*>(src + (size_t)s * slab_stride);
 #pragma unroll
@@ -211,7 +212,7 @@ int wg6_launch(const Wg6Problem& q, const Wg6Plan& plan, float* slabs, unsigned*
 
 int wg6_reduce(const float* slabs, int S, int T, int m_pad, int n_pad, float* grad, int Cn, int Cm, int accumulate, hipStream_t st) {
   const long long total = (long long)T * Cm * (n_pad / 4);
-  const int blocks = (int)std::min<long long>((total + 255) / 256, 8192);
+  const int blocks = (int)std::min<long long>((total + 255) / 256, 16384);
   hipLaunchKernelGGL(wg6_reduce_kernel, dim3(std::max(blocks, 1)), dim3(256), 0, st, slabs, S, T, m_pad, n_pad, grad, Cn, Cm, accumulate);
   return check_launch("wg6_reduce");
 }

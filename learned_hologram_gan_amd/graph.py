@@ -24,6 +24,9 @@ class GraphedGenerator:
                 self.generator(self.static_in)
         torch.cuda.current_stream().wait_stream(side)
         torch.cuda.synchronize()
+        from . import hip_ops
+
+        hip_ops.begin_graph_capture()
         self.graph = torch.cuda.CUDAGraph()
         with torch.no_grad(), torch.cuda.graph(self.graph):
             self.static_out = self.generator(self.static_in)
@@ -63,8 +66,6 @@ class GraphedTrainStep:
         self.rgbd, self.tamp, self.tphs = RGBD.detach().clone(), target_amp.detach().clone(), target_phs.detach().clone()
         self.idx = torch.zeros(B, dtype=torch.int64, device=dev)
         self.alphas = [torch.zeros((B, 1, 1, 1), dtype=torch.float32, device=dev) for _ in range(self.ratio)]
-        self._idx_host = torch.zeros(B, dtype=torch.int64).pin_memory()
-        self._alpha_host = torch.zeros((max(self.ratio, 1), B, 1, 1, 1), dtype=torch.float32).pin_memory()
         opts = [(trainer._opt_G, 1)] + ([(trainer._opt_D, self.ratio)] if self.ratio else [])
         self._opts = opts
         # Building the graph must not train: the state every step touches is saved, the warm-up steps run eagerly on the statics
@@ -77,11 +78,13 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
         for opt, calls in opts:
             opt.device_consts = torch.zeros((calls, 4), dtype=torch.float32, device=dev)
-            opt._consts_host = torch.zeros((calls, 4), dtype=torch.float32).pin_memory()
             opt._consts_cursor = 0
         self._stage(None, None)
         self._stage_consts()
         torch.cuda.synchronize()
+        from . import hip_ops
+
+        hip_ops.begin_graph_capture()
         self.graph = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self.graph):
             self.out = trainer._train_step(self.rgbd, self.tamp, self.tphs, self.idx, self.alphas)
@@ -118,21 +121,20 @@ class GraphedTrainStep:
         torch.cuda.synchronize()
 
     def _stage(self, plane_indices, gp_alphas):
-        """Host draws of one batch -> the static device buffers (pinned staging, asynchronous copies on the current stream)."""
+        """Host draws of one batch -> the static device buffers.  Every batch gets FRESH pinned staging tensors (the caching host
+        allocator hands a block out again only after the copy that read it has run): the host may be several replays ahead of the GPU,
+        so a staging buffer of its own would be overwritten before the copy of an earlier batch has executed."""
         W, B = self.W, self.idx.shape[0]
         idx = plane_indices if plane_indices is not None else W.propagator.draw_indices(B)
-        self._idx_host.copy_(torch.as_tensor(idx).reshape(-1).to(torch.int64).cpu())
-        self.idx.copy_(self._idx_host, non_blocking=True)
+        self.idx.copy_(torch.as_tensor(idx).reshape(-1).to(torch.int64).cpu().pin_memory(), non_blocking=True)
         for k in range(self.ratio):
             a = gp_alphas[k] if gp_alphas is not None else torch.rand(B, 1, 1, 1)  # the reference's draw: CPU generator
-            self._alpha_host[k].copy_(torch.as_tensor(a).reshape(B, 1, 1, 1).float().cpu())
-            self.alphas[k].copy_(self._alpha_host[k], non_blocking=True)
+            self.alphas[k].copy_(torch.as_tensor(a).reshape(B, 1, 1, 1).float().cpu().pin_memory(), non_blocking=True)
 
     def _stage_consts(self):
         for opt, calls in self._opts:
             scale = 1.0  # single process: the gradient buffer holds this rank's own gradient
-            opt._consts_host.copy_(opt.consts_rows(opt.step_count + 1, calls, scale))
-            opt.device_consts.copy_(opt._consts_host, non_blocking=True)
+            opt.device_consts.copy_(opt.consts_rows(opt.step_count + 1, calls, scale).pin_memory(), non_blocking=True)
 
     def _replay(self):
         self.graph.replay()

@@ -636,6 +636,14 @@ def _amax_slot(device):
     return ring.take()
 
 
+def begin_graph_capture() -> None:
+    """Call right before a hipGraph capture: the zero-filled slot rings of EARLIER captures are dropped, so that this capture fills its
+    own (a slot handed out from a ring whose fill launch belongs to another graph would never be re-zeroed by this graph's replays:
+    lhg_absmax max-accumulates, and the scales — though still valid upper bounds — would depend on the replay history)."""
+    for key in [k for k in _AMAX_POOL if k[2]]:
+        del _AMAX_POOL[key]
+
+
 def apply_env_precision() -> None:
     """Kept for the entry points (trainingModel.py, generatePOH.py): LHG_CONV_PRECISION is read by the library itself at load time."""
     _mode()
