@@ -648,7 +648,7 @@ static std::map<std::array<int, 12>, int> g_gg_choice, g_wg_choice;
 // LHG_TUNE_CACHE=<file>: choices are appended to that file and read back by later processes (one line per geometry, tagged with
 // TUNE_SCHEMA so that a build with a different variant numbering ignores stale lines).
 constexpr int TUNE_RUNS = 5;
-constexpr const char* TUNE_SCHEMA = "lhg-tune-6";
+constexpr const char* TUNE_SCHEMA = "lhg-tune-7";
 static void tune_cache_load() {
   static bool done = false;
   if (done) return;
@@ -958,8 +958,9 @@ static int launch_gg_split(GGParams& p, hipStream_t st) {
   const bool n128 = p.rows_pad % 128 == 0;
   // 10..19 (merged parity classes only): variant v - 10 in one launch per class — what wins on the layers whose classes are long
   // enough by themselves (512 -> 1024 @ 48^2: 493 us against 572 merged; 128 -> 256 @ 96^2: 267 against 206)
-  const int NV = ncls > 1 ? 20 : 10;  // 3, 4: eight consumer waves (two per SIMD) on the 128x128 / 128x64 tiles; 5..8: strip-staged 3x3 kernel (gg4s);
-                          // 9: 64 pixels x 128 output channels (half the activation splits of the 64x64 tile, same pixel granularity)
+  const int NV = ncls > 1 ? 20 : 12;  // 3, 4: eight consumer waves (two per SIMD) on the 128x128 / 128x64 tiles; 5..8: strip-staged 3x3 kernel (gg4s);
+                          // 9: 64 pixels x 128 output channels (half the activation splits of the 64x64 tile, same pixel granularity);
+                          // 10, 11 (single class only): gg4s with eight consumer waves on 256 x 128 / 256 x 64 strips, one workgroup per CU
   // gg4s_kernel: fp16 planes, full 3x3 tap set, stride 1 both ways, same extents in and out
   bool strips = split_f16() && ncls == 1 && g.T == 9 && g.istep == 1 && g.ostep == 1 && g.oy0 == 0 && g.ox0 == 0 && g.gh == g.Hi && g.gw == g.Wi && g.Ho == g.Hi &&
                 g.Wo == g.Wi && (long long)g.N * g.Hi * (g.Wi + 2) < (1ll << 31);
@@ -979,6 +980,7 @@ static int launch_gg_split(GGParams& p, hipStream_t st) {
   const bool f16 = split_f16();
   if (f16) LHG_REQUIRE(p.a_amax != nullptr && p.w_amax != nullptr, "gather-GEMM (fp32_split_f16 mode): the operand's absmax pointer is missing (lhg_absmax)");
   auto valid = [&](int v) {
+    if (ncls == 1 && v >= 10) return f16 && strips && (v == 11 || n128);
     if (v >= 10) v -= 10;
     if (v == 9) return f16 && n128;
     if (v >= 5) return strips && (v == 5 || v == 7 || n128);
@@ -1006,6 +1008,8 @@ static int launch_gg_split(GGParams& p, hipStream_t st) {
         case 7: hipLaunchKernelGGL((gg4s_kernel<128, 64>), dim3(blocks_strip(128, 64)), dim3(512), 0, st, p, ib, wb); break;
         case 8: hipLaunchKernelGGL((gg4s_kernel<128, 128>), dim3(blocks_strip(128, 128)), dim3(512), 0, st, p, ib, wb); break;
         case 9: launch3(gg3s_kernel<64, 128, 2, 2, 32, float, 4, _Float16>, 64, 128, 512); break;
+        case 10: hipLaunchKernelGGL((gg4s_kernel<256, 128, 4, 2>), dim3(blocks_strip(256, 128)), dim3(768), 0, st, p, ib, wb); break;
+        case 11: hipLaunchKernelGGL((gg4s_kernel<256, 64, 4, 2>), dim3(blocks_strip(256, 64)), dim3(768), 0, st, p, ib, wb); break;
         default: break;
       }
     } else {
@@ -1017,7 +1021,7 @@ static int launch_gg_split(GGParams& p, hipStream_t st) {
     }
   };
   auto run = [&](int v) {
-    if (v < 10) { run_one(v); return; }
+    if (v < 10 || ncls == 1) { run_one(v); return; }
     for (int c = 0; c < ncls; ++c) {
       GGParams one = p;
       one.g = cls_geom(c);

@@ -1223,9 +1223,15 @@ class ConvBiasActFn(TrackedFunction):
 _SYNC_STATS = False
 
 
-def set_sync_batch_stats(on: bool) -> None:
-    global _SYNC_STATS
+_SYNC_GROUP = None  # process group the synchronised statistics are reduced over (None: the default group)
+
+
+def set_sync_batch_stats(on: bool, group=None) -> None:
+    """``group``: the process group whose ranks share their batch statistics — pass the group the GradSynchronizer averages over when it
+    is not the default one (a sub-group synchronizer with default-group statistics would mix replicas that do not train together)."""
+    global _SYNC_STATS, _SYNC_GROUP
     _SYNC_STATS = bool(on)
+    _SYNC_GROUP = group if on else None
 
 
 def sync_world() -> int:
@@ -1234,14 +1240,28 @@ def sync_world() -> int:
         return 1
     import torch.distributed as dist
 
-    return dist.get_world_size() if dist.is_available() and dist.is_initialized() else 1
+    return dist.get_world_size(_SYNC_GROUP) if dist.is_available() and dist.is_initialized() else 1
 
 
 def all_reduce_(t, op="sum"):
     import torch.distributed as dist
 
-    dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX if op == "max" else dist.ReduceOp.SUM, group=_SYNC_GROUP)
     return t
+
+
+def assert_equal_batches(samples: int, device) -> None:
+    """The synchronised statistics weight every replica equally (mean of means, 1 / (pixels * world) in the backward sums): that is
+    the global-batch result only when every rank holds the SAME number of samples.  One small MAX all-reduce and one host read per
+    step (the option is a parity mode, off by default) — a ragged last batch raises instead of training on wrong statistics
+    (torch.nn.SyncBatchNorm all-gathers the counts for the same reason)."""
+    if sync_world() == 1:
+        return
+    t = torch.tensor([float(samples), -float(samples)], device=device)
+    all_reduce_(t, "max")
+    hi, lo = t.tolist()
+    if hi != -lo:
+        raise RuntimeError(f"sync_batch_stats needs equal per-rank batches: this rank holds {samples} samples, the ranks hold between {int(-lo)} and {int(hi)}")
 
 
 def _global_batch_stats(stats, Cc, pixels, world, running_mean, running_var):

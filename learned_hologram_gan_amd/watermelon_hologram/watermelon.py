@@ -129,6 +129,7 @@ class watermelon:
         self.discriminator_loss_weight = discriminator_loss_weight
         self.discriminator_train_ratio, self.discriminator_lambda = discriminator_train_ratio, discriminator_lambda
         hip_ops.set_sync_batch_stats(sync_batch_stats)
+        self._sync_batch_stats = bool(sync_batch_stats)
         self.generator.to(self.device)
         flat_G = FlatParams(self.generator)
         broadcast_module_state(self.generator, flat_G.data)  # data-parallel replicas start from rank 0's weights
@@ -204,6 +205,8 @@ class watermelon:
         """One batch of the reference loop (watermelon.py:207-277).  Returns detached tensors for logging."""
         if self._opt_G is None:
             raise RuntimeError("call configure(...) (or train(...)) before train_step")
+        if getattr(self, "_sync_batch_stats", False):
+            hip_ops.assert_equal_batches(RGBD.shape[0], RGBD.device)  # global-batch statistics weight the replicas equally
         with hip_ops.deferred_gc():  # no collector pauses while the host thread is feeding the GPU
             if self.use_graph and RGBD.is_cuda and self._sync_G.world == 1:
                 # the whole batch as ONE hipGraph replay (graph.GraphedTrainStep): ~900 launches per step leave the host

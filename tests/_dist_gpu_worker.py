@@ -315,6 +315,14 @@ def syncbn():
         dist.all_gather(both, ref_grads[m])
         agree["grads_" + m] = bool(torch.equal(both[0], both[1]))
     res["single_process_step_agrees_between_ranks"] = agree
+    # The noise floor of the comparison, measured in the same worker: the SAME single-process step with the samples in
+    # reverse order — mathematically the same batch statistics, losses and averaged gradients, another fp32 summation order.
+    flip = lambda t: torch.flip(t, dims=(0,))  # noqa: E731
+    perm_out, perm_grads, _, _, _ = run(tuple(flip(t) for t in cat), flip(torch.cat(idxs)), flip(torch.cat(alphas)), False)
+    if rank == 0:
+        l2f = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-300)).item()  # noqa: E731
+        res.update(floor_g=l2f(perm_grads["G"], ref_grads["G"]), floor_d=l2f(perm_grads["D"], ref_grads["D"]),
+                   floor_hat=l2f(flip(perm_out["hat_amps"]), ref_out["hat_amps"]))
     if rank == 0:
         l2 = lambda a, b: ((a.double() - b.double()).norm() / b.double().norm().clamp_min(1e-300)).item()  # noqa: E731
         mean_losses = sum(gathered) / world

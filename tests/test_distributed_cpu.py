@@ -334,6 +334,51 @@ def test_bench_gpus_n_starts_n_ranks_by_itself():
     assert res.returncode != 0 and "WORLD_SIZE=1" in (res.stderr + res.stdout)
 
 
+def _equal_batches_worker(rank, world, port, q):
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    from learned_hologram_gan_amd import distributed, hip_ops
+
+    distributed.init_from_env("gloo")
+    ok = True
+    hip_ops.set_sync_batch_stats(False)
+    hip_ops.assert_equal_batches(3 + rank, "cpu")  # per-replica statistics: nothing to check
+    hip_ops.set_sync_batch_stats(True)
+    ok = ok and hip_ops.sync_world() == world
+    hip_ops.assert_equal_batches(4, "cpu")  # equal batches pass
+    try:
+        hip_ops.assert_equal_batches(4 - rank, "cpu")  # a ragged last batch: rank 1 holds 3 samples
+        ok = False
+    except RuntimeError as e:
+        ok = ok and "equal per-rank batches" in str(e)
+    # a sub-group: statistics follow the group they were given
+    sub = dist.new_group([0, 1])
+    hip_ops.set_sync_batch_stats(True, group=sub)
+    t = torch.tensor([float(rank + 1)])
+    ok = ok and hip_ops.all_reduce_(t).item() == 3.0
+    hip_ops.set_sync_batch_stats(False)
+    ok = ok and hip_ops.sync_world() == 1
+    dist.barrier()
+    q.put((rank, bool(ok)))
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_synchronised_statistics_refuse_ragged_batches_world2():
+    """sync_batch_stats weights the replicas equally: unequal per-rank batches must raise, and the reductions follow the
+    process group handed to set_sync_batch_stats."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_equal_batches_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert sorted(results) == [(0, True), (1, True)]
+
+
 def test_spawn_local_ranks_reports_a_failing_rank():
     import sys
 

@@ -995,7 +995,7 @@ def test_every_tiling_variant_gives_the_same_bits():
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     seen = {}
-    for gv, wv in ((2, 21), (0, 18), (9, 22), (5, 25), (8, 10), (12, 13)):
+    for gv, wv in ((2, 21), (0, 18), (9, 22), (5, 25), (8, 10), (12, 13), (10, 21), (11, 18)):  # 10, 11: twelve-wave strips (single-class launches)
         # LHG_WG6=0: the per-tap weight-gradient kernels this test forces (the tap-fused kernel's variants: tests/test_gpu_wgrad6.py)
         env = dict(os.environ, LHG_AUTOTUNE="0", LHG_GGS_VARIANT=str(gv), LHG_WG_VARIANT=str(wv), LHG_WG6="0", PYTHONPATH=root)
         out = subprocess.run([sys.executable, "-c", _VARIANT_CHILD], cwd=root, env=env, capture_output=True, text=True)
