@@ -69,7 +69,7 @@ const Variant kVariants[] = {
     LHG_WG6(64, 64, 2, 2, 3, 1, 1, 2, 0.44f),
     LHG_WG6(64, 64, 2, 2, 3, 3, 1, 1, 0.47f),
     // 3x3 stride 2
-    LHG_WG6(128, 128, 4, 2, 3, 1, 2, 1, 0.43f),
+    LHG_WG6(128, 128, 4, 2, 3, 1, 2, 1, 0.47f),
     LHG_WG6(128, 64, 4, 1, 3, 1, 2, 1, 0.41f),
     LHG_WG6(64, 128, 2, 2, 3, 1, 2, 1, 0.45f),
     LHG_WG6(64, 64, 2, 2, 3, 1, 2, 2, 0.36f),

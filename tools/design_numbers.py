@@ -1,7 +1,7 @@
 """Regenerate the measured numbers of DESIGN.md from the committed records under profiles/, so that the text cannot drift from them
 ("What's weak" #8).  Everything between the two marker lines of DESIGN.md is replaced.
 
-    python tools/design_numbers.py [round tag, default r03]      (run it after copying new records into profiles/)
+    python tools/design_numbers.py [round tag, default r04]      (run it after copying new records into profiles/)
 
 Inputs: profiles/<tag>_bench_line.json (one line of `python bench.py`), <tag>_kernel_steady.txt (tools/steady_profile.py),
 <tag>_pmc_traffic.json (tools/pmc_traffic.py), <tag>_truth_tests.jsonl (tests/test_gpu_truth.py), <tag>_pmc_mfma.jsonl (tools/pmc_mfma.sh).
@@ -12,7 +12,7 @@ import re
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r03"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
 BEGIN, END = "<!-- BEGIN GENERATED: measurements (tools/design_numbers.py) -->", "<!-- END GENERATED -->"
 
 
@@ -45,7 +45,7 @@ def family_ms(rows):
            "angular-spectrum passes": 0.0, "other": 0.0}
     launches = dict.fromkeys(fam, 0.0)
     for name, n, us in rows:
-        if "wgrad_reduce" in name:
+        if "wgrad_reduce" in name or "wg6_reduce" in name:
             k = "weight-gradient slab reduce"
         elif "channel_absmax" in name:
             k = "per-channel max (wgrad scales)"
@@ -79,6 +79,7 @@ def main():
         out += [f"**Bench line** (`profiles/{TAG}_bench_line.json`; {b['config']['workload']}):", "",
                 "| quantity | value |", "|---|---|",
                 f"| step | **{b['ms_per_step']:.2f} ms = {b['value']:.1f} frames/s** (`dtype`: {b['dtype']}) |",
+                f"| host time to enqueue a step | {b.get('host_ms_per_step', float('nan')):.1f} ms ({'one hipGraph replay' if b.get('graph') else 'eager launches'}): the step is GPU-bound |",
                 f"| gather-GEMM under the timed conditions | {r['achieved']:.1f} TFLOP/s of algorithmic fp32 work = **{r['frac']:.3f}** of {r['peak']} ({r['kernel_ms_per_step']:.2f} ms/step in {r['launches_per_step']:.0f} launches, {r['algorithmic_gflop_per_step']:.0f} GFLOP) |",
                 f"| gather-GEMM, second stream off | {iso.get('achieved', 0):.1f} TFLOP/s = {iso.get('frac', 0):.3f} ({iso.get('kernel_ms_per_step', 0):.2f} ms/step) |",
                 f"| weight-gradient GEMM | {r['wgrad_kernel']['achieved']:.1f} TFLOP/s timed, {iso.get('wgrad_kernel', {}).get('achieved', 0):.1f} isolated ({iso.get('wgrad_kernel', {}).get('kernel_ms_per_step', 0):.2f} ms/step, {r['wgrad_kernel']['algorithmic_gflop_per_step']:.0f} GFLOP) |",
@@ -109,6 +110,31 @@ def main():
         out += [f"**HBM traffic per launch** (`profiles/{TAG}_pmc_traffic.json`, git {t.get('git_sha')}): gather-GEMM {g['hbm_bytes_per_launch_corrected'] / 1e6:.0f} MB "
                 f"(read 2 x {g['fetch_kib_per_launch'] / 1024:.0f} MiB, written {g['write_kib_per_launch'] / 1024:.0f} MiB); weight-gradient GEMM "
                 f"{w['hbm_bytes_per_launch_corrected'] / 1e6:.0f} MB of which **{w['write_kib_per_launch'] / 1024:.1f} MiB written** (the split-K slabs).", ""]
+    path = os.path.join(REPO, "profiles", f"{TAG}_wg6_sweep.jsonl")
+    if os.path.exists(path):
+        out += [f"**Tap-fused weight-gradient GEMM per layer** (`profiles/{TAG}_wg6_sweep.jsonl`, `tools/wg6_sweep.py`: GEMM + reduction, isolated, random operands; "
+                f"per-tap kernels: `profiles/{TAG}_wg6_sweep_legacy.txt`):", "", "| layer | best variant / splits | us | TFLOP/s | launches per step |", "|---|---|---|---|---|"]
+        tot = 0.0
+        for ln in open(path):
+            if not ln.strip():
+                continue
+            r_ = json.loads(ln)
+            vs = [v for v in r_["variants"] if not (v["S"] > 1 and v["fused"])] or r_["variants"]
+            if not vs:
+                continue
+            best = min(vs, key=lambda v: v["us"])
+            tot += best["us"] * r_["count"]
+            out.append(f"| {r_['layer']} | {best['name']}, S = {best['S']} | {best['us']:.0f} | {r_['flops'] / best['us'] / 1e6:.0f} | {r_['count']} |")
+        out += ["", f"Sum over the step's launches at the best variant: {tot / 1e3:.2f} ms.", ""]
+    path = os.path.join(REPO, "profiles", f"{TAG}_4k_kernel_steady.txt")
+    if os.path.exists(path):
+        lines4 = open(path).read().splitlines()
+        out += [f"**4K frame** (`profiles/{TAG}_4k_kernel_steady.txt`, `{TAG}_4k_pmc_traffic.json`) — {lines4[0]}:", "", "| kernel family | launches/frame | ms/frame | share |", "|---|---|---|---|"]
+        for ln in lines4[1:]:
+            m = re.match(r"\s+family (.+?)\s+([\d.]+)/frame\s+([\d.]+) ms/frame\s+([\d.]+)%", ln)
+            if m:
+                out.append(f"| {m.group(1).strip()} | {float(m.group(2)):.0f} | {float(m.group(3)):.2f} | {m.group(4)} % |")
+        out.append("")
     path = os.path.join(REPO, "profiles", f"{TAG}_truth_tests.jsonl")
     if os.path.exists(path):
         recs = [json.loads(ln) for ln in open(path) if ln.strip()]

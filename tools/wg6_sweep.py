@@ -58,6 +58,7 @@ def main():
     ap.add_argument("--quick", action="store_true")
     ap.add_argument("--json", default=None)
     ap.add_argument("--reps", type=int, default=6)
+    ap.add_argument("--only-convt", action="store_true")
     args = ap.parse_args()
     from learned_hologram_gan_amd import hip_ops as ops
     from learned_hologram_gan_amd import native
@@ -69,7 +70,9 @@ def main():
     out = open(args.json, "a") if args.json else None
     legacy = os.environ.get("LHG_WG6", "1") == "0"
     total_plan = 0.0
-    for (name, N, Ci, Co, H, W, k, stride, count) in LAYERS:
+    import ctypes
+
+    for (name, N, Ci, Co, H, W, k, stride, count) in ([] if args.only_convt else LAYERS):
         g = torch.Generator().manual_seed(1)
         x = torch.rand((N, H, W, Ci), generator=g).to(dev) * 2 - 1
         Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
@@ -80,8 +83,6 @@ def main():
         with torch.no_grad():
             us = time_call(run, args.reps)
         total_plan += us * count
-        import ctypes
-
         pv, ps, pf = ctypes.c_int(-1), ctypes.c_int(0), ctypes.c_int(0)
         lib.lhg_wg6_last_plan(ctypes.byref(pv), ctypes.byref(ps), ctypes.byref(pf))
         chosen = "" if legacy else f" [v{pv.value} {names[pv.value] if pv.value >= 0 else '-'} S={ps.value} fused={pf.value}]"
@@ -121,9 +122,26 @@ def main():
             w.grad = None
             y.backward(gy, retain_graph=True, inputs=[w])
 
+        lib.lhg_wg6_force(-1, -1, -1)
         us = time_call(run, args.reps)
         total_plan += us
-        print(f"{name:42s} backward incl. autograd: {us:8.1f} us ({flops / us / 1e6:6.1f} TFLOP/s incl. overhead)", flush=True)
+        pv, ps, pf = ctypes.c_int(-1), ctypes.c_int(0), ctypes.c_int(0)
+        lib.lhg_wg6_last_plan(ctypes.byref(pv), ctypes.byref(ps), ctypes.byref(pf))
+        print(f"{name:42s} backward incl. autograd: {us:8.1f} us ({flops / us / 1e6:6.1f} TFLOP/s incl. overhead) [v{pv.value} S={ps.value} fused={pf.value}]", flush=True)
+        if not legacy and not args.quick:
+            pad = lambda c: (c + 63) // 64 * 64  # noqa: E731
+            steps = (N * H * (W + 2) + 31) // 32
+            for v, vn in enumerate(names):
+                tile, cw, t, ny, st_ = vn.split()
+                bm, bn = map(int, tile.split("x"))
+                if t != "nt2" or pad(Co) % bm or pad(Ci) % bn:  # strip operand = gy (Co channels), point operand = x (Ci)
+                    continue
+                tiles = (pad(Co) // bm) * (pad(Ci) // bn) * 2
+                for S in sorted({max(1, min(steps // 8, s_)) for s_ in (1, max(1, 128 // tiles), max(1, 256 // tiles), max(1, 512 // tiles))}):
+                    lib.lhg_wg6_force(v, S, 1 if S == 1 else 0)
+                    u = time_call(run, args.reps)
+                    print(f"    v{v:2d} {vn:26s} S={S:3d}: {u:8.1f} us", flush=True)
+            lib.lhg_wg6_force(-1, -1, -1)
     print(f"sum over the step's launches: {total_plan / 1e3:.2f} ms")
 
 
