@@ -7,6 +7,8 @@ from learned_hologram_gan_amd import hip_ops
 from learned_hologram_gan_amd.watermelon_hologram.watermelon import watermelon
 side = os.environ.get("PROBE_SIDE", "1") == "1"
 hip_ops.SIDE_WGRAD = side
+if os.environ.get("PROBE_BF16", "0") == "1":
+    hip_ops.set_activation_storage("bf16")
 dev = "cuda:0"
 rows = int(os.environ.get("PROBE_ROWS", "384")); B = 4
 stack = torch.linspace(-4e-4, 0.0, 21)[:-1]
