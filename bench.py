@@ -115,6 +115,22 @@ def pmc_traffic():
     return None, None
 
 
+def pmc_traffic_4k():
+    """HBM bytes per gather-GEMM launch of the 4K leg from the newest committed PMC passes (tools/profile_4k.sh), with their revision."""
+    files = sorted(glob.glob(os.path.join(REPO, "profiles", "r*_4k_pmc_traffic.json")))
+    for path in reversed(files):
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            fam = d["families"]["gather-GEMM"]
+            return fam["hbm_bytes_per_launch_corrected"], {"file": os.path.relpath(path, REPO), "git_sha": d.get("git_sha"),
+                                                           "launches_per_frame": fam.get("launches_per_frame"),
+                                                           "hbm_bytes_per_frame_corrected": fam.get("hbm_bytes_per_frame_corrected")}
+        except (OSError, KeyError, ValueError):
+            continue
+    return None, None
+
+
 def cpu_baseline(args):
     """The same train step through the CPU oracle (checker code timed as the reported baseline) ON THE BENCH WORKLOAD — the same frame
     size and the same batch per step as the GPU line beside it — 1 warm-up + the median of 3 runs while they fit the
@@ -209,7 +225,7 @@ def secondary_4k(native, dev, world, sync, peak, peak_note, planes=8, warmup=2, 
                                    f"{rows + 2 * pad}x{cols + 2 * int(pad * cols / rows)} transforms) + {planes}-plane propagate; replicas only"},
             "roofline": {"kernel": "gather-GEMM (the frame's 12.89 TFLOP of convolutions)", "bound": "mfma", "achieved": round(a, 3), "peak": peak,
                          "peak_note": peak_note, "unit": "TFLOP/s", "frac": round(a / peak, 4),
-                         "frac_of_fp32_mfma_peak": round(a / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                         "frac_of_fp32_mfma_peak": round(a / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": pmc_traffic_4k()[0], "traffic_source": pmc_traffic_4k()[1],
                          "kernel_ms_per_frame": round(gg["total_ms"] / steps, 3),
                          "algorithmic_gflop_per_frame": round(gg["algorithmic_flops"] / steps / 1e9, 1)}}
 
