@@ -260,6 +260,9 @@ int lhg_conv_transpose2x2_backward_weight_into(const float* x, int N, int H, int
                                                const float* x_absmax, const float* gy_absmax, lhg_stream_t s);
 /* Debugging aid of the tap-fused kernel (tools/wg6_sweep.py, tests): force its tile variant (0 .. lhg_wg6_variants() - 1), split count
  * and reduction form (1 in-launch, 0 separate launch) for the following calls; -1 = the library's deterministic plan. */
+/* lhg_channel_absmax_finish over an explicit number of partial rows: several producers (the two halves of a batch normalised
+ * separately: hip_ops.BatchNormPairTrainFn) have left their rows one behind the other in one buffer. */
+int lhg_channel_absmax_finish_rows(const float* partial, int rows, int C, float* out, lhg_stream_t s);
 int lhg_wg6_force(int variant, int splits, int fused);
 int lhg_wg6_last_plan(int* variant, int* splits, int* fused); /* what the last tap-fused launch of this process ran with */
 int lhg_wg6_variants(void);

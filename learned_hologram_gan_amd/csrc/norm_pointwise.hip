@@ -908,6 +908,12 @@ int lhg_channel_absmax_finish(const float* partial, long long pixels, int C, flo
                      apply_blocks(pixels, col_map(C)), C, reinterpret_cast<unsigned*>(out));
   return check_launch("channel_absmax_finish");
 }
+int lhg_channel_absmax_finish_rows(const float* partial, int rows, int C, float* out, lhg_stream_t s) {
+  LHG_REQUIRE(partial != nullptr && out != nullptr && rows > 0 && C > 0 && C % 4 == 0, "channel_absmax_finish_rows: missing buffer or bad shape");
+  hipLaunchKernelGGL(channel_absmax_reduce, dim3((C + 31) / 32), dim3(1024), 0, as_stream(s), reinterpret_cast<const unsigned*>(partial), rows, C,
+                     reinterpret_cast<unsigned*>(out));
+  return check_launch("channel_absmax_finish_rows");
+}
 int lhg_bn_apply_chanmax(const float* x, int ldx, long long pixels, int C, const float* stats, const float* gamma, const float* beta,
                          const float* res, int ldres, int act, float slope, float* y, int ldy, float* y_absmax, float* y_chanmax_partial,
                          lhg_stream_t s) {

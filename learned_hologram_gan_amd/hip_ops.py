@@ -511,7 +511,9 @@ def operand_chanmax(t):
         call("lhg_channel_absmax", p + 4 * c0, pixels, c1 - c0, ld, out.data_ptr() + 4 * c0, ptr(ws), st)
 
     at = 0
-    for off, cc, partial, grid_pixels in parts:
+    for entry in parts:
+        off, cc, partial, grid_pixels = entry[:4]
+        rows = entry[4] if len(entry) > 4 else None  # explicit row count: several producers' rows one behind the other (BatchNormPairTrainFn)
         if off < at or off + cc > Cc or off % 4:
             continue
         if off > at:
@@ -520,7 +522,10 @@ def operand_chanmax(t):
         # stream is ordered behind that kernel (it reads t).
         CHANMAX_STATS["fused"] += 1
         partial.record_stream(cur)
-        call("lhg_channel_absmax_finish", ptr(partial), grid_pixels, cc, out.data_ptr() + 4 * off, st)
+        if rows is not None:
+            call("lhg_channel_absmax_finish_rows", ptr(partial), int(rows), cc, out.data_ptr() + 4 * off, st)
+        else:
+            call("lhg_channel_absmax_finish", ptr(partial), grid_pixels, cc, out.data_ptr() + 4 * off, st)
         at = off + cc
     if at < Cc:
         measure(at, Cc)
@@ -1345,6 +1350,95 @@ class BatchNormTrainFn(TrackedFunction):
             return gx, None, None, None, None, (gres if ctx.has_res else None), None, None, None
         gx, gres, ggamma, gbeta = BatchNormGradFn.apply(gy, x, y, gamma, stats, ctx.act, ctx.slope, ctx.has_res, ctx.world)
         return gx, ggamma, gbeta, None, None, (gres if ctx.has_res else None), None, None, None
+
+
+class BatchNormPairTrainFn(TrackedFunction):
+    """y = act(BN(x) * gamma + beta) for a batch that is TWO batches of the reference stacked on dim 0 — D(real) and D(fake) of the critic
+    update (ref: watermelon.py:243-244, two forward calls of the same module) run as one pass: the convolutions see both halves in one
+    GEMM, and this op normalises every half with ITS OWN batch statistics, first half first (statistics, running-statistics update,
+    apply — then the same for the second half), exactly what the two calls compute.  One tensor out, one node in the graph; the backward
+    does the same per half and adds both halves' d gamma / d beta.  Plain backward only (the gradient penalty's pass is a call of its
+    own through BatchNormTrainFn); per-replica statistics only."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, running_mean, running_var, act, slope):
+        px, N, H, W, Cc, ldx = nhwc(x)
+        if N % 2:
+            raise ValueError("BatchNormPairTrainFn: the batch must be two stacked batches of equal size")
+        if sync_world() > 1:
+            raise NotImplementedError("BatchNormPairTrainFn: per-replica statistics only")
+        half = (N // 2) * H * W
+        es = x.element_size()
+        stats = torch.empty((2, 2 * Cc), dtype=torch.float32, device=x.device)
+        y = new_nhwc(N, H, W, Cc, x.device)
+        py, _, _, _, _, ldy = nhwc(y)
+        y_amax = fused_absmax_slot(x.device)  # both halves max-accumulate into the one slot
+        rows = int(native.load().lhg_chanmax_partial_rows(half, Cc)) if any(ctx.needs_input_grad) else 0
+        part = chanmax_partial_for(half, Cc, x.device) if rows else None
+        if part is not None:
+            part = torch.empty((2 * rows * Cc,), dtype=torch.float32, device=x.device)
+        for h in range(2):
+            xo, yo = px + h * half * ldx * es, py + h * half * ldy * es
+            call("lhg_bn_stats", xo, half, Cc, ldx, stats[h].data_ptr(), ptr(running_mean), ptr(running_var), BN_MOMENTUM, BN_EPS,
+                 ptr(_bn_ws(Cc, x.device, 4104)), stream_ptr())
+            if part is not None:
+                call("lhg_bn_apply_chanmax", xo, ldx, half, Cc, stats[h].data_ptr(), ptr(gamma), ptr(beta), None, 0, act, float(slope), yo, ldy,
+                     ptr(y_amax), part.data_ptr() + 4 * h * rows * Cc, stream_ptr())
+            else:
+                call("lhg_bn_apply", xo, ldx, half, Cc, stats[h].data_ptr(), ptr(gamma), ptr(beta), None, 0, act, float(slope), yo, ldy, ptr(y_amax),
+                     stream_ptr())
+        tag_absmax(y, y_amax)
+        if part is not None:
+            tag_chanmax_source(y, [(0, Cc, part, 2 * half, 2 * rows)])
+        ctx.save_for_backward(x, y, gamma, stats)
+        ctx.act, ctx.slope = act, slope
+        ctx.beta = beta if ctx.needs_input_grad[2] else None
+        ctx.beta_value = beta
+        note_use(gamma, ctx.needs_input_grad[1])
+        note_use(ctx.beta)
+        return y
+
+    @staticmethod
+    def backward(ctx, gy):
+        if torch.is_grad_enabled():
+            raise NotImplementedError("BatchNormPairTrainFn is not twice differentiable (the gradient penalty uses BatchNormTrainFn)")
+        x, y, gamma, stats = ctx.saved_tensors
+        gy = _as_nhwc_view(gy)
+        pg, N, H, W, Cc, ldg = nhwc(gy)
+        px, _, _, _, _, ldx = nhwc(x)
+        py, _, _, _, _, ldy = nhwc(y)
+        half, es = (N // 2) * H * W, x.element_size()
+        mask_from_x = ctx.beta_value is not None and ctx.act in (ACT_RELU, ACT_LEAKY) and _ACT_DTYPE == torch.float32
+        s_gamma = _small_grad_slot(gamma) if ctx.needs_input_grad[1] else None
+        s_beta = _small_grad_slot(ctx.beta)
+        into_slots = s_gamma is not None and s_beta is not None and param_grads_wanted()
+        ggamma = s_gamma if into_slots else torch.empty((Cc,), dtype=torch.float32, device=gy.device)
+        gbeta = s_beta if into_slots else torch.empty((Cc,), dtype=torch.float32, device=gy.device)
+        gx = new_nhwc(N, H, W, Cc, gy.device)
+        pgx = gx.data_ptr()
+        gx_amax = fused_absmax_slot(gy.device)
+        rows = int(native.load().lhg_chanmax_partial_rows(half, Cc))
+        part = chanmax_partial_for(half, Cc, gy.device)
+        if part is not None:
+            part = torch.empty((2 * rows * Cc,), dtype=torch.float32, device=gy.device)
+        for h in range(2):
+            off = h * half
+            acc = 1 if (into_slots or h == 1) else 0  # the second half adds to the first's sums
+            args = (pg + off * ldg * es, ldg, px + off * ldx * es, ldx, None if mask_from_x else py + off * ldy * es, ldy, half, Cc,
+                    stats[h].data_ptr(), ptr(gamma), ctx.act, float(ctx.slope), pgx + off * Cc * es, Cc, None, Cc, ptr(ggamma), ptr(gbeta), acc,
+                    ptr(_bn_ws(Cc, gy.device)), ptr(gx_amax), ptr(ctx.beta_value) if mask_from_x else None)
+            if part is not None:
+                call("lhg_bn_backward_chanmax", *args, part.data_ptr() + 4 * h * rows * Cc, None, stream_ptr())
+            else:
+                call("lhg_bn_backward", *args, stream_ptr())
+        tag_absmax(gx, gx_amax)
+        if part is not None:
+            tag_chanmax_source(gx, [(0, Cc, part, 2 * half, 2 * rows)])
+        if into_slots:
+            note_contribution(gamma)
+            note_contribution(ctx.beta)
+            return gx, None, None, None, None, None, None
+        return gx, ggamma, gbeta, None, None, None, None
 
 
 def bn_backward_raw(gy, x, y, gamma, stats, act, slope, want_res, ggamma, gbeta, accumulate, beta=None, world=1):

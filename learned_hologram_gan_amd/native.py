@@ -72,6 +72,7 @@ _SIGNATURES = {
     "lhg_channel_absmax": [_p, _ll, _i, _i, _p, _p, _p],
     "lhg_chanmax_partial_rows": [_ll, _i],
     "lhg_channel_absmax_finish": [_p, _ll, _i, _p, _p],
+    "lhg_channel_absmax_finish_rows": [_p, _i, _i, _p, _p],
     "lhg_bn_apply_chanmax": [_p, _i, _ll, _i, _p, _p, _p, _p, _i, _i, _f, _p, _i, _p, _p, _p],
     "lhg_bn_backward_chanmax": [_p, _i, _p, _i, _p, _i, _ll, _i, _p, _p, _i, _f, _p, _i, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p],
     "lhg_wgrad_reduce": [_p, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p],

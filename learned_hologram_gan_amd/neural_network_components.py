@@ -40,7 +40,17 @@ def _count_batch(*bns):
 
 def flush_batch_counters():
     if _PENDING_COUNTERS:
-        torch._foreach_add_(_PENDING_COUNTERS, 1)
+        # a layer counted twice (two stacked batches through one pass: WGANGPDiscriminator192.forward_pair) gets ONE add of 2 — the
+        # multi-tensor kernel must not see the same tensor twice
+        counts = {}
+        for t in _PENDING_COUNTERS:
+            key = id(t)
+            counts[key] = (t, counts[key][1] + 1) if key in counts else (t, 1)
+        tensors, scalars = [v[0] for v in counts.values()], [v[1] for v in counts.values()]
+        if all(c == 1 for c in scalars):
+            torch._foreach_add_(tensors, 1)
+        else:
+            torch._foreach_add_(tensors, scalars)
         _PENDING_COUNTERS.clear()
 
 

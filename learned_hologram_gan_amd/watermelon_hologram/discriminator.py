@@ -59,6 +59,29 @@ class WGANGPDiscriminator192(nn.Module):
         return s.reshape(s.shape[0], -1).float()  # (N, H/8, W/8, 1) -> (N, H*W/64), same order as Flatten on NCHW; scores are fp32
 
 
+    def forward_pair(self, a, b):
+        """(D(a), D(b)) — the two critic passes of a WGAN-GP update (ref: watermelon.py:243-244: ``self.discriminator(target_amps)``,
+        ``self.discriminator(fake)``) as ONE pass over the two batches stacked on dim 0: every convolution is one GEMM over 2B samples
+        (twice the pixels: better chip fill on the deep layers, one weight-gradient GEMM instead of two), every BatchNorm normalises the
+        halves separately and in order (BatchNormPairTrainFn: a's statistics and running-statistics update, then b's) — the values two
+        calls compute.  Falls back to two calls outside training, with synchronised statistics or for unequal batches."""
+        if not self.training or ops.sync_world() > 1 or a.shape != b.shape or not a.is_cuda:
+            return self.forward(a), self.forward(b)
+        B = a.shape[0]
+        h = ops.ToNHWC.apply(torch.cat((a, b), 0), 32)
+        c1 = self.block1[0]
+        h = ops.ConvBiasActFn.apply(h, c1.weight, c1.bias, 1, ACT_LEAKY, 0.2)
+        for blk in (self.block2, self.block3, self.block4, self.block5, self.block6):
+            conv, bn = blk[0], blk[1]
+            y = ops.Conv2dFn.apply(h, conv.weight, conv.bias, conv.stride[0], "feeds_bn")
+            h = ops.BatchNormPairTrainFn.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, ACT_LEAKY, 0.2)
+            _count_batch(bn, bn)
+        flush_batch_counters()
+        s = ops.Conv2dFn.apply(h, self.conv.weight, self.conv.bias, 1, None)
+        s = s.reshape(s.shape[0], -1).float()
+        return s[:B], s[B:]
+
+
 class fakeDiscriminator(nn.Module):
     """Returns 0 (training without the critic). ref: discriminator.py:54-67."""
 

@@ -103,6 +103,7 @@ class watermelon:
         self._opt_G = self._opt_D = self._sync_G = self._sync_D = None
         self.skip_unused_critic_grads = True  # see train_step: critic weight gradients of the generator pass are dead values
         # train_step as one hipGraph replay per batch (single process; static batch shape): LHG_TRAIN_GRAPH=1, or set the attribute
+        self.pair_critic_passes = os.environ.get("LHG_PAIR_CRITIC", "1") != "0"  # A/B switch of forward_pair (round 4)
         self.use_graph = os.environ.get("LHG_TRAIN_GRAPH", "0") == "1"
         self._graphed = None
 
@@ -223,8 +224,12 @@ class watermelon:
         fake = hat_amps.detach()
         d_total = torch.zeros((), device=self.device)
         for it in range(ratio):
-            real_validity = self.discriminator(target_amps)
-            fake_validity = self.discriminator(fake)
+            if self.pair_critic_passes and hasattr(self.discriminator, "forward_pair"):
+                # D(real) and D(fake) as one pass over the stacked batches (same values: WGANGPDiscriminator192.forward_pair)
+                real_validity, fake_validity = self.discriminator.forward_pair(target_amps, fake)
+            else:
+                real_validity = self.discriminator(target_amps)
+                fake_validity = self.discriminator(fake)
             gp = self.compute_gradient_penalty(target_amps, fake, None if gp_alphas is None else gp_alphas[it])
             d_loss = (-torch.mean(real_validity) + torch.mean(fake_validity)) + self.discriminator_lambda * gp
             self._opt_D.zero_grad()

@@ -77,3 +77,37 @@ def test_graphed_step_draws_like_the_eager_step():
     for key in finals[0][0]:
         assert torch.equal(finals[0][0][key], finals[1][0][key]), key
     assert torch.equal(finals[0][1], finals[1][1])
+
+
+def test_critic_forward_pair_equals_two_passes():
+    """WGANGPDiscriminator192.forward_pair(a, b) — D(real) and D(fake) of a critic update as one pass over the stacked batches — against
+    two calls (ref: watermelon.py:243-244): scores, BatchNorm running statistics and batch counters bit-identical (a convolution's
+    output does not depend on the batch it sits in, every BatchNorm normalises the halves separately and in order); parameter
+    gradients equal up to the summation order of the weight-gradient GEMM (one over 2B samples instead of two accumulated), through
+    autograd's accumulation and through the flat-buffer slots."""
+    from learned_hologram_gan_amd.optim import FlatParams
+    from learned_hologram_gan_amd.watermelon_hologram.discriminator import WGANGPDiscriminator192
+
+    g = torch.Generator().manual_seed(3)
+    a, b = torch.rand((2, 3, 64, 64), generator=g).to(DEV), torch.rand((2, 3, 64, 64), generator=g).to(DEV)
+    for slots in (False, True):
+        out = {}
+        for pair in (False, True):
+            D = WGANGPDiscriminator192(cuda=True)
+            D.load_state_dict(seeded.critic_state_dict())
+            D.to(DEV).train()
+            flat = FlatParams(D) if slots else None
+            if flat is not None:
+                flat.zero_grad()
+            sa, sb = D.forward_pair(a, b) if pair else (D(a), D(b))
+            loss = -(sa * sa).mean() + (sb * (1 + sb)).mean()
+            loss.backward()
+            torch.cuda.synchronize()
+            grads = flat.grad.clone() if slots else torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).flatten() for p in D.parameters()])
+            bufs = torch.cat([t.detach().flatten().double() for t in D.buffers()])
+            out[pair] = (sa.detach().clone(), sb.detach().clone(), bufs, grads)
+        (sa0, sb0, bu0, g0), (sa1, sb1, bu1, g1) = out[False], out[True]
+        assert torch.equal(sa0, sa1) and torch.equal(sb0, sb1), slots
+        assert torch.equal(bu0, bu1), slots
+        err = ((g0.double() - g1.double()).norm() / g0.double().norm()).item()
+        assert err < 2e-5, (slots, err)
