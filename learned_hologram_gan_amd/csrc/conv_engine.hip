@@ -252,6 +252,7 @@ __global__ __launch_bounds__(256, 2) void gg_kernel(const GGParams p) {
 
 #include "gg2_kernel.inc"
 #include "gg2b_kernel.inc"
+#include "gg_epilogue.inc"
 #include "gg3s_kernel.inc"
 #include "gg4s_kernel.inc"
 
@@ -767,6 +768,15 @@ static int default_precision() {
 }
 static int g_precision = default_precision();
 
+
+// gg_epilogue.inc stores through a descriptor based at the tile's first output pixel with 32-bit offsets below 2^30: bound the bytes a
+// tile of up to 256 consecutive sub-grid points can span (whole image rows it touches, at the output's step), for either row pitch.
+static bool epilogue_window_fits(const Geom& g, int ldres, int es) {
+  const long long rows = (long long)g.ostep * (256 / std::max(1, g.gw) + 2) + 1;
+  const long long bytes = rows * g.Wo * (long long)std::max(g.ldo, ldres) * es;
+  return bytes < (1ll << 30);
+}
+
 static int launch_gg_bf16(GGParams& p, hipStream_t st);
 static int launch_gg_split(GGParams& p, hipStream_t st);
 
@@ -877,6 +887,7 @@ static int launch_gg_bf16_t(GGParams& p, hipStream_t st) {
   const unsigned long long in_bytes = (((unsigned long long)g.N * g.Hi * g.Wi - 1) * g.ldi + g.Ci) * (unsigned long long)ES;
   const unsigned long long wp_bytes = (unsigned long long)(max_ws + 1) * p.rows_pad * g.Ci * 2ull;
   LHG_REQUIRE(wp_bytes < (1ull << 32) - 64, "gather-GEMM (bf16 mode): weight panels of 4 GiB and more are not supported");
+  LHG_REQUIRE(p.planar_out || epilogue_window_fits(g, p.res ? p.ldres : 0, ES), "gather-GEMM: an output tile spans 1 GiB or more (Wo %d, ld %d)", g.Wo, g.ldo);
   const unsigned long long ib = in_bytes;
   const unsigned wb = (unsigned)wp_bytes;
   auto blocks = [&](int bm, int bn) { return (unsigned)(((g.M + bm - 1) / bm) * (p.rows_pad / bn)); };
@@ -893,7 +904,7 @@ static int launch_gg_bf16_t(GGParams& p, hipStream_t st) {
     switch (v) {
       case 6: hipLaunchKernelGGL((gg3s_kernel<128, 128, 1, 4, 64, TA>), dim3(blocks(128, 128)), dim3(512), 0, st, p, ib, wb); break;
       case 7: hipLaunchKernelGGL((gg3s_kernel<128, 64, 1, 4, 64, TA>), dim3(blocks(128, 64)), dim3(512), 0, st, p, ib, wb); break;
-      case 8: hipLaunchKernelGGL((gg3s_kernel<64, 64, 1, 4, 64, TA>), dim3(blocks(64, 64)), dim3(512), 0, st, p, ib, wb); break;
+      case 8: hipLaunchKernelGGL((gg3s_kernel<64, 64, 1, 8, 64, TA>), dim3(blocks(64, 64)), dim3(512), 0, st, p, ib, wb); break;
       case 9: hipLaunchKernelGGL((gg3s_kernel<128, 128, 1, 4, 32, TA>), dim3(blocks(128, 128)), dim3(512), 0, st, p, ib, wb); break;
       case 0: hipLaunchKernelGGL((gg2b_kernel<128, 128, 2, 2, 32, TA>), dim3(blocks(128, 128)), dim3(256), 0, st, p, ib, wb); break;
       case 1: hipLaunchKernelGGL((gg2b_kernel<128, 64, 2, 2, 32, TA>), dim3(blocks(128, 64)), dim3(256), 0, st, p, ib, wb); break;
@@ -938,6 +949,7 @@ static int launch_gg_split(GGParams& p, hipStream_t st) {
   const unsigned long long ib = (((unsigned long long)g.N * g.Hi * g.Wi - 1) * g.ldi + g.Ci) * 4ull;
   const unsigned long long wp_bytes = (unsigned long long)(max_ws + 1) * p.rows_pad * g.Ci * 2ull * NP;
   LHG_REQUIRE(wp_bytes < (1ull << 32) - 64, "gather-GEMM (split mode): weight panels of 4 GiB and more are not supported");
+  LHG_REQUIRE(p.planar_out || epilogue_window_fits(g, p.res ? p.ldres : 0, 4), "gather-GEMM: an output tile spans 1 GiB or more (Wo %d, ld %d)", g.Wo, g.ldo);
   const unsigned wb = (unsigned)wp_bytes;
   // workgroups of a bm x bn tiling; for a merged launch also the classes' first workgroups (written into p before it is copied)
   GGParams* q = &p;  // the parameter block being launched: p, or (variants 10..19) a copy of it holding one class
@@ -986,6 +998,8 @@ static int launch_gg_split(GGParams& p, hipStream_t st) {
     if (v >= 5) return strips && (v == 5 || v == 7 || n128);
     return (v == 0 || v == 3) ? n128 : (NP == 3 || f16 || v < 3);
   };
+  // (fourth template argument of gg3s_kernel: waves per SIMD the register allocation must leave room for — what the tile's LDS lets
+  //  a CU hold; without it the straight-line epilogue is scheduled into twice the main loop's registers and halves the occupancy)
   auto run_one = [&](int v) {
     if (NP == 3) {
       switch (v) {
@@ -999,24 +1013,24 @@ static int launch_gg_split(GGParams& p, hipStream_t st) {
     } else if (f16) {
       switch (v) {
         case 3: launch3(gg3s_kernel<128, 128, 2, 1, 32, float, 8, _Float16>, 128, 128, 768); break;
-        case 4: launch3(gg3s_kernel<128, 64, 2, 1, 32, float, 8, _Float16>, 128, 64, 768); break;
-        case 0: launch3(gg3s_kernel<128, 128, 2, 2, 32, float, 4, _Float16>, 128, 128, 512); break;
-        case 1: launch3(gg3s_kernel<128, 64, 2, 2, 32, float, 4, _Float16>, 128, 64, 512); break;
-        case 2: launch3(gg3s_kernel<64, 64, 2, 2, 32, float, 4, _Float16>, 64, 64, 512); break;
+        case 4: launch3(gg3s_kernel<128, 64, 2, 6, 32, float, 8, _Float16>, 128, 64, 768); break;
+        case 0: launch3(gg3s_kernel<128, 128, 2, 4, 32, float, 4, _Float16>, 128, 128, 512); break;
+        case 1: launch3(gg3s_kernel<128, 64, 2, 4, 32, float, 4, _Float16>, 128, 64, 512); break;
+        case 2: launch3(gg3s_kernel<64, 64, 2, 8, 32, float, 4, _Float16>, 64, 64, 512); break;
         case 5: hipLaunchKernelGGL((gg4s_kernel<64, 64>), dim3(blocks_strip(64, 64)), dim3(512), 0, st, p, ib, wb); break;
         case 6: hipLaunchKernelGGL((gg4s_kernel<64, 128>), dim3(blocks_strip(64, 128)), dim3(512), 0, st, p, ib, wb); break;
         case 7: hipLaunchKernelGGL((gg4s_kernel<128, 64>), dim3(blocks_strip(128, 64)), dim3(512), 0, st, p, ib, wb); break;
         case 8: hipLaunchKernelGGL((gg4s_kernel<128, 128>), dim3(blocks_strip(128, 128)), dim3(512), 0, st, p, ib, wb); break;
-        case 9: launch3(gg3s_kernel<64, 128, 2, 2, 32, float, 4, _Float16>, 64, 128, 512); break;
+        case 9: launch3(gg3s_kernel<64, 128, 2, 4, 32, float, 4, _Float16>, 64, 128, 512); break;
         case 10: hipLaunchKernelGGL((gg4s_kernel<256, 128, 4, 2>), dim3(blocks_strip(256, 128)), dim3(768), 0, st, p, ib, wb); break;
         case 11: hipLaunchKernelGGL((gg4s_kernel<256, 64, 4, 2>), dim3(blocks_strip(256, 64)), dim3(768), 0, st, p, ib, wb); break;
         default: break;
       }
     } else {
       switch (v) {
-        case 0: launch3(gg3s_kernel<128, 128, 2, 2>, 128, 128, 512); break;
-        case 1: launch3(gg3s_kernel<128, 64, 2, 2>, 128, 64, 512); break;
-        default: launch3(gg3s_kernel<64, 64, 2, 2>, 64, 64, 512); break;
+        case 0: launch3(gg3s_kernel<128, 128, 2, 4>, 128, 128, 512); break;
+        case 1: launch3(gg3s_kernel<128, 64, 2, 4>, 128, 64, 512); break;
+        default: launch3(gg3s_kernel<64, 64, 2, 8>, 64, 64, 512); break;
       }
     }
   };
