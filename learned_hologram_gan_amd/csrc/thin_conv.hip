@@ -228,8 +228,11 @@ __global__ __launch_bounds__(256) void thin_fanin_kernel(const ThinParams p) {
 
 // ------------------------------------------------------------------------------------------------ wgrad
 // Same mapping: lane <-> wide channel, thin strip staged in LDS; a lane accumulates its channel's T x CT gradients over the
-// pixels its wave visits, so there is no cross-lane reduction.  Workgroups walk row segments item, item + gridDim.x, ...;
-// every (workgroup, pixel range) pair writes one partial slab: partial[slab][t][ct][cw], summed by thin_wgrad_reduce_kernel.
+// pixels its wave visits, so there is no cross-lane reduction.  Workgroups walk row segments item, item + gridDim.x, ...; the
+// waves of a workgroup that share a channel block add their sums through LDS in wave order and the workgroup writes ONE partial
+// slab: partial[workgroup][t][ct][cw], summed by thin_wgrad_reduce_kernel.  (Round 4: one slab per wave meant 256 workgroups for the
+// 1024-slab budget — one wave per SIMD, every group of TP pixel loads waited for in full: 243 us for 151 MB at 384^2 x 4.  Now up to
+// 1024 workgroups, and the next group's loads are in flight while the current one is multiplied.)
 template <int T, int CT>
 __global__ __launch_bounds__(256) void thin_wgrad_kernel(const ThinParams p, const float* __restrict__ thin, const float* __restrict__ wide,
                                                         float* __restrict__ partial) {
@@ -254,16 +257,20 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const ThinParams p, con
     const int row = item / segs, seg = item - row * segs;
     const int y = row % p.H;
     const int x_begin = seg * p.segw, x_cnt = min(p.segw, p.W - x_begin);
+    const int per = ((x_cnt + wpp - 1) / wpp + TP - 1) / TP * TP;
+    const int xs = wp * per, xe = min(x_cnt, xs + per);
+    const float* q0 = wide + ((long long)row * p.W + x_begin) * p.ld_w + cc;
+    auto load_group = [&](int x0, float (&wv)[TP]) {
+#pragma unroll
+      for (int j = 0; j < TP; ++j) wv[j] = x0 + j < xe ? q0[(long long)(x0 + j) * p.ld_w] : 0.f;
+    };
+    float wv[TP], wn[TP];
+    load_group(xs, wv);  // goes out before the strip is staged
     __syncthreads();  // previous strip fully consumed
     stage_strip<CT, HALO>(p, thin, row, y, x_begin, tw);
     __syncthreads();
-    const int per = ((x_cnt + wpp - 1) / wpp + TP - 1) / TP * TP;
-    const int xs = wp * per, xe = min(x_cnt, xs + per);
     for (int x0 = xs; x0 < xe; x0 += TP) {
-      float wv[TP];
-      const float* q = wide + ((long long)row * p.W + x_begin + x0) * p.ld_w + cc;
-#pragma unroll
-      for (int j = 0; j < TP; ++j) wv[j] = x0 + j < xe ? q[(long long)(x0 + j < xe ? j : 0) * p.ld_w] : 0.f;
+      load_group(x0 + TP, wn);
 #pragma unroll
       for (int r = 0; r < ROWS; ++r) {
         float s[TP + 2 * HALO][CT];
@@ -279,19 +286,36 @@ __global__ __launch_bounds__(256) void thin_wgrad_kernel(const ThinParams p, con
 #pragma unroll
             for (int ct = 0; ct < CT; ++ct) acc[r * ROWS + kx][ct] = fmaf(s[j + kx][ct], wv[j], acc[r * ROWS + kx][ct]);
       }
+#pragma unroll
+      for (int j = 0; j < TP; ++j) wv[j] = wn[j];
     }
   }
-  if (live) {
+  // the wpp waves of a channel block: wave 0 stores, waves 1.. add in order (fixed summation order), then the block's slab is written
+  __syncthreads();  // the last strip is no longer read
+  float* red = thin_lds + (size_t)wc * T * CT * 64;
+  for (int w = 0; w < wpp; ++w) {
+    if (wp == w) {
+#pragma unroll
+      for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int ct = 0; ct < CT; ++ct) {
+          float* r = red + (t * CT + ct) * 64 + lane;
+          *r = w == 0 ? acc[t][ct] : *r + acc[t][ct];
+        }
+    }
+    __syncthreads();
+  }
+  if (live && wp == 0) {
     // sign < 0: the strip was sampled at p + d_t' while the gradient tap is t = T-1-t' (d_{T-1-t} = -d_t)
-    float* slab = partial + (size_t)(blockIdx.x * wpp + wp) * T * CT * p.cw + c;
+    float* slab = partial + (size_t)blockIdx.x * T * CT * p.cw + c;
 #pragma unroll
     for (int t = 0; t < T; ++t)
 #pragma unroll
-      for (int ct = 0; ct < CT; ++ct) slab[((size_t)(p.sign > 0 ? t : T - 1 - t) * CT + ct) * p.cw] = acc[t][ct];
+      for (int ct = 0; ct < CT; ++ct) slab[((size_t)(p.sign > 0 ? t : T - 1 - t) * CT + ct) * p.cw] = red[(t * CT + ct) * 64 + lane];
   }
 }
 
-// gw[ct*st + cw*sw + t] = sum_wave partial[wave][t][ct][cw] (double accumulation, fixed order).  grid ceil(J/32), block 32 x 32.
+// gw[ct*st + cw*sw + t] = sum_slab partial[slab][t][ct][cw] (double accumulation, fixed order).  grid ceil(J/32), block 32 x 32.
 __global__ __launch_bounds__(1024) void thin_wgrad_reduce_kernel(const float* __restrict__ partial, int nwaves, int T, int CT, int cw,
                                                                    int ct_real, int st, int sw, float* __restrict__ gw) {
   __shared__ double red[32][32];
@@ -338,12 +362,12 @@ static int launch_lane_kernel(int kind, ThinParams& p, hipStream_t st) {
   const unsigned gy = (unsigned)((cblocks + p.wpc - 1) / p.wpc);
   const size_t lds = (size_t)(2 * HALO + 1) * (segw + 2 * HALO) * CT * sizeof(float);
   if (kind == K_WGRAD) {
-    const int wpp = 4 / p.wpc;
-    int blocks = p.nwaves / wpp;  // nwaves = slab budget
+    int blocks = p.nwaves;  // nwaves = slab budget; one slab per workgroup
     if (blocks > items) blocks = items;
     if (blocks < 1) blocks = 1;
-    p.nwaves = blocks * wpp;
-    hipLaunchKernelGGL((thin_wgrad_kernel<T, CT>), dim3(blocks, gy), dim3(256), lds, st, p, p.thin, p.wide, p.out);
+    p.nwaves = blocks;
+    const size_t lds_red = (size_t)p.wpc * T * CT * 64 * sizeof(float);  // the waves' sums meet in the strip's LDS
+    hipLaunchKernelGGL((thin_wgrad_kernel<T, CT>), dim3(blocks, gy), dim3(256), std::max(lds, lds_red), st, p, p.thin, p.wide, p.out);
     return check_launch("thin_wgrad");
   }
   hipLaunchKernelGGL((thin_fanout_kernel<T, CT>), dim3(items, gy), dim3(256), lds, st, p, p.thin, p.out);
