@@ -419,6 +419,32 @@ __device__ __forceinline__ float2 apply_filter(float2 z, float2 f, int op) {
   }
 }
 
+// The same on U values at once with the operation chosen OUTSIDE the element loop: `apply_filter` inside an unrolled loop compiles to
+// a run-time switch per element behind each element's own load and wait — one exposed memory latency per element (round 4: the
+// column passes spent most of their time there).  Same arithmetic per element, so the same bits.
+template <int U>
+__device__ __forceinline__ void apply_filter_batch(float2 (&z)[U], const float2 (&f)[U], int op) {
+  switch (op) {  // uniform
+    case F_MUL:
+#pragma unroll
+      for (int u = 0; u < U; ++u) z[u] = apply_filter(z[u], f[u], F_MUL);
+      break;
+    case F_MUL_CONJ:
+#pragma unroll
+      for (int u = 0; u < U; ++u) z[u] = apply_filter(z[u], f[u], F_MUL_CONJ);
+      break;
+    case F_DIV:
+#pragma unroll
+      for (int u = 0; u < U; ++u) z[u] = apply_filter(z[u], f[u], F_DIV);
+      break;
+    case F_DIV_CONJ:
+#pragma unroll
+      for (int u = 0; u < U; ++u) z[u] = apply_filter(z[u], f[u], F_DIV_CONJ);
+      break;
+    default: break;
+  }
+}
+
 // ---------------------------------------------------------------------------------------- Bluestein (chirp-z) lengths
 // A length n outside 2^a 3^b (832 = 2^6 13: the 192^2 frame with the CLI's default pad 320) is transformed as a circular convolution of
 // length m >= 2n - 1 (bluestein_len: a power of two, or 2^a 3^b above 4096) with the chirp c[j] = exp(i pi j^2 / n):
@@ -544,23 +570,68 @@ __global__ __launch_bounds__(PRIMES ? 512 : 1024) void cols_filter_kernel(const 
     for (int i = tid; i < L; i += nth) twl[i] = p.tw[i];
   // load G columns (zero outside the stored rows)
   const int lg = __ffs(p.G) - 1, gm = p.G - 1;  // G is a power of two
-  for (int i = tid; i < p.R * p.G; i += nth) {
-    const int g = i & gm, r = i >> lg;
-    const int sr = r - p.src_off;
-    float2 z = make_float2(0.f, 0.f);
-    if (sr >= 0 && sr < p.src_rows) z = p.src[((size_t)plane * p.src_rows + sr) * p.C + c0 + g];
-    buf[g * stride + r] = z;
+  // (CU = 4 accesses of every thread in flight: one 1024-thread workgroup per CU with one load per thread is ~8 KB in flight, far
+  //  below what the memory latency needs; addresses are clamped and the value selected, so no load sits behind a branch)
+  constexpr int CU = 4;
+  const int total = p.R * p.G;
+  {
+    const float2* srcp = p.src + (size_t)plane * p.src_rows * p.C + c0;
+    int i = tid;
+    for (; i + (CU - 1) * nth < total; i += CU * nth) {
+      float2 z[CU];
+#pragma unroll
+      for (int u = 0; u < CU; ++u) {
+        const int idx = i + u * nth, g = idx & gm, sr = (idx >> lg) - p.src_off;
+        const bool ok = sr >= 0 && sr < p.src_rows;
+        const float2 l = srcp[(size_t)(ok ? sr : 0) * p.C + g];
+        z[u] = ok ? l : make_float2(0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < CU; ++u) {
+        const int idx = i + u * nth;
+        buf[(idx & gm) * stride + (idx >> lg)] = z[u];
+      }
+    }
+    for (; i < total; i += nth) {
+      const int g = i & gm, r = i >> lg, sr = r - p.src_off;
+      float2 z = make_float2(0.f, 0.f);
+      if (sr >= 0 && sr < p.src_rows) z = srcp[(size_t)sr * p.C + g];
+      buf[g * stride + r] = z;
+    }
   }
   __syncthreads();
   if (p.do_fwd) fft_line<false, PRIMES>(buf, p.R, p.M, p.G, stride, tw, p.tw);
   const int s1 = p.f1_op ? (p.f1_index ? p.f1_index[plane] : 0) : 0;
   const int s2 = p.f2_op ? (p.f2_index ? p.f2_index[plane] : 0) : 0;
   if (p.f1_op || p.f2_op || p.scale != 1.f) {
-    for (int i = tid; i < p.R * p.G; i += nth) {
+    const float2* f1p = p.f1_op ? p.f1 + (size_t)s1 * p.R * p.C + c0 : nullptr;
+    const float2* f2p = p.f2_op ? p.f2 + (size_t)s2 * p.R * p.C + c0 : nullptr;
+    int i = tid;
+    for (; i + (CU - 1) * nth < total; i += CU * nth) {
+      float2 z[CU], fa[CU], fb[CU];
+      if (p.f1_op) {
+#pragma unroll
+        for (int u = 0; u < CU; ++u) { const int idx = i + u * nth; fa[u] = f1p[(size_t)(idx >> lg) * p.C + (idx & gm)]; }
+      }
+      if (p.f2_op) {
+#pragma unroll
+        for (int u = 0; u < CU; ++u) { const int idx = i + u * nth; fb[u] = f2p[(size_t)(idx >> lg) * p.C + (idx & gm)]; }
+      }
+#pragma unroll
+      for (int u = 0; u < CU; ++u) { const int idx = i + u * nth; z[u] = buf[(idx & gm) * stride + (idx >> lg)]; }
+      if (p.f1_op) apply_filter_batch<CU>(z, fa, p.f1_op);
+      if (p.f2_op) apply_filter_batch<CU>(z, fb, p.f2_op);
+#pragma unroll
+      for (int u = 0; u < CU; ++u) {
+        const int idx = i + u * nth;
+        buf[(idx & gm) * stride + (idx >> lg)] = make_float2(z[u].x * p.scale, z[u].y * p.scale);
+      }
+    }
+    for (; i < total; i += nth) {
       const int g = i & gm, k = i >> lg;
       float2 z = buf[g * stride + k];
-      if (p.f1_op) z = apply_filter(z, p.f1[((size_t)s1 * p.R + k) * p.C + c0 + g], p.f1_op);
-      if (p.f2_op) z = apply_filter(z, p.f2[((size_t)s2 * p.R + k) * p.C + c0 + g], p.f2_op);
+      if (p.f1_op) z = apply_filter(z, f1p[(size_t)k * p.C + g], p.f1_op);
+      if (p.f2_op) z = apply_filter(z, f2p[(size_t)k * p.C + g], p.f2_op);
       z.x *= p.scale; z.y *= p.scale;
       buf[g * stride + k] = z;
     }
