@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define LHG_ABI_VERSION 6
+#define LHG_ABI_VERSION 7
 
 enum {
   LHG_OK = 0,
@@ -301,12 +301,15 @@ int lhg_bn_backward(const float* gy, int ldgy, const float* x, int ldx, const fl
                     float* ggamma, float* gbeta, int accumulate, float* ws, float* gx_absmax,
                     const float* beta, lhg_stream_t s);
 /* lhg_bn_backward (fp32 storage) that also writes the per-channel partial maxima of gx and, when both `gres` and
- * `gres_chanmax_partial` are non-NULL, of gres (the gy operand of the block's shortcut conv) — see lhg_channel_absmax_finish. */
+ * `gres_chanmax_partial` are non-NULL, of gres (the gy operand of the block's shortcut conv) — see lhg_channel_absmax_finish.
+ * `gres_absmax` (ABI 7; NULL: not measured): max|gres| is max-accumulated into it like max|gx| into `gx_absmax` — the tensor scale
+ * the shortcut conv's input-gradient GEMM needs, without a pass of its own over gres. */
 int lhg_bn_backward_chanmax(const float* gy, int ldgy, const float* x, int ldx, const float* y, int ldy,
                             long long pixels, int C, const float* stats, const float* gamma,
                             int act, float slope, float* gx, int ldgx, float* gres, int ldgres,
                             float* ggamma, float* gbeta, int accumulate, float* ws, float* gx_absmax,
-                            const float* beta, float* gx_chanmax_partial, float* gres_chanmax_partial, lhg_stream_t s);
+                            const float* beta, float* gx_chanmax_partial, float* gres_chanmax_partial, float* gres_absmax,
+                            lhg_stream_t s);
 /* Double backward of the gx output above (WGAN-GP, ref: watermelon.py:466-473):
  * given ggx (cotangent of gx) returns ggy (cotangent of gy), gx2 (cotangent of x) and
  * ggamma2 (cotangent of gamma).  ws: >= 5*4096*C floats. */

@@ -343,11 +343,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const T* __restrict__ gy, in
                                                     float* __restrict__ ggamma, float* __restrict__ gbeta, int accumulate, int lanes_c,
                                                     int rows, float* __restrict__ gx_amax, const float* __restrict__ beta, float invn,
                                                     unsigned* __restrict__ cmax_partial,        // as bn_apply_kernel's, of gx
-                                                    unsigned* __restrict__ cmax_partial_res) {  // the same of gres (null without gres)
+                                                    unsigned* __restrict__ cmax_partial_res,    // the same of gres (null without gres)
+                                                    float* __restrict__ gres_amax = nullptr) {  // max|gres| (null: not measured)
   __shared__ u32x4 cred[256];
   const int tx = threadIdx.x % lanes_c, ty = threadIdx.x / lanes_c;
-  unsigned am = 0;
-  const unsigned seen = amax_peek(gx_amax);
+  unsigned am = 0, amr = 0;
+  const unsigned seen = amax_peek(gx_amax), seen_r = amax_peek(gres_amax);
   for (int cb0 = blockIdx.y * lanes_c * 4; cb0 < C; cb0 += gridDim.y * lanes_c * 4) {  // uniform trip count: barriers inside
     const int cb = cb0 + tx * 4;
     const bool live = cb < C;
@@ -380,7 +381,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const T* __restrict__ gy, in
             if (act != LHG_ACT_NONE) g *= act_grad4(recompute ? bn_affine(v.b, fa, fb) : v.c, act, slope);
             if (gres) {
               st4(gres + (size_t)q * ldgres + cb, g);
-              if (cmax_partial_res) {
+              if (cmax_partial_res || gres_amax) {
 #pragma unroll
                 for (int e = 0; e < 4; ++e) cr[e] = fmaxf(cr[e], fabsf(g[e]));
               }
@@ -392,11 +393,16 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const T* __restrict__ gy, in
             for (int e = 0; e < 4; ++e) cm[e] = fmaxf(cm[e], fabsf(o[e]));
           });
       am = max(am, __float_as_uint(fmaxf(fmaxf(cm[0], cm[1]), fmaxf(cm[2], cm[3]))));
+      amr = max(amr, __float_as_uint(fmaxf(fmaxf(cr[0], cr[1]), fmaxf(cr[2], cr[3]))));
     }
     if (cmax_partial) channel_max_commit(cred, __builtin_bit_cast(u32x4, cm), tx, ty, lanes_c, rows, live, cmax_partial + (size_t)blockIdx.x * C + cb);
     if (cmax_partial_res) channel_max_commit(cred, __builtin_bit_cast(u32x4, cr), tx, ty, lanes_c, rows, live, cmax_partial_res + (size_t)blockIdx.x * C + cb);
   }
   if (gx_amax) amax_commit(am, gx_amax, seen);
+  if (gres_amax) {  // (uniform)
+    __syncthreads();  // amax_commit's four-word LDS scratch is reused
+    amax_commit(amr, gres_amax, seen_r);
+  }
 }
 
 // ------------------------------------------------------------------ BN double backward (WGAN-GP)
@@ -787,7 +793,7 @@ static int bn_backward_impl(const float* gy, int ldgy, const float* x, int ldx, 
                             const float* stats, const float* gamma, int act, float slope, float* gx, int ldgx, float* gres, int ldgres,
                             float* ggamma, float* gbeta, int accumulate, float* ws, float* gx_absmax, const float* beta, lhg_stream_t s,
                             int phase = 0, float* sums_io = nullptr, float inv_count = 0.f, float* cmax_partial = nullptr,
-                            float* cmax_partial_res = nullptr) {
+                            float* cmax_partial_res = nullptr, float* gres_absmax = nullptr) {
   LHG_NHWC_OK(gy, C, ldgy, "bn_backward(gy)");
   LHG_NHWC_OK(x, C, ldx, "bn_backward(x)");
   if (phase != 1) LHG_NHWC_OK(gx, C, ldgx, "bn_backward(gx)");
@@ -810,7 +816,7 @@ static int bn_backward_impl(const float* gy, int ldgy, const float* x, int ldx, 
     const float invn = phase == 2 ? inv_count : 1.f / (float)pixels;
     hipLaunchKernelGGL((bn_bwd_apply<T>), dim3(nb2, cm.gy), dim3(256), 0, as_stream(s), as_act<T>(gy), ldgy, as_act<T>(x), ldx, as_act<T>(y), ldy, pixels, C, stats,
                        gamma, sums, act, slope, as_act<T>(gx), ldgx, as_act<T>(gres), ldgres, ggamma, gbeta, accumulate, cm.lanes_c, cm.rows, gx_absmax, beta, invn,
-                       reinterpret_cast<unsigned*>(cmax_partial), reinterpret_cast<unsigned*>(gres ? cmax_partial_res : nullptr));
+                       reinterpret_cast<unsigned*>(cmax_partial), reinterpret_cast<unsigned*>(gres ? cmax_partial_res : nullptr), gres ? gres_absmax : nullptr);
   }
   return check_launch("bn_backward");
 }
@@ -923,10 +929,10 @@ int lhg_bn_apply_chanmax(const float* x, int ldx, long long pixels, int C, const
 int lhg_bn_backward_chanmax(const float* gy, int ldgy, const float* x, int ldx, const float* y, int ldy, long long pixels, int C,
                             const float* stats, const float* gamma, int act, float slope, float* gx, int ldgx, float* gres, int ldgres,
                             float* ggamma, float* gbeta, int accumulate, float* ws, float* gx_absmax, const float* beta,
-                            float* gx_chanmax_partial, float* gres_chanmax_partial, lhg_stream_t s) {
+                            float* gx_chanmax_partial, float* gres_chanmax_partial, float* gres_absmax, lhg_stream_t s) {
   LHG_REQUIRE(gx_chanmax_partial != nullptr && !act_is_bf16(), "bn_backward_chanmax: fp32 tensors and a partial buffer (lhg_chanmax_partial_rows x C floats)");
   return bn_backward_impl<float>(gy, ldgy, x, ldx, y, ldy, pixels, C, stats, gamma, act, slope, gx, ldgx, gres, ldgres, ggamma, gbeta, accumulate, ws,
-                                 gx_absmax, beta, s, 0, nullptr, 0.f, gx_chanmax_partial, gres_chanmax_partial);
+                                 gx_absmax, beta, s, 0, nullptr, 0.f, gx_chanmax_partial, gres_chanmax_partial, gres_absmax);
 }
 int lhg_bn_stats(const float* x, long long pixels, int C, int ld, float* stats, float* running_mean, float* running_var,
                  float momentum, float eps, float* ws, lhg_stream_t s) {

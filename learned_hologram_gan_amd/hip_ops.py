@@ -176,7 +176,8 @@ class CatViewsFn(Function):
 
     @staticmethod
     def backward(ctx, g):
-        return g[..., : ctx.ca], g[..., ctx.ca :], None
+        # the slices' elements are a subset of g's: its measured max|.| bounds theirs (the input-gradient GEMMs that read them need a scale)
+        return _inherit_absmax(g[..., : ctx.ca], g), _inherit_absmax(g[..., ctx.ca :], g), None
 
 
 def _as_nhwc_view(t):
@@ -1428,7 +1429,7 @@ class BatchNormPairTrainFn(TrackedFunction):
                     stats[h].data_ptr(), ptr(gamma), ctx.act, float(ctx.slope), pgx + off * Cc * es, Cc, None, Cc, ptr(ggamma), ptr(gbeta), acc,
                     ptr(_bn_ws(Cc, gy.device)), ptr(gx_amax), ptr(ctx.beta_value) if mask_from_x else None)
             if part is not None:
-                call("lhg_bn_backward_chanmax", *args, part.data_ptr() + 4 * h * rows * Cc, None, stream_ptr())
+                call("lhg_bn_backward_chanmax", *args, part.data_ptr() + 4 * h * rows * Cc, None, None, stream_ptr())
             else:
                 call("lhg_bn_backward", *args, stream_ptr())
         tag_absmax(gx, gx_amax)
@@ -1467,15 +1468,18 @@ def bn_backward_raw(gy, x, y, gamma, stats, act, slope, want_res, ggamma, gbeta,
         return gx, gres
     part = chanmax_partial_for(N * H * W, Cc, gy.device)  # gx is the gy operand of the preceding conv's weight gradient
     part_res = chanmax_partial_for(N * H * W, Cc, gy.device) if (want_res and part is not None) else None  # gres: of the shortcut conv's
+    gres_amax = fused_absmax_slot(gy.device) if (want_res and part is not None) else None  # gres is the gy of the shortcut conv's input gradient
     if part is not None:
         call("lhg_bn_backward_chanmax", pg, ldg, px, ldx, py, ldy, N * H * W, Cc, ptr(stats), ptr(gamma), act, float(slope),
              ptr(gx), Cc, ptr(gres), Cc, ptr(ggamma), ptr(gbeta), int(accumulate), ptr(_bn_ws(Cc, gy.device)), ptr(gx_amax), ptr(beta),
-             ptr(part), ptr(part_res), stream_ptr())
+             ptr(part), ptr(part_res), ptr(gres_amax), stream_ptr())
     else:
         call("lhg_bn_backward", pg, ldg, px, ldx, py, ldy, N * H * W, Cc, ptr(stats), ptr(gamma), act, float(slope),
              ptr(gx), Cc, ptr(gres), Cc, ptr(ggamma), ptr(gbeta), int(accumulate), ptr(_bn_ws(Cc, gy.device)), ptr(gx_amax), ptr(beta),
              stream_ptr())
     tag_absmax(gx, gx_amax)
+    if gres_amax is not None:
+        tag_absmax(gres, gres_amax)
     if part is not None:
         tag_chanmax_source(gx, [(0, Cc, part, N * H * W)])
     if part_res is not None:

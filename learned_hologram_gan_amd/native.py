@@ -36,7 +36,7 @@ class PackItem(C.Structure):
 
 
 # name -> argtypes (restype is int unless listed in _RESTYPE)
-ABI_VERSION = 6  # LHG_ABI_VERSION of include/lhg_hip.h this binding was written against
+ABI_VERSION = 7  # LHG_ABI_VERSION of include/lhg_hip.h this binding was written against
 
 _SIGNATURES = {
     "lhg_abi_version": [],
@@ -74,7 +74,7 @@ _SIGNATURES = {
     "lhg_channel_absmax_finish": [_p, _ll, _i, _p, _p],
     "lhg_channel_absmax_finish_rows": [_p, _i, _i, _p, _p],
     "lhg_bn_apply_chanmax": [_p, _i, _ll, _i, _p, _p, _p, _p, _i, _i, _f, _p, _i, _p, _p, _p],
-    "lhg_bn_backward_chanmax": [_p, _i, _p, _i, _p, _i, _ll, _i, _p, _p, _i, _f, _p, _i, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p],
+    "lhg_bn_backward_chanmax": [_p, _i, _p, _i, _p, _i, _ll, _i, _p, _p, _i, _f, _p, _i, _p, _i, _p, _p, _i, _p, _p, _p, _p, _p, _p, _p],
     "lhg_wgrad_reduce": [_p, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p],
     "lhg_channel_sum": [_p, _ll, _i, _i, _p, _i, _p, _p],
     "lhg_bn_stats": [_p, _ll, _i, _i, _p, _p, _p, _f, _f, _p, _p],

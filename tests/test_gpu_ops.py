@@ -208,7 +208,7 @@ def test_channel_absmax_matches_torch(ops):
 
 
 def test_bn_kernels_leave_the_per_channel_maxima_of_what_they_write(ops):
-    """lhg_bn_apply_chanmax / lhg_bn_backward_chanmax + lhg_channel_absmax_finish (ABI 5): the per-channel maxima of y / gx, bit for bit
+    """lhg_bn_apply_chanmax / lhg_bn_backward_chanmax + lhg_channel_absmax_finish (ABI 5; max|gres| ABI 7): the per-channel maxima of y / gx, bit for bit
     those of a pass over the tensor, and y / gx / the parameter gradients bit-identical to the plain calls'."""
     from learned_hologram_gan_amd.native import call, load, ptr, stream_ptr
 
@@ -236,10 +236,12 @@ def test_bn_kernels_leave_the_per_channel_maxima_of_what_they_write(ops):
             if fused:
                 part.fill_(float("nan"))
                 part_res = torch.full_like(part, float("nan"))
-                call("lhg_bn_backward_chanmax", *args, ptr(part), ptr(part_res), stream_ptr())
+                res_amax = torch.zeros(1, device=DEV)  # ABI 7: max|gres| max-accumulated into a zeroed slot
+                call("lhg_bn_backward_chanmax", *args, ptr(part), ptr(part_res), ptr(res_amax), stream_ptr())
                 for p_, t_ in ((part, gx), (part_res, gr)):
                     call("lhg_channel_absmax_finish", ptr(p_), pixels, C, ptr(out), stream_ptr())
                     assert torch.equal(out, t_.abs().amax(dim=0)), (C, pixels)
+                assert res_amax.item() == gr.abs().max().item(), (C, pixels)
             else:
                 call("lhg_bn_backward", *args, stream_ptr())
             res.append((gx, gr, gg, gb))
