@@ -250,9 +250,9 @@ __global__ __launch_bounds__(256, 2) void gg_kernel(const GGParams p) {
   }
 }
 
+#include "gg_epilogue.inc"
 #include "gg2_kernel.inc"
 #include "gg2b_kernel.inc"
-#include "gg_epilogue.inc"
 #include "gg3s_kernel.inc"
 #include "gg4s_kernel.inc"
 
@@ -828,6 +828,7 @@ static int launch_gg(GGParams& p, hipStream_t st) {
   LHG_REQUIRE((reinterpret_cast<uintptr_t>(p.wp) & 15) == 0, "gather-GEMM: packed weights must be 16-byte aligned");
   LHG_REQUIRE(p.rows_pad % 64 == 0 && p.rows_pad >= g.Co, "gather-GEMM: rows_pad %d must be a multiple of 64 covering Co=%d", p.rows_pad, g.Co);
   LHG_REQUIRE((long long)g.N * g.Ho * g.Wo < (1ll << 31) && (long long)g.N * g.Hi * g.Wi < (1ll << 31), "gather-GEMM: more than 2^31 pixels");
+  LHG_REQUIRE(p.planar_out || epilogue_window_fits(g, p.res ? p.ldres : 0, 4), "gather-GEMM: an output tile spans 1 GiB or more (Wo %d, ld %d)", g.Wo, g.ldo);
   // extents addressed through 32-bit buffer descriptors by the pipelined kernels
   int max_ws = 0;
   for (int t = 0; t < g.T; ++t) max_ws = std::max(max_ws, g.ws[t]);
