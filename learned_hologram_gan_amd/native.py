@@ -160,7 +160,16 @@ def load():
     return lib
 
 
+# torch.cuda.current_stream() builds a Stream object per call (~9 us; ~500 calls per train step: 4 - 5 ms of the host's launch loop,
+# tools/host_profile.py); the raw getters behind it return the same hipStream_t in well under a microsecond.
+_RAW_STREAM = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+_RAW_DEVICE = getattr(torch._C, "_cuda_getDevice", None)
+
+
 def stream_ptr() -> int:
+    """The current HIP stream of the current device as an integer handle (what every lhg_* entry point takes last)."""
+    if _RAW_STREAM is not None and _RAW_DEVICE is not None:
+        return _RAW_STREAM(_RAW_DEVICE())
     return torch.cuda.current_stream().cuda_stream
 
 
