@@ -47,7 +47,7 @@ int main() {
   hipMalloc(&din, h.size() * 2); hipMalloc(&dout, 2048 * 256 * 4);
   hipMemcpy(din, h.data(), h.size() * 2, hipMemcpyHostToDevice);
   hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
-  const int iters = 4000;
+  const int iters = 40000;
   for (int waves = 1; waves <= 2; ++waves)
     for (int shape : {32, 16}) {
       const int blocks = 256 * waves;   // 256-thread blocks: 4 waves each -> `waves` waves per SIMD
