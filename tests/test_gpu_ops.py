@@ -407,6 +407,33 @@ def test_conv2d_fused_epilogue(ops):
     assert (buf[..., :64] == 7.0).all()
 
 
+@pytest.mark.parametrize("k,stride", [(3, 1), (1, 1), (3, 2)], ids=["3x3", "1x1", "3x3s2"])
+@pytest.mark.parametrize("act", [0, 1, 2, 3], ids=["none", "relu", "leaky", "sigmoid"])
+def test_gather_gemm_epilogue_writes_its_window_and_nothing_else(ops, k, stride, act):
+    """The tile store goes through a buffer descriptor based at the tile's first pixel (csrc/gg_epilogue.inc): padding rows of the strip
+    kernel, rows past the end of the last tile and columns past Co get offsets the descriptor rejects.  Output into a channel slice of a
+    wider NaN-filled buffer at odd extents, Co = 48 (a partial 32-column block), residual from a slice with another row pitch, every
+    activation: the slice equals the float64 reference, max|y| is exact, and every byte outside the slice is still NaN."""
+    N, Ci, Co, H, W = 3, 64, 48, 13, 11
+    x, w, b = rnd(N, Ci, H, W, seed=11), rnd(Co, Ci, k, k, seed=12, scale=0.05), rnd(Co, seed=13)
+    Ho, Wo = (H + 2 * (k // 2) - k) // stride + 1, (W + 2 * (k // 2) - k) // stride + 1
+    res = rnd(N, Co, Ho, Wo, seed=14)
+    ref = F.conv2d(x.double(), w.double(), b.double(), stride=stride, padding=k // 2) + res.double()
+    ref = {0: ref, 1: F.relu(ref), 2: F.leaky_relu(ref, 0.2), 3: torch.sigmoid(ref)}[act]
+    buf = torch.full((N, Ho, Wo, 160), float("nan"), device=DEV)
+    rbuf = torch.zeros((N, Ho, Wo, 96), device=DEV)
+    rbuf[..., 32:80] = res.permute(0, 2, 3, 1).to(DEV)
+    y = ops.conv2d_forward_raw(to_nhwc(x), w.to(DEV), b.to(DEV), stride, act=act, slope=0.2, res=rbuf[..., 32:80],
+                               out=ops.OutSlot(buf[..., 64:112]), measure_out=True)
+    torch.cuda.synchronize()
+    got = buf[..., 64:112].permute(0, 3, 1, 2).cpu().double()
+    assert rel_err(got, ref) < TOL, (k, stride, act)
+    assert torch.isnan(buf[..., :64]).all() and torch.isnan(buf[..., 112:]).all(), "stores outside the output slice"
+    known = y.__dict__.get("_lhg_amax")
+    if known is not None:  # (the fp16-split mode measures max|y| on the way out)
+        assert known[1].item() == buf[..., 64:112].abs().max().item()
+
+
 @pytest.mark.parametrize("case", [(2, 64, 32, 8, 10), (1, 128, 64, 12, 12), (2, 1024, 512, 2, 2)], ids=str)
 def test_conv_transpose2x2(ops, case):
     N, Ci, Co, H, W = case
@@ -980,8 +1007,16 @@ with torch.no_grad():
     gx2 = ops.Conv2dInputGradFn.apply(gy2, w, 2, 48, 40, 128)
     slot = torch.zeros(128, 128, 3, 3, device="cuda")
     ops.conv2d_weight_grad_raw(x, gy, (128, 128, 3, 3), 1, slot)
+    # the tile store's window (csrc/gg_epilogue.inc) under THIS variant: odd extents, Co = 80 (a partial column block), output into a
+    # channel slice of a NaN-filled buffer, residual with another row pitch, ReLU — outside the slice every byte must still be NaN
+    xs = torch.randn(3, 13, 11, 128, device="cuda"); ws = torch.randn(80, 128, 3, 3, device="cuda") * 0.05
+    buf = torch.full((3, 13, 11, 192), float("nan"), device="cuda"); rbuf = torch.randn(3, 13, 11, 96, device="cuda")
+    ops.conv2d_forward_raw(xs, ws, None, 1, act=ops.ACT_RELU, res=rbuf[..., 8:88], out=ops.OutSlot(buf[..., 64:144]))
+    torch.cuda.synchronize()
+    assert torch.isnan(buf[..., :64]).all() and torch.isnan(buf[..., 144:]).all() and not torch.isnan(buf[..., 64:144]).any(), "stray stores"
+    ys = buf[..., 64:144].contiguous()
 torch.cuda.synchronize()
-print("HASH", " ".join(hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest()[:16] for t in (y, gx, gx2, slot)))
+print("HASH", " ".join(hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest()[:16] for t in (y, gx, gx2, slot, ys)))
 """
 
 
