@@ -747,7 +747,7 @@ struct ScopedKernelTime {
 
 // LHG_XCD=0 keeps the hardware's round-robin tile order (for A/B measurements of the L2 effect)
 static int xcd_order() {
-  static const int on = [] { const char* e = getenv("LHG_XCD"); return e ? atoi(e) != 0 : 1; }();
+  static const int on = [] { const char* e = getenv("LHG_XCD"); return e ? atoi(e) : 1; }();  // 2: merged-class launches in the round-3 order (gg3s_kernel)
   return on;
 }
 
