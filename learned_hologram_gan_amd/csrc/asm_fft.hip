@@ -565,7 +565,10 @@ __global__ __launch_bounds__(PRIMES ? 512 : 1024) void cols_filter_kernel(const 
   const int stride = L + 1;
   const int tid = threadIdx.x, nth = blockDim.x;
   const int groups = p.C / p.G;
-  const int plane = blockIdx.x / groups, c0 = (blockIdx.x - plane * groups) * p.G;
+  // XCD-contiguous block order: a workgroup's G columns are G * 8 bytes of every row — half a 128-byte line at G = 8 — and the workgroup
+  // that owns the other half is the next block: in the hardware's round-robin order it runs on ANOTHER XCD, whose L2 fetches the line again
+  const int bx = (int)xcd_contiguous(blockIdx.x, gridDim.x);
+  const int plane = bx / groups, c0 = (bx - plane * groups) * p.G;
   if (p.tw_in_lds)
     for (int i = tid; i < L; i += nth) twl[i] = p.tw[i];
   // load G columns (zero outside the stored rows)

@@ -43,6 +43,16 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
 
+// Workgroups are dealt round-robin over the 8 XCDs (linear id % 8 labels the XCD group), each XCD with a private 4 MiB L2.
+// Renumber them so that every XCD walks ONE contiguous range of the tile order: tiles that share input rows (the three rows of
+// a 3x3 gather), an A panel (all n-tiles of one m-tile) or a K slab (all tiles of one weight-gradient split) then meet in the
+// same L2 instead of being fetched once per XCD.  Bijective for any grid size; placement is a speed matter only.
+__device__ __forceinline__ unsigned xcd_contiguous(unsigned lin, unsigned total) {
+  constexpr unsigned XCDS = 8;
+  const unsigned x = lin % XCDS, j = lin / XCDS, q = total / XCDS, r = total % XCDS;
+  return x * q + (x < r ? x : r) + j;
+}
+
 __device__ __forceinline__ float apply_act(float v, int act, float slope) {
   switch (act) {
     case LHG_ACT_RELU: return v > 0.f ? v : 0.f;

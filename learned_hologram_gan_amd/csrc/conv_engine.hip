@@ -83,16 +83,7 @@ struct WGParams {
   const float* gout_amax;
 };
 
-// Workgroups are dealt round-robin over the 8 XCDs (linear id % 8 labels the XCD group), each XCD with a private 4 MiB L2.
-// Renumber them so that every XCD walks ONE contiguous range of the tile order: tiles that share input rows (the three rows of
-// a 3x3 gather), an A panel (all n-tiles of one m-tile) or a K slab (all tiles of one weight-gradient split) then meet in the
-// same L2 instead of being fetched once per XCD.  Bijective for any grid size; placement is a speed matter only.
-__device__ __forceinline__ unsigned xcd_contiguous(unsigned lin, unsigned total) {
-  constexpr unsigned XCDS = 8;
-  const unsigned x = lin % XCDS, j = lin / XCDS, q = total / XCDS, r = total % XCDS;
-  return x * q + (x < r ? x : r) + j;
-}
-
+// (xcd_contiguous: common.h)
 struct Block3 { int x, y, z; };
 __device__ __forceinline__ Block3 xcd_block3(bool enabled) {
   if (!enabled) return {(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};

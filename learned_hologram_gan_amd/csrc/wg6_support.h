@@ -52,12 +52,7 @@ __device__ __forceinline__ f16x8 tr_read_frag_f16(const _Float16* p0, int row_st
   return __builtin_bit_cast(f16x8, v);
 }
 
-// Workgroups are dealt round-robin over the 8 XCDs; renumber them so that every XCD walks one contiguous range (conv_engine.hip)
-__device__ __forceinline__ unsigned xcd_contiguous(unsigned lin, unsigned total) {
-  constexpr unsigned XCDS = 8;
-  const unsigned x = lin % XCDS, j = lin / XCDS, q = total / XCDS, r = total % XCDS;
-  return x * q + (x < r ? x : r) + j;
-}
+// (xcd_contiguous: common.h)
 struct Block3 { int x, y, z; };
 __device__ __forceinline__ Block3 xcd_block3(bool enabled) {
   if (!enabled) return {(int)blockIdx.x, (int)blockIdx.y, (int)blockIdx.z};
