@@ -513,22 +513,43 @@ __global__ __launch_bounds__(MAXT) void rows_forward_kernel(const float* __restr
   for (int i = tid; i < nf * L; i += nth) buf[i] = make_float2(0.f, 0.f);
   __syncthreads();
   const int row0 = blockIdx.x * nf;
-  for (int i = tid; i < nf * cols0; i += nth) {
-    const int f = i / cols0, x = i - f * cols0;
-    const int row = row0 + f;
-    if (row < total_rows) {
-      const size_t o = (size_t)row * cols0 + x;
-      float2 z;
-      if (in_mode == IN_COMPLEX) {
-        z = reinterpret_cast<const float2*>(in_a)[o];
-      } else {
-        const float ph = (in_mode == IN_POLAR ? in_b[o] : in_a[o]) * phase_scale;
-        float sn, cs;
-        sincosf(ph, &sn, &cs);
-        const float a = in_mode == IN_POLAR ? in_a[o] : 1.f;
-        z = make_float2(a * cs, a * sn);
+  // RU loads of every thread in flight before the first is used (a workgroup per CU with one load per thread leaves the memory latency
+  // exposed; round 4): addresses are clamped to a valid element and the value is dropped when the row is past the end
+  constexpr int RU = 4;
+  auto polar = [&](float amp, float ph_raw) {
+    float sn, cs;
+    sincosf(ph_raw * phase_scale, &sn, &cs);
+    return make_float2(amp * cs, amp * sn);
+  };
+  {
+    const int total = nf * cols0;
+    int i = tid;
+    for (; i + (RU - 1) * nth < total; i += RU * nth) {
+      float2 zc[RU];
+      float va[RU], vb[RU];
+      int dst[RU];
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+        const int idx = i + u * nth, f = idx / cols0, x = idx - f * cols0;
+        const bool ok = row0 + f < total_rows;
+        const size_t o = ok ? (size_t)(row0 + f) * cols0 + x : 0;
+        dst[u] = ok ? f * L + pad_c + x : -1;
+        if (in_mode == IN_COMPLEX) zc[u] = reinterpret_cast<const float2*>(in_a)[o];
+        else if (in_mode == IN_POLAR) { va[u] = in_a[o]; vb[u] = in_b[o]; }
+        else { va[u] = 1.f; vb[u] = in_a[o]; }
       }
-      buf[f * L + pad_c + x] = z;
+#pragma unroll
+      for (int u = 0; u < RU; ++u)
+        if (dst[u] >= 0) buf[dst[u]] = in_mode == IN_COMPLEX ? zc[u] : polar(va[u], vb[u]);
+    }
+    for (; i < total; i += nth) {
+      const int f = i / cols0, x = i - f * cols0;
+      const int row = row0 + f;
+      if (row < total_rows) {
+        const size_t o = (size_t)row * cols0 + x;
+        buf[f * L + pad_c + x] = in_mode == IN_COMPLEX ? reinterpret_cast<const float2*>(in_a)[o]
+                                                      : polar(in_mode == IN_POLAR ? in_a[o] : 1.f, in_mode == IN_POLAR ? in_b[o] : in_a[o]);
+      }
     }
   }
   __syncthreads();
@@ -662,10 +683,30 @@ __global__ __launch_bounds__(MAXT) void rows_inverse_kernel(const float2* __rest
   if (tw_in_lds)
     for (int i = tid; i < L; i += nth) twl[i] = twg[i];
   const int row0 = blockIdx.x * nf;
-  for (int i = tid; i < nf * n; i += nth) {
-    const int f = i / n;
-    const int row = row0 + f;
-    buf[f * L + (i - f * n)] = row < total_rows ? t2[(size_t)row * n + (i - f * n)] : make_float2(0.f, 0.f);
+  {
+    constexpr int RU = 4;  // loads of every thread in flight (see rows_forward_kernel)
+    const int total = nf * n;
+    int i = tid;
+    for (; i + (RU - 1) * nth < total; i += RU * nth) {
+      float2 z[RU];
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+        const int idx = i + u * nth, f = idx / n;
+        const bool ok = row0 + f < total_rows;
+        const float2 l = t2[ok ? (size_t)(row0 + f) * n + (idx - f * n) : 0];
+        z[u] = ok ? l : make_float2(0.f, 0.f);
+      }
+#pragma unroll
+      for (int u = 0; u < RU; ++u) {
+        const int idx = i + u * nth, f = idx / n;
+        buf[f * L + (idx - f * n)] = z[u];
+      }
+    }
+    for (; i < total; i += nth) {
+      const int f = i / n;
+      const int row = row0 + f;
+      buf[f * L + (i - f * n)] = row < total_rows ? t2[(size_t)row * n + (i - f * n)] : make_float2(0.f, 0.f);
+    }
   }
   __syncthreads();
   fft_line<true, PRIMES>(buf, n, m, nf, L, tw, twg);
