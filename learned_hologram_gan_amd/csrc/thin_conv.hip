@@ -164,6 +164,12 @@ __global__ __launch_bounds__(256) void thin_fanout_kernel(const ThinParams p, co
 }
 
 // ------------------------------------------------------------------------------------------------ fan-in
+// the value of another lane of the same row of 16 through a DPP control (no LDS traffic)
+template <int CTRL>
+__device__ __forceinline__ float dpp_f32(float v) {
+  return __builtin_bit_cast(float, __builtin_amdgcn_update_dpp(0, __builtin_bit_cast(int, v), CTRL, 0xF, 0xF, true));
+}
+
 template <int T, int CT, int CH>
 __global__ __launch_bounds__(256) void thin_fanin_kernel(const ThinParams p) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -211,8 +217,28 @@ __global__ __launch_bounds__(256) void thin_fanin_kernel(const ThinParams p) {
           for (int e = 0; e < 4; ++e) acc[ct] = fmaf(v[e], wr[t][ct][ch][e], acc[ct]);
       }
     }
-    // sum over the lpp lanes of this pixel (xor tree over the low lane bits: fixed order)
-    for (int m = 1; m < p.lpp; m <<= 1)
+    // sum over the lpp lanes of this pixel: the xor tree over the low lane bits, in fixed order.  Inside a row of 16 lanes the partner
+    // values come through DPP (quad permutes for distances 1 and 2; the half-row / row mirrors pair a lane with one of the OTHER group of
+    // four / eight, whose lanes all hold that group's sum by then — the same pairs of sums as xor 4 / 8, same bits); only distances 16 and
+    // 32 go through the LDS crossbar (ds_bpermute).  Measured: no change of the kernels' time — 32 permutes per four pixels were not what
+    // bounds the 64 -> 6 head (120 us for 151 MB at 384^2) — kept because it takes that traffic off the LDS unit.
+    if (p.lpp > 1) {
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) acc[ct] += dpp_f32<0xB1>(acc[ct]);    // quad_perm [1,0,3,2]
+    }
+    if (p.lpp > 2) {
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) acc[ct] += dpp_f32<0x4E>(acc[ct]);    // quad_perm [2,3,0,1]
+    }
+    if (p.lpp > 4) {
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) acc[ct] += dpp_f32<0x141>(acc[ct]);   // row_half_mirror
+    }
+    if (p.lpp > 8) {
+#pragma unroll
+      for (int ct = 0; ct < CT; ++ct) acc[ct] += dpp_f32<0x140>(acc[ct]);   // row_mirror
+    }
+    for (int m = 16; m < p.lpp; m <<= 1)
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) acc[ct] += __shfl_xor(acc[ct], m, 64);
     if (live && cl == 0) {
