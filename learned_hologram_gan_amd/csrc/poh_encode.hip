@@ -24,22 +24,32 @@ __device__ __forceinline__ float stencil_weight(int dy, int dx, float w0, float 
   return (dy == 0 && dx == 0) ? w0 : ((dy == 0 || dx == 0) ? w1 : w2);
 }
 
+// The nine taps are loaded first — from clamped coordinates, a tap outside the image replaced by zero — and accumulated afterwards in the
+// same order: with a `continue` per tap every load sat behind its own branch and the kernel ran at 0.36 TB/s on the 4K frame (round 4).
 __device__ __forceinline__ float2 stencil_at(const float2* __restrict__ f, int y, int x, int rows, int cols, float w0, float w1, float w2) {
-  float2 acc = make_float2(0.f, 0.f);
+  float2 v[3][3];
 #pragma unroll
   for (int dy = -1; dy <= 1; ++dy) {
     const int yy = y + dy;
-    if ((unsigned)yy >= (unsigned)rows) continue;
+    const bool oky = (unsigned)yy < (unsigned)rows;
+    const size_t rowoff = (size_t)(oky ? yy : y) * cols;
 #pragma unroll
     for (int dx = -1; dx <= 1; ++dx) {
       const int xx = x + dx;
-      if ((unsigned)xx >= (unsigned)cols) continue;
-      const float w = stencil_weight(dy, dx, w0, w1, w2);
-      const float2 v = f[(size_t)yy * cols + xx];
-      acc.x += w * v.x;
-      acc.y += w * v.y;
+      const bool ok = oky && (unsigned)xx < (unsigned)cols;
+      const float2 l = f[rowoff + (ok ? xx : x)];
+      v[dy + 1][dx + 1] = ok ? l : make_float2(0.f, 0.f);
     }
   }
+  float2 acc = make_float2(0.f, 0.f);
+#pragma unroll
+  for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+    for (int dx = -1; dx <= 1; ++dx) {
+      const float w = stencil_weight(dy, dx, w0, w1, w2);
+      acc.x += w * v[dy + 1][dx + 1].x;
+      acc.y += w * v[dy + 1][dx + 1].y;
+    }
   return acc;
 }
 
