@@ -46,6 +46,54 @@ __global__ __launch_bounds__(256) void wg6_reduce_kernel(const float* __restrict
   }
 }
 
+// The same sum for many splits and few outputs (64 -> 64 @ 384^2: S = 256 slabs of 9 x 64 x 64, i.e. 36 workgroups of the kernel above walking
+// 256 loads each): the four waves of a workgroup take the four contiguous quarters of the split axis for the SAME 64 outputs and wave 0 adds
+// the quarters in order, ((q0 + q1) + q2) + q3 — a fixed order, used for S >= 32 only (below that the kernel above, whose order the in-launch
+// reduction shares).
+__global__ __launch_bounds__(256) void wg6_reduce4_kernel(const float* __restrict__ slabs, int S, int T, int m_pad, int n_pad, float* __restrict__ grad,
+                                                          int Cn, int Cm, int accumulate) {
+  __shared__ f32x4 part[3][64];
+  const int n4 = n_pad / 4;
+  const long long total = (long long)T * Cm * n4;
+  const size_t slab_stride = (size_t)T * m_pad * n_pad;
+  const int o = threadIdx.x & 63, q = threadIdx.x >> 6;
+  const long long i = (long long)blockIdx.x * 64 + o;
+  const bool live = i < total;
+  const long long ii = live ? i : total - 1;
+  const int c4 = (int)(ii % n4);
+  const int m = (int)((ii / n4) % Cm);
+  const int tap = (int)(ii / ((long long)n4 * Cm));
+  const int chunk = (S + 3) / 4, s0 = q * chunk, s1 = min(S, s0 + chunk);
+  const float* src = slabs + ((size_t)tap * m_pad + m) * n_pad + c4 * 4;
+  f32x4 v = {0.f, 0.f, 0.f, 0.f};
+  if (s0 < s1) {
+    v = *reinterpret_cast<const f32x4*>(src + (size_t)s0 * slab_stride);
+    int s = s0 + 1;
+    for (; s + 8 <= s1; s += 8) {
+      f32x4 r[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) r[u] = *reinterpret_cast<const f32x4*>(src + (size_t)(s + u) * slab_stride);
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v += r[u];
+    }
+    for (; s < s1; ++s) v += *reinterpret_cast<const f32x4*>(src + (size_t)s * slab_stride);
+  }
+  if (q > 0) part[q - 1][o] = v;
+  __syncthreads();
+  if (q == 0 && live) {
+    const int filled = (S + chunk - 1) / chunk;  // quarters that hold splits (S >= 32: all four)
+    for (int k = 1; k < filled; ++k) v += part[k - 1][o];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int n = c4 * 4 + e;
+      if (n < Cn) {
+        float* dst = grad + ((size_t)n * Cm + m) * T + tap;
+        *dst = accumulate ? *dst + v[e] : v[e];
+      }
+    }
+  }
+}
+
 namespace {
 
 struct Variant {
@@ -212,6 +260,11 @@ int wg6_launch(const Wg6Problem& q, const Wg6Plan& plan, float* slabs, unsigned*
 
 int wg6_reduce(const float* slabs, int S, int T, int m_pad, int n_pad, float* grad, int Cn, int Cm, int accumulate, hipStream_t st) {
   const long long total = (long long)T * Cm * (n_pad / 4);
+  static const int split4 = [] { const char* e = getenv("LHG_WG6_REDUCE4"); return e ? atoi(e) : 1; }();  // 0: the one-thread-per-output kernel for every S (A/B)
+  if (split4 && S >= 32 && total < (1ll << 20)) {  // many splits, few outputs: the split axis over the workgroup's four waves
+    hipLaunchKernelGGL(wg6_reduce4_kernel, dim3((unsigned)((total + 63) / 64)), dim3(256), 0, st, slabs, S, T, m_pad, n_pad, grad, Cn, Cm, accumulate);
+    return check_launch("wg6_reduce4");
+  }
   const int blocks = (int)std::min<long long>((total + 255) / 256, 16384);
   hipLaunchKernelGGL(wg6_reduce_kernel, dim3(std::max(blocks, 1)), dim3(256), 0, st, slabs, S, T, m_pad, n_pad, grad, Cn, Cm, accumulate);
   return check_launch("wg6_reduce");

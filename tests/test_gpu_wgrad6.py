@@ -142,6 +142,33 @@ def test_conv_transpose_weight_gradient_every_variant(lib, case):
     lib.lhg_wg6_force(-1, -1, -1)
 
 
+def test_many_splits_take_the_split_parallel_reduce(lib):
+    """S >= 32 with few outputs (the 64-channel layers at 384^2 run S = 128 .. 256): lhg_wgrad's reduce splits the S axis over the four waves
+    of a workgroup and adds the quarters in order — against float64, equal to itself on repetition, and within rounding of the sequential
+    order (S = 31 runs the one-thread-per-output kernel)."""
+    from learned_hologram_gan_amd import hip_ops as ops
+
+    N, Ci, Co, H, W = 4, 64, 64, 96, 96
+    x, gy = rnd(N, Ci, H, W, seed=31), rnd(N, Co, H, W, seed=32)
+    wd = torch.zeros(Co, Ci, 3, 3, dtype=torch.float64, requires_grad=True)
+    F.conv2d(x.double(), wd, None, padding=1).backward(gy.double())
+    xh, gh = to_nhwc(x), to_nhwc(gy)
+    got = {}
+    for S in (31, 32, 33, 64, 147):
+        lib.lhg_wg6_force(-1, S, 0)
+        a = _conv_wgrad(ops, xh, gh, (Co, Ci, 3, 3), 1)
+        b = _conv_wgrad(ops, xh, gh, (Co, Ci, 3, 3), 1)
+        assert torch.equal(a, b), S
+        assert rel_err(a.cpu().double(), wd.grad) < 1e-5, (S, rel_err(a.cpu().double(), wd.grad))
+        slot = torch.full((Co, Ci, 3, 3), 0.5, device=DEV)
+        with torch.no_grad():
+            ops.conv2d_weight_grad_raw(xh, gh, (Co, Ci, 3, 3), 1, slot)
+        assert torch.equal(slot, a + 0.5), (S, "accumulate")
+        got[S] = a
+    lib.lhg_wg6_force(-1, -1, -1)
+    assert rel_err(got[32].cpu().double(), got[31].cpu().double()) < 1e-6
+
+
 def test_in_launch_reduction_is_repeatable_under_load(lib):
     """The last-arriver reduction (agent-scope release / ticket / acquire) run 200 times back to back on a geometry with many splits,
     alternating with a second stream that keeps the chip busy: every result identical to the separate-launch reduction's bits."""
