@@ -549,11 +549,37 @@ __global__ __launch_bounds__(256) void pack_batch_tiled_kernel(const PackBatch b
   for (unsigned tl = blockIdx.x - it.blk0; tl < (unsigned)(kt * rt); tl += nblk) {
     const int row0 = (int)(tl / kt) * 32, k0 = (int)(tl % kt) * 32;
     // segment g: row-major panels: row row0 + g, its k0 .. k0 + 31 (d1) and all taps; input-gradient panels: k = k0 + g, rows row0 .. + 31 (d1)
-    for (int e = threadIdx.x; e < 32 * run; e += 256) {
-      const int g = e / run, o = e - g * run;
-      const int d0 = it.rows_from_d0 ? row0 + g : k0 + g;
-      const int d1 = (it.rows_from_d0 ? k0 : row0) + o / T;
-      tile[g][o] = (d0 < it.D0 && d1 < it.D1) ? it.w[((size_t)d0 * it.D1 + (it.rows_from_d0 ? k0 : row0)) * T + o] * sc : 0.f;
+    const int d1_0 = it.rows_from_d0 ? k0 : row0;
+    if (((it.D1 * T) & 3) == 0 && d1_0 + 32 <= it.D1 && (reinterpret_cast<uintptr_t>(it.w) & 15) == 0) {
+      // whole runs inside the weight, 16-byte aligned (D1 T and 32 T floats are multiples of four): 16-byte loads, all of a thread's
+      // loads requested before the first is used (with one 4-byte load per iteration the pass ran at a fifth of the memory rate)
+      const int run4 = run / 4;                    // 8 T
+      constexpr int PL = (32 * 8 * PACK_TILE_TMAX + 255) / 256;  // <= 9 loads per thread
+      f32x4 q[PL];
+#pragma unroll
+      for (int u = 0; u < PL; ++u) {
+        const int e = threadIdx.x + 256 * u;
+        const int g = e / run4, o4 = e - g * run4;
+        const int d0 = it.rows_from_d0 ? row0 + g : k0 + g;
+        const bool ok = e < 32 * run4 && d0 < it.D0;
+        q[u] = ok ? *reinterpret_cast<const f32x4*>(it.w + ((size_t)d0 * it.D1 + d1_0) * T + 4 * o4) : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+#pragma unroll
+      for (int u = 0; u < PL; ++u) {
+        const int e = threadIdx.x + 256 * u;
+        if (e < 32 * run4) {
+          const int g = e / run4, o4 = e - g * run4;
+#pragma unroll
+          for (int c = 0; c < 4; ++c) tile[g][4 * o4 + c] = q[u][c] * sc;
+        }
+      }
+    } else {
+      for (int e = threadIdx.x; e < 32 * run; e += 256) {
+        const int g = e / run, o = e - g * run;
+        const int d0 = it.rows_from_d0 ? row0 + g : k0 + g;
+        const int d1 = d1_0 + o / T;
+        tile[g][o] = (d0 < it.D0 && d1 < it.D1) ? it.w[((size_t)d0 * it.D1 + d1_0) * T + o] * sc : 0.f;
+      }
     }
     __syncthreads();
     // outputs: (t, row, k pair): 16 lanes cover the 32 k of one (t, row): two 64-byte runs (plane 0 / plane 1)
