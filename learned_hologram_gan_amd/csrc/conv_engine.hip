@@ -464,8 +464,10 @@ struct PackItem {
   const float* w;
   _Float16* dst;
   unsigned* amax;
+  const unsigned* amax_src;  // where the pack reads max|w|: `amax`, or the slot of an earlier item of the batch with the SAME weight (its other
+                             // panel form): that weight is measured once, and the first workgroup of this item copies the value into `amax`
   int D0, D1, T, rows_from_d0, rows_pad, k_pad;
-  unsigned blk0, ablk0;  // first workgroup of this weight in the pack / max|w| launches
+  unsigned blk0, ablk0;  // first workgroup of this weight in the pack / max|w| launches (a duplicate owns no max|w| workgroups)
 };
 struct PackBatch {
   int n;
@@ -515,7 +517,8 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const PackBatch b) {  /
   const unsigned nblk = (i + 1 < b.n ? b.it[i + 1].blk0 : b.blocks) - it.blk0;
   const size_t total = (size_t)it.T * it.rows_pad * it.k_pad;
   const int kch = it.k_pad / 32;
-  const float sc = split_scale(__uint_as_float(*it.amax));
+  const float sc = split_scale(__uint_as_float(*it.amax_src));
+  if (it.amax_src != it.amax && blockIdx.x == it.blk0 && threadIdx.x == 0) *it.amax = *it.amax_src;
   const int rows = it.rows_from_d0 ? it.D0 : it.D1, K = it.rows_from_d0 ? it.D1 : it.D0;
   for (size_t e = (size_t)(blockIdx.x - it.blk0) * 256 + threadIdx.x; e < total; e += (size_t)nblk * 256) {
     const int k = (int)(e % it.k_pad);
@@ -544,7 +547,8 @@ __global__ __launch_bounds__(256) void pack_batch_tiled_kernel(const PackBatch b
   const PackItem& it = b.it[i];
   const unsigned nblk = (i + 1 < b.n ? b.it[i + 1].blk0 : b.blocks) - it.blk0;
   const int T = it.T, kt = it.k_pad / 32, rt = it.rows_pad / 32, kch = it.k_pad / 32;
-  const float sc = split_scale(__uint_as_float(*it.amax));
+  const float sc = split_scale(__uint_as_float(*it.amax_src));
+  if (it.amax_src != it.amax && blockIdx.x == it.blk0 && threadIdx.x == 0) *it.amax = *it.amax_src;
   const int run = 32 * T;  // floats per contiguous source run
   for (unsigned tl = blockIdx.x - it.blk0; tl < (unsigned)(kt * rt); tl += nblk) {
     const int row0 = (int)(tl / kt) * 32, k0 = (int)(tl % kt) * 32;
@@ -1369,14 +1373,17 @@ int lhg_pack_weights(const lhg_pack_item* items, int n, lhg_stream_t s) {
       it.D0 = q.D0; it.D1 = q.D1; it.T = q.KH * q.KW; it.rows_from_d0 = q.rows_from_d0; it.rows_pad = q.rows_pad; it.k_pad = q.k_pad;
       it.blk0 = blk;
       it.ablk0 = ablk;
+      it.amax_src = it.amax;
+      for (int j = 0; j < i; ++j)  // the same weight earlier in the batch (forward panels and input-gradient panels): measured once
+        if (b.it[j].w == it.w && b.it[j].D0 == it.D0 && b.it[j].D1 == it.D1 && b.it[j].T == it.T && b.it[j].amax_src == b.it[j].amax) { it.amax_src = b.it[j].amax; break; }
       blk += tiled ? (unsigned)std::min<size_t>((size_t)(q.rows_pad / 32) * (q.k_pad / 32), 16384)  // one 32 x 32 tile (all taps) per workgroup
                    : (unsigned)std::min<size_t>((total + 1023) / 1024, 16384);                    // 4 elements per thread
-      ablk += (unsigned)std::min<size_t>((elems + 2047) / 2048, 2048);
+      if (it.amax_src == it.amax) ablk += (unsigned)std::min<size_t>((elems + 2047) / 2048, 2048);
     }
     b.blocks = blk;
     b.ablocks = ablk;
     hipLaunchKernelGGL(pack_batch_zero_kernel, dim3(1), dim3(PACK_BATCH), 0, as_stream(s), b);
-    hipLaunchKernelGGL(pack_batch_absmax_kernel, dim3(ablk), dim3(256), 0, as_stream(s), b);
+    if (ablk) hipLaunchKernelGGL(pack_batch_absmax_kernel, dim3(ablk), dim3(256), 0, as_stream(s), b);
     if (tiled) hipLaunchKernelGGL(pack_batch_tiled_kernel, dim3(blk), dim3(256), 0, as_stream(s), b);
     else hipLaunchKernelGGL(pack_batch_kernel, dim3(blk), dim3(256), 0, as_stream(s), b);
   }
