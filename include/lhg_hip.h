@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define LHG_ABI_VERSION 7
+#define LHG_ABI_VERSION 8
 
 enum {
   LHG_OK = 0,
@@ -341,6 +341,11 @@ int lhg_maxpool2x2_forward(const float* x, int N, int H, int W, int C, int ldx, 
 /* gx = gy routed to the first maximal element of each window (PyTorch tie rule). */
 int lhg_maxpool2x2_backward(const float* x, int ldx, const float* gy, int ldgy, int N, int H, int W, int C,
                             float* gx, int ldgx, lhg_stream_t s);
+/* ABI 8: the same with `gadd` (N, H, W, C; row pitch ldgadd) added to gx on the way out — the gradient that reached x through its other
+ * consumer (the skip connection of the UNet, ref: neural_network_components.py:310-313): autograd would add the two full-size gradients
+ * in a pass of its own over a strided slice. */
+int lhg_maxpool2x2_backward_add(const float* x, int ldx, const float* gy, int ldgy, int N, int H, int W, int C,
+                                const float* gadd, int ldgadd, float* gx, int ldgx, lhg_stream_t s);
 /* g_out = g * act'(y) with the mask taken from the forward output y. */
 int lhg_act_backward(const float* g, int ldg, const float* y, int ldy, long long pixels, int C,
                      int act, float slope, float* out, int ldo, lhg_stream_t s);

@@ -615,7 +615,8 @@ __global__ __launch_bounds__(256) void maxpool_fwd_kernel(const T* __restrict__ 
 
 template <class T>
 __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ x, int ldx, const T* __restrict__ gy, int ldgy,
-                                                          int N, int H, int W, int C, T* __restrict__ gx, int ldgx) {
+                                                          int N, int H, int W, int C, T* __restrict__ gx, int ldgx,
+                                                          const T* __restrict__ gadd = nullptr, int ldga = 0) {  // gadd: added to gx (same pixels)
   const int Ho = H / 2, Wo = W / 2, C4 = C / 4;
   const size_t total = (size_t)N * Ho * Wo * C4;
   for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < total; i += (size_t)gridDim.x * blockDim.x) {
@@ -640,6 +641,10 @@ __global__ __launch_bounds__(256) void maxpool_bwd_kernel(const T* __restrict__ 
         if (v[k][e] > bv) { bv = v[k][e]; best = k; }  // first maximum wins (row-major window scan)
 #pragma unroll
       for (int k = 0; k < 4; ++k) o[k][e] = k == best ? g[e] : 0.f;
+    }
+    if (gadd) {  // the gradient that reached x through its other consumer (a skip connection): one pass instead of autograd's strided add
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] += ld4(gadd + offs[k] * ldga + c);
     }
 #pragma unroll
     for (int k = 0; k < 4; ++k) st4(gx + offs[k] * ldgx + c, o[k]);
@@ -856,13 +861,15 @@ static int maxpool_fwd_impl(const float* x, int N, int H, int W, int C, int ldx,
 }
 
 template <class T>
-static int maxpool_bwd_impl(const float* x, int ldx, const float* gy, int ldgy, int N, int H, int W, int C, float* gx, int ldgx, lhg_stream_t s) {
+static int maxpool_bwd_impl(const float* x, int ldx, const float* gy, int ldgy, int N, int H, int W, int C, float* gx, int ldgx, lhg_stream_t s,
+                            const float* gadd = nullptr, int ldga = 0) {
   LHG_NHWC_OK(x, C, ldx, "maxpool_bwd(x)");
   LHG_NHWC_OK(gy, C, ldgy, "maxpool_bwd(gy)");
   LHG_NHWC_OK(gx, C, ldgx, "maxpool_bwd(gx)");
+  if (gadd) LHG_NHWC_OK(gadd, C, ldga, "maxpool_bwd(gadd)");
   const size_t total = (size_t)N * (H / 2) * (W / 2) * (C / 4);
   hipLaunchKernelGGL((maxpool_bwd_kernel<T>), dim3(grid_for(total, 256, 8192)), dim3(256), 0, as_stream(s), as_act<T>(x), ldx, as_act<T>(gy), ldgy, N, H, W,
-                     C, as_act<T>(gx), ldgx);
+                     C, as_act<T>(gx), ldgx, as_act<T>(gadd), ldga);
   return check_launch("maxpool_bwd");
 }
 
@@ -984,6 +991,11 @@ int lhg_maxpool2x2_forward(const float* x, int N, int H, int W, int C, int ldx, 
 int lhg_maxpool2x2_backward(const float* x, int ldx, const float* gy, int ldgy, int N, int H, int W, int C, float* gx, int ldgx,
                             lhg_stream_t s) {
   return LHG_ACT_CALL(maxpool_bwd_impl, x, ldx, gy, ldgy, N, H, W, C, gx, ldgx, s);
+}
+int lhg_maxpool2x2_backward_add(const float* x, int ldx, const float* gy, int ldgy, int N, int H, int W, int C, const float* gadd, int ldgadd,
+                                float* gx, int ldgx, lhg_stream_t s) {
+  LHG_REQUIRE(gadd != nullptr, "maxpool2x2_backward_add: the tensor to add is missing");
+  return LHG_ACT_CALL(maxpool_bwd_impl, x, ldx, gy, ldgy, N, H, W, C, gx, ldgx, s, gadd, ldgadd);
 }
 int lhg_act_backward(const float* g, int ldg, const float* y, int ldy, long long pixels, int C, int act, float slope, float* out,
                      int ldo, lhg_stream_t s) {

@@ -1578,6 +1578,47 @@ class MaxPool2x2Fn(Function):
         return _inherit_absmax(gx, gy)  # gx holds gy's values and zeros
 
 
+class MaxPool2x2SkipFn(Function):
+    """(max_pool2d(x, 2), x): MaxPool2x2Fn for an input with a second consumer — an encoder block's output feeds the next block through the
+    pool AND the decoder through the skip concatenation (ref: neural_network_components.py:299-313).  The second output is x itself;
+    the gradient that arrives through it (a channel slice of the concatenation's gradient: strided) is added to the pool's gradient by
+    the pool's own backward kernel (lhg_maxpool2x2_backward_add) instead of by autograd's accumulation — a pass of its own over the two
+    full-size gradients, 2 - 10 x slower than a dense add because one of them is a strided slice (round 4: 0.4 ms per step)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.set_materialize_grads(False)  # an unused output must not cost a zero-filled gradient
+        px, N, H, W, Cc, ldx = nhwc(x)
+        y = new_nhwc(N, H // 2, W // 2, Cc, x.device)
+        call("lhg_maxpool2x2_forward", px, N, H, W, Cc, ldx, ptr(y), Cc, stream_ptr())
+        ctx.save_for_backward(x)
+        return _inherit_chanmax(_inherit_absmax(y, x), x), x
+
+    @staticmethod
+    def backward(ctx, gy, g_skip):
+        (x,) = ctx.saved_tensors
+        if gy is None:
+            return g_skip
+        px, N, H, W, Cc, ldx = nhwc(x)
+        pg, _, _, _, _, ldg = nhwc(gy)
+        gx = new_nhwc(N, H, W, Cc, x.device)
+        if g_skip is None:
+            call("lhg_maxpool2x2_backward", px, ldx, pg, ldg, N, H, W, Cc, ptr(gx), Cc, stream_ptr())
+            return _inherit_absmax(gx, gy)
+        g_skip = _as_nhwc_view(g_skip)
+        ps, _, _, _, _, lds = nhwc(g_skip)
+        call("lhg_maxpool2x2_backward_add", px, ldx, pg, ldg, N, H, W, Cc, ps, lds, ptr(gx), Cc, stream_ptr())
+        return gx
+
+
+def maxpool2x2_with_skip(x):
+    """(pool(x), x') with x' an alias of x for its other consumer — see MaxPool2x2SkipFn (LHG_FUSE_SKIP_GRAD=0: plain MaxPool2x2Fn)."""
+    if not FUSE_SKIP_GRAD or not (torch.is_grad_enabled() and x.requires_grad):
+        return MaxPool2x2Fn.apply(x), x
+    y, xs = MaxPool2x2SkipFn.apply(x)
+    return y, _inherit_chanmax(_inherit_absmax(xs, x), x, alias=True)
+
+
 # --------------------------------------------------------------------------- sigmoid head (planar output)
 class SigmoidHeadFn(TrackedFunction):
     """y (N, Co, H, W) = sigmoid(conv1x1(x) + bias), written planar by the GEMM epilogue.

@@ -36,7 +36,7 @@ class PackItem(C.Structure):
 
 
 # name -> argtypes (restype is int unless listed in _RESTYPE)
-ABI_VERSION = 7  # LHG_ABI_VERSION of include/lhg_hip.h this binding was written against
+ABI_VERSION = 8  # LHG_ABI_VERSION of include/lhg_hip.h this binding was written against
 
 _SIGNATURES = {
     "lhg_abi_version": [],
@@ -87,6 +87,7 @@ _SIGNATURES = {
     "lhg_bn_backward_backward_apply": [_p, _p, _p, _p, _ll, _i, _p, _p, _p, _f, _i, _f, _p, _p, _p, _p],
     "lhg_maxpool2x2_forward": [_p, _i, _i, _i, _i, _i, _p, _i, _p],
     "lhg_maxpool2x2_backward": [_p, _i, _p, _i, _i, _i, _i, _i, _p, _i, _p],
+    "lhg_maxpool2x2_backward_add": [_p, _i, _p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p],
     "lhg_act_backward": [_p, _i, _p, _i, _ll, _i, _i, _f, _p, _i, _p],
     "lhg_asm_propagate": [_p, _p, _i, _f, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _sz, _p, _p, _p],
     "lhg_asm_to_spectrum": [_p, _p, _i, _f, _i, _i, _i, _i, _i, _p, _p, _p, _sz, _p, _p, _p],

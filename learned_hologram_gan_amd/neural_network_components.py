@@ -191,15 +191,21 @@ class UNet(nn.Module):
         x = ops.ToNHWC.apply(X, 32)
         new = lambda h, w, c: ops.new_nhwc(N, h, w, c, dev)  # noqa: E731  (fp32, or bf16 in the bf16 storage mode)
         buf4, buf3, buf2, buf1 = new(H, W, 128), new(H // 2, W // 2, 256), new(H // 4, W // 4, 512), new(H // 8, W // 8, 1024)
-        pool = ops.MaxPool2x2Fn.apply
         # one max|.| slot per concatenation buffer: the encoder block and the transposed conv that fill its halves both measure into it
         sh4, sh3, sh2, sh1 = (ops.AmaxShare(dev) for _ in range(4))
 
+        # (an encoder output feeds the pool and the skip concatenation: maxpool2x2_with_skip hands back an alias for the skip, and the
+        #  pool's backward kernel adds the skip's gradient itself)
+        pool_skip = ops.maxpool2x2_with_skip
         e1 = self._block(self.encoder1[0]).forward_nhwc(x, OutSlot(buf4[..., :64], sh4))
-        e2 = self._block(self.encoder2[1]).forward_nhwc(pool(e1), OutSlot(buf3[..., :128], sh3))
-        e3 = self._block(self.encoder3[1]).forward_nhwc(pool(e2), OutSlot(buf2[..., :256], sh2))
-        e4 = self._block(self.encoder4[1]).forward_nhwc(pool(e3), OutSlot(buf1[..., :512], sh1))
-        b = self._block(self.bottleneck[1]).forward_nhwc(pool(e4))
+        p1, e1 = pool_skip(e1)
+        e2 = self._block(self.encoder2[1]).forward_nhwc(p1, OutSlot(buf3[..., :128], sh3))
+        p2, e2 = pool_skip(e2)
+        e3 = self._block(self.encoder3[1]).forward_nhwc(p2, OutSlot(buf2[..., :256], sh2))
+        p3, e3 = pool_skip(e3)
+        e4 = self._block(self.encoder4[1]).forward_nhwc(p3, OutSlot(buf1[..., :512], sh1))
+        p4, e4 = pool_skip(e4)
+        b = self._block(self.bottleneck[1]).forward_nhwc(p4)
         u = self._up(self.bottleneck[2], b, OutSlot(buf1[..., 512:], sh1))
         d = self._block(self.decoder1[0]).forward_nhwc(self._cat(e4, u, buf1, sh1))
         u = self._up(self.decoder1[1], d, OutSlot(buf2[..., 256:], sh2))

@@ -507,6 +507,28 @@ def test_maxpool(ops):
     assert torch.equal(to_nchw(xg.grad), xr.grad)
 
 
+def test_maxpool_with_skip_adds_the_second_consumers_gradient_in_its_backward_kernel(ops):
+    """maxpool2x2_with_skip (lhg_maxpool2x2_backward_add, ABI 8): (pool(x), alias of x); the gradient through the alias — here a STRIDED
+    channel slice, as the skip concatenation's gradient is — is added by the pool's backward kernel: equal to autograd's own sum bit
+    for bit (one fp32 add per element either way); each output alone works too."""
+    x = rnd(2, 64, 12, 16, seed=1)
+    proj, skip = rnd(2, 64, 6, 8, seed=2), rnd(2, 64, 12, 16, seed=3)
+    xr = x.clone().requires_grad_(True)
+    (F.max_pool2d(xr, 2, 2) * proj).sum().backward()
+    wide = torch.zeros(2, 12, 16, 128, device=DEV)
+    wide[..., 32:96] = to_nhwc(skip)
+    for use_pool, use_skip in ((True, True), (True, False), (False, True)):
+        xg = to_nhwc(x).requires_grad_(True)
+        yg, xs = ops.maxpool2x2_with_skip(xg)
+        assert torch.equal(to_nchw(yg), F.max_pool2d(x, 2, 2)) and xs.data_ptr() == xg.data_ptr()
+        loss = (yg * to_nhwc(proj)).sum() if use_pool else 0
+        if use_skip:
+            loss = loss + (xs * wide[..., 32:96]).sum()  # d loss / d xs is the strided slice itself
+        loss.backward()
+        want = (xr.grad if use_pool else 0) + (skip if use_skip else 0)
+        assert torch.equal(to_nchw(xg.grad), want), (use_pool, use_skip)
+
+
 def test_layout_roundtrip_and_grad(ops):
     x = rnd(2, 3, 8, 12, seed=1)
     xg = x.to(DEV).requires_grad_(True)
