@@ -839,7 +839,10 @@ static int launch_gg(GGParams& p, hipStream_t st) {
   const Geom& g = p.g;
   if (g.M <= 0) return LHG_OK;
   p.xcd = xcd_order();
+  // LHG_GG_PRIO: 0 / 1 / 2 only (s_setprio placement: same bits).  Rounds 2 - 4 ran timing ablations through values >= 10 that produced
+  // WRONG results on purpose; the shipped kernels no longer contain them and such a value is refused loudly, here and in native.load().
   static const int prio = [] { const char* e = getenv("LHG_GG_PRIO"); return e ? atoi(e) : 1; }();
+  LHG_REQUIRE(prio >= 0 && prio <= 2, "LHG_GG_PRIO=%d: only 0, 1, 2 exist (the timing ablations of earlier rounds gave wrong results and were removed)", prio);
   p.prio = prio;
   if (g_precision == LHG_PRECISION_BF16) return launch_gg_bf16(p, st);
   LHG_REQUIRE(!act_is_bf16(), "bf16 activation storage needs the bf16 conv precision (lhg_set_conv_precision(LHG_PRECISION_BF16))");

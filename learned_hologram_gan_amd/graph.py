@@ -76,9 +76,9 @@ class GraphedTrainStep:
             self._stage(None, None)
             trainer._train_step(self.rgbd, self.tamp, self.tphs, self.idx, self.alphas)
         torch.cuda.synchronize()
-        for opt, calls in opts:
-            opt.device_consts = torch.zeros((calls, 4), dtype=torch.float32, device=dev)
-            opt._consts_cursor = 0
+        # this graph's own Adam constants (several graphs — one per batch shape — may share the optimisers): installed on the optimisers
+        # for the capture only, so that every eager step before, between and after replays takes its constants from the host
+        self._consts = [torch.zeros((calls, 4), dtype=torch.float32, device=dev) for _, calls in opts]
         self._stage(None, None)
         self._stage_consts()
         torch.cuda.synchronize()
@@ -86,8 +86,14 @@ class GraphedTrainStep:
 
         hip_ops.begin_graph_capture()
         self.graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(self.graph):
-            self.out = trainer._train_step(self.rgbd, self.tamp, self.tphs, self.idx, self.alphas)
+        try:
+            for (opt, _), consts in zip(opts, self._consts):
+                opt.device_consts, opt._consts_cursor = consts, 0
+            with torch.cuda.graph(self.graph):
+                self.out = trainer._train_step(self.rgbd, self.tamp, self.tphs, self.idx, self.alphas)
+        finally:
+            for opt, _ in opts:
+                opt.device_consts = None
         self._restore(saved)
 
     def _snapshot(self):
@@ -132,9 +138,9 @@ class GraphedTrainStep:
             self.alphas[k].copy_(torch.as_tensor(a).reshape(B, 1, 1, 1).float().cpu().pin_memory(), non_blocking=True)
 
     def _stage_consts(self):
-        for opt, calls in self._opts:
+        for (opt, calls), consts in zip(self._opts, self._consts):
             scale = 1.0  # single process: the gradient buffer holds this rank's own gradient
-            opt.device_consts.copy_(opt.consts_rows(opt.step_count + 1, calls, scale).pin_memory(), non_blocking=True)
+            consts.copy_(opt.consts_rows(opt.step_count + 1, calls, scale).pin_memory(), non_blocking=True)
 
     def _replay(self):
         self.graph.replay()

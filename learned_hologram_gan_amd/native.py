@@ -154,6 +154,11 @@ def load():
             raise NativeLibraryError(f"{LIB_PATH} does not export {name}") from e
         fn.argtypes = argtypes
         fn.restype = _RESTYPE.get(name, C.c_int)
+    prio = os.environ.get("LHG_GG_PRIO")
+    if prio is not None and prio.strip() not in ("0", "1", "2"):
+        # values >= 10 used to select timing ablations of the gather-GEMM that gave WRONG results on purpose (rounds 2 - 4); they are gone
+        # from the kernels, and a stale environment must not pass silently: the C side refuses the launch as well (conv_engine.hip)
+        raise NativeLibraryError(f"LHG_GG_PRIO={prio!r}: only 0, 1, 2 exist (s_setprio placement; the wrong-result timing ablations were removed)")
     got = lib.lhg_abi_version()
     if got != ABI_VERSION:
         raise NativeLibraryError(f"ABI version mismatch: library {got}, binding {ABI_VERSION}")

@@ -81,7 +81,9 @@ class FusedAdam:
         if self.flat.grad.is_cuda:
             hip_ops.join_side_stream(self.flat.grad.device)  # weight gradients accumulated on the side stream
         consts = None
-        if self.device_consts is not None:
+        # device constants are for launches being CAPTURED (their replays must follow the step count): an eager step — warm-up of a
+        # capture, a step after ``use_graph`` was switched off, a ragged last batch — takes step_count / lr / grad_scale from the host
+        if self.device_consts is not None and self.flat.grad.is_cuda and torch.cuda.is_current_stream_capturing():
             consts = self.device_consts[self._consts_cursor % self.device_consts.shape[0]]
             self._consts_cursor += 1
         hip_ops.adam_step_(self.flat.data, self.flat.grad, self.exp_avg, self.exp_avg_sq, self.lr, self.betas[0], self.betas[1],

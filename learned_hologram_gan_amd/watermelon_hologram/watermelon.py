@@ -211,11 +211,16 @@ class watermelon:
         with hip_ops.deferred_gc():  # no collector pauses while the host thread is feeding the GPU
             if self.use_graph and RGBD.is_cuda and self._sync_G.world == 1:
                 # the whole batch as ONE hipGraph replay (graph.GraphedTrainStep): ~900 launches per step leave the host
-                if self._graphed is None or self._graphed.rgbd.shape != RGBD.shape:
+                # one graph per batch shape (a ragged last batch alternates with the full one every epoch: no re-capture).  The returned
+                # tensors are the graph's STATIC outputs — the next replay of the same shape overwrites them; clone what must outlive a step
+                key = tuple(RGBD.shape)
+                if self._graphed is None:
+                    self._graphed = {}
+                if key not in self._graphed:
                     from ..graph import GraphedTrainStep
 
-                    self._graphed = GraphedTrainStep(self, RGBD, target_amp, target_phs)
-                return self._graphed(RGBD, target_amp, target_phs, plane_indices, gp_alphas)
+                    self._graphed[key] = GraphedTrainStep(self, RGBD, target_amp, target_phs)
+                return self._graphed[key](RGBD, target_amp, target_phs, plane_indices, gp_alphas)
             return self._train_step(RGBD, target_amp, target_phs, plane_indices, gp_alphas)
 
     def _train_step(self, RGBD, target_amp, target_phs, plane_indices, gp_alphas):

@@ -62,6 +62,37 @@ def test_graphed_train_step_equals_the_eager_step_bit_for_bit(ratio):
         assert torch.equal(es[key], gs[key]), (key, (es[key].double() - gs[key].double()).abs().max().item())
 
 
+def test_eager_steps_after_graph_replays_take_their_adam_constants_from_the_host():
+    """once a graph had been built, FusedAdam.step() kept reading the device constants of the last staged replay in every
+    later EAGER step (bias corrections, learning rate and gradient scale of the wrong step).  Two graphed batches, then ``use_graph``
+    off and a learning-rate change, then two eager batches must equal the all-eager run bit for bit; and a second batch SHAPE gets a
+    graph of its own without disturbing the first (its replays still follow the step count)."""
+    B = 2
+    batches = [seeded.smooth_batch(B, 64, 64, seed=90 + k) for k in range(5)]
+    small = seeded.smooth_batch(1, 64, 64, seed=99)
+    idx = torch.tensor([4, 1])
+    alpha = [torch.tensor([0.25, 0.6]).view(B, 1, 1, 1).to(DEV)]
+    finals = []
+    for graph in (False, True):
+        W = _trainer(1, graph)
+        for k, (rgbd, tamp, tphs) in enumerate(batches):
+            if k == 2:  # ragged batch in between: its own graph (or an eager step), then back to the first shape
+                W.train_step(*(t.to(DEV) for t in small), torch.tensor([2]), [torch.tensor([0.5]).view(1, 1, 1, 1).to(DEV)])
+            if k == 3:
+                W.use_graph = False
+                W._opt_G.lr = W._opt_D.lr = 2.5e-4  # what ReduceOnPlateau does between epochs
+            W.train_step(rgbd.to(DEV), tamp.to(DEV), tphs.to(DEV), idx, alpha)
+        torch.cuda.synchronize()
+        if graph:
+            assert W._graphed is not None and len(W._graphed) == 2, "one graph per batch shape"
+            assert W._opt_G.device_consts is None and W._opt_D.device_consts is None
+        finals.append(_state(W))
+    (es, ec), (gs, gc) = finals
+    assert ec == gc == (6, 6), (ec, gc)
+    for key in es:
+        assert torch.equal(es[key], gs[key]), (key, (es[key].double() - gs[key].double()).abs().max().item())
+
+
 def test_graphed_step_draws_like_the_eager_step():
     """Without explicit indices / alphas both paths draw from the CPU generator in the same order (randperm, then one rand per critic
     update): same seed, same batches -> same bits; and building the graph consumes no draws."""

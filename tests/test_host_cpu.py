@@ -105,6 +105,37 @@ def test_missing_library_fails_loudly(monkeypatch, tmp_path):
         native.load()
 
 
+def test_wrong_result_switches_of_the_gather_gemm_are_gone_and_refused(monkeypatch):
+    """LHG_GG_PRIO >= 10 used to select timing ablations inside the shipped gather-GEMM kernels (no stores, no
+    barriers, no epilogue: wrong results on purpose).  The kernels no longer contain them; a stale value makes native.load() fail
+    loudly (the C side refuses the launch as well), and the kernel sources carry no run-time ablation branch."""
+    import os
+
+    from learned_hologram_gan_amd import native
+
+    for bad in ("22", "10", "25", "-1", "x"):
+        monkeypatch.setattr(native, "_lib", None)
+        monkeypatch.setenv("LHG_GG_PRIO", bad)
+        with pytest.raises(native.NativeLibraryError, match="LHG_GG_PRIO"):
+            native.load()
+    for ok in ("0", "1", "2"):
+        monkeypatch.setattr(native, "_lib", None)
+        monkeypatch.setenv("LHG_GG_PRIO", ok)
+        native.load()
+    monkeypatch.delenv("LHG_GG_PRIO")
+    monkeypatch.setattr(native, "_lib", None)
+    native.load()
+    csrc = os.path.join(os.path.dirname(native.__file__), "csrc")
+    for name in ("gg3s_kernel.inc", "gg4s_kernel.inc", "gg_epilogue.inc"):
+        src = open(os.path.join(csrc, name)).read()
+        code = "\n".join(ln.split("//")[0] for ln in src.splitlines())  # comments may tell the history
+        assert "abl !=" not in code and "abl ==" not in code and "int abl" not in code, name
+        for n in range(10, 26):
+            assert f"prio == {n}" not in src and f"prio != {n}" not in src and f"prio >= {n}" not in src, (name, n)
+    engine = open(os.path.join(csrc, "conv_engine.hip")).read()
+    assert "prio >= 0 && prio <= 2" in engine  # the launch itself refuses anything else
+
+
 def test_constants_follow_reference_op_order(golden):
     from learned_hologram_gan_amd.angular_spectrum_method import (
         bandLimitedAngularSpectrumMethod_for_multiple_distances as Mu,
