@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define LHG_ABI_VERSION 8
+#define LHG_ABI_VERSION 9
 
 enum {
   LHG_OK = 0,
@@ -334,6 +334,47 @@ int lhg_bn_backward_backward_sums(const float* ggx, const float* gy, const float
 int lhg_bn_backward_backward_apply(const float* ggx, const float* gy, const float* x, const float* y, long long pixels, int C,
                                    const float* stats, const float* gamma, const float* sums, float inv_count, int act, float slope,
                                    float* ggy, float* gx2, float* ggamma2, lhg_stream_t s);
+
+/* ------------------------------------------------------------------ fused calls (ABI 9)
+ * Every reduction above is two launches: per-workgroup partial rows, then a small kernel that folds the rows.  The calls below finish
+ * the rows INSIDE the launch that writes them (the last workgroup of a group of 32 rows folds its group, the last group folds the
+ * groups; fixed summation order, double accumulation: bit-repeatable whatever the arrival order) and put a whole BatchNorm forward /
+ * backward behind one entry point: 2 launches where lhg_bn_stats + lhg_bn_apply_chanmax + lhg_channel_absmax_finish were 4, 2 where
+ * lhg_bn_backward_chanmax + two finishes were 5.  A train step at 384 x 384, batch 4 makes ~200 launches fewer.
+ * Scratch: `ws` = LHG_FUSED_WS_FLOATS floats (16-byte aligned, contents irrelevant) and `tickets` = LHG_FUSED_TICKETS unsigned that are
+ * ZERO before the first call and that every call leaves at zero again.  The caller keeps ONE pair per stream: two calls may share a pair
+ * only if their launches cannot overlap (same stream).  C <= 4096.
+ * ref: F.batch_norm(training=True) via nn.LazyBatchNorm2d neural_network_components.py:23-32, nn.BatchNorm2d discriminator.py:34-40,
+ * the double backward watermelon.py:466-473. */
+#define LHG_FUSED_WS_FLOATS 1114112
+#define LHG_FUSED_TICKETS 4160
+long long lhg_fused_workspace_floats(void);
+int lhg_fused_ticket_count(void);
+/* lhg_bn_stats + lhg_bn_apply(_chanmax) in one call: batch statistics of x -> `stats` (2*C floats: mean, invstd) and the running
+ * statistics (may be NULL), then y = act((x - mean)*invstd*gamma + beta + res).  y_absmax as for lhg_bn_apply.  y_chanmax (may be
+ * NULL; fp32 storage) with chanmax_finish != 0: C floats that receive the FINISHED per-channel max|y| (the apply launch folds its
+ * own partial rows: measured ~11 us longer per launch, on the stream the step waits for); with chanmax_finish == 0 it is the
+ * partial-row buffer of lhg_bn_apply_chanmax (lhg_chanmax_partial_rows x C floats), finished by lhg_channel_absmax_finish on
+ * whatever stream asks — the op layer's choice: that launch runs on the weight-gradient stream, beside the main chain. */
+int lhg_bn_forward_train(const float* x, int ldx, long long pixels, int C, const float* gamma, const float* beta,
+                         float* running_mean, float* running_var, float momentum, float eps,
+                         const float* res, int ldres, int act, float slope, float* y, int ldy,
+                         float* stats, float* y_absmax, float* y_chanmax, int chanmax_finish,
+                         float* ws, unsigned* tickets, lhg_stream_t s);
+/* lhg_bn_backward(_chanmax) in one call and two launches; gx_chanmax / gres_chanmax (may be NULL; fp32 storage): finished maxima
+ * (C floats each) or partial-row buffers, by chanmax_finish as above.  Everything else as lhg_bn_backward_chanmax. */
+int lhg_bn_backward_fused(const float* gy, int ldgy, const float* x, int ldx, const float* y, int ldy, long long pixels, int C,
+                          const float* stats, const float* gamma, const float* beta, int act, float slope,
+                          float* gx, int ldgx, float* gres, int ldgres, float* ggamma, float* gbeta, int accumulate,
+                          float* gx_absmax, float* gres_absmax, float* gx_chanmax, float* gres_chanmax, int chanmax_finish,
+                          float* ws, unsigned* tickets, lhg_stream_t s);
+/* lhg_bn_backward_backward in two launches. */
+int lhg_bn_backward_backward_fused(const float* ggx, const float* gy, const float* x, const float* y, long long pixels, int C,
+                                   const float* stats, const float* gamma, int act, float slope,
+                                   float* ggy, float* gx2, float* ggamma2, float* ws, unsigned* tickets, lhg_stream_t s);
+/* lhg_channel_sum / lhg_channel_absmax in one launch each. */
+int lhg_channel_sum_fused(const float* x, long long pixels, int C, int ld, float* out, int accumulate, float* ws, unsigned* tickets, lhg_stream_t s);
+int lhg_channel_absmax_fused(const float* x, long long pixels, int C, int ld, float* out, float* ws, unsigned* tickets, lhg_stream_t s);
 
 /* ------------------------------------------------------------------ pointwise / pooling */
 /* 2x2 stride-2 max pool, NHWC.  ref: neural_network_components.py:252-268. */

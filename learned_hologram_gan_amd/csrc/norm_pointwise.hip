@@ -39,6 +39,10 @@ __device__ __forceinline__ void pixel_loop(long long q0, long long q1, long long
   for (; q < q1; q += step) use(q, load(q));
 }
 
+// agent-scope relaxed accesses (sc1) for rows that cross workgroups: see draw_last below
+template <class V> __device__ __forceinline__ void st_agent(V* p, V v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+template <class V> __device__ __forceinline__ V ld_agent(const V* p) { return __hip_atomic_load(const_cast<V*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+
 // NSUM partial sums per channel.  pre(cb) -> per-column constants, load(q, cb) -> loaded values of one pixel,
 // use(values, constants, acc) adds the NSUM float4 contributions.
 template <int NSUM, class P, class L, class F>
@@ -70,10 +74,162 @@ __device__ __forceinline__ void column_reduce(long long pixels, int C, int lanes
         for (int r = 0; r < rows; ++r)
 #pragma unroll
           for (int e = 0; e < 4; ++e) s[e] += red[k][(r * lanes_c + tx) * 4 + e];
-        *reinterpret_cast<f32x4*>(partial + ((size_t)blockIdx.x * NSUM + k) * C + cb) = s;
+        float* row = partial + ((size_t)blockIdx.x * NSUM + k) * C + cb;  // (agent-scope stores: another workgroup may fold this row, column_finish)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) st_agent(row + e, s[e]);
       }
     }
     __syncthreads();
+  }
+}
+
+// ------------------------------------------------------------------ in-launch finish of the two-stage reductions (round 5)
+// A column reduction used to be two launches: per-workgroup partial rows, then a small kernel that sums the rows (reduce_partials,
+// bn_stats_reduce_final, channel_absmax_reduce: 290 launches of 8 - 15 us per train step, each also a host dispatch).  With `Fin` the
+// launch that writes the rows finishes them itself: partial rows are grouped by FIN_GROUP; the LAST workgroup of a group to publish its
+// row (release, ticket fetch_add, acquire — the hand-off of wg6_kernel.inc: nobody waits for anybody, any dispatch order) folds the
+// group's rows into one first-level row, and the last GROUP to do so folds the first-level rows and writes the result.  Rows and groups
+// are summed in index order in double whoever arrives last: the result does not depend on the arrival order (bit-repeatable).  Two levels
+// because one workgroup walking 2048 rows is latency-bound (~100 us); 32 rows, then <= 64 groups, are two short hops.  The tickets
+// are zero before the launch and the last arrivers put the zero back (one persistent buffer per stream: hip_ops._fused_scratch).
+constexpr int FIN_GROUP = 32, FIN_MAXG = 64;  // rows per group; groups per channel block (2048 partial rows at most)
+struct Fin {
+  unsigned* tickets;  // [gridDim.y][1 + FIN_MAXG]; nullptr: no in-launch finish (the rows are all this launch leaves)
+  void* level1;       // first-level rows: doubles [groups][NSUM][C] for sums, unsigned [NB][groups][C] for maxima
+};
+
+// Rows that cross workgroups (partial rows, first-level rows) are written and read with AGENT-SCOPE relaxed atomic accesses (sc1: they
+// write through / bypass the per-XCD L2 and the per-CU vector cache) instead of plain accesses bracketed by release / acquire fences: on
+// this chip an agent-scope release is `buffer_wbl2` — a write-back of the XCD's whole L2 — and an acquire `buffer_inv`, executed here by
+// every one of ~2000 workgroups per launch (first version of this code: the train step went from 32 to 45 ms).  The rows are a few KB.
+
+// true in every thread of the workgroup that draws ticket `total - 1`.  Every thread's earlier st_agent stores have completed (vmcnt)
+// before the ticket is drawn, so whoever draws a later ticket reads them with ld_agent.  Called by all 256 threads.
+__device__ __forceinline__ bool draw_last(unsigned* ticket, unsigned total) {
+  __shared__ unsigned last_flag;
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const unsigned old = __hip_atomic_fetch_add(ticket, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const bool last = old == total - 1u;
+    if (last) __hip_atomic_store(ticket, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // the next launch finds the ticket at zero again
+    last_flag = last ? 1u : 0u;
+  }
+  __syncthreads();
+  return last_flag != 0u;
+}
+
+// Sums: partial[row][k][c] floats (row = blockIdx.x of the writer) -> final(c, double sums[NSUM]) called by one thread per channel of
+// this workgroup's channel block.  Called by all threads after the workgroup's own row has been stored.
+template <int NSUM, class F>
+__device__ __forceinline__ void column_finish(const float* __restrict__ partial, int C, int lanes_c, const Fin& fin, F final_fn) {
+  __shared__ double fsh[NSUM * 256];
+  const int nblk = gridDim.x;
+  const int ch = lanes_c * 4, nsl = 256 / ch;
+  const int cl = threadIdx.x % ch, slice = threadIdx.x / ch;
+  const int c = blockIdx.y * ch + cl;
+  const bool live = c < C;
+  const int g = blockIdx.x / FIN_GROUP, ngroups = (nblk + FIN_GROUP - 1) / FIN_GROUP;
+  const int r0 = g * FIN_GROUP, nr = min(FIN_GROUP, nblk - r0);
+  unsigned* tk = fin.tickets + (size_t)blockIdx.y * (1 + FIN_MAXG);
+  double* level1 = static_cast<double*>(fin.level1);
+  if (!draw_last(tk + 1 + g, (unsigned)nr)) return;
+  double acc[NSUM];
+#pragma unroll
+  for (int k = 0; k < NSUM; ++k) acc[k] = 0.0;
+  if (live) {
+#pragma unroll 4
+    for (int r = slice; r < nr; r += nsl)
+#pragma unroll
+      for (int k = 0; k < NSUM; ++k) acc[k] += (double)ld_agent(partial + ((size_t)(r0 + r) * NSUM + k) * C + c);
+  }
+#pragma unroll
+  for (int k = 0; k < NSUM; ++k) fsh[k * 256 + slice * ch + cl] = acc[k];
+  __syncthreads();
+  if (slice == 0 && live) {
+#pragma unroll
+    for (int k = 0; k < NSUM; ++k) {
+      double t = 0.0;
+      for (int q = 0; q < nsl; ++q) t += fsh[k * 256 + q * ch + cl];
+      st_agent(level1 + ((size_t)g * NSUM + k) * C + c, t);
+    }
+  }
+  if (!draw_last(tk, (unsigned)ngroups)) return;
+#pragma unroll
+  for (int k = 0; k < NSUM; ++k) acc[k] = 0.0;
+  if (live) {
+#pragma unroll 4
+    for (int q = slice; q < ngroups; q += nsl)
+#pragma unroll
+      for (int k = 0; k < NSUM; ++k) acc[k] += ld_agent(level1 + ((size_t)q * NSUM + k) * C + c);
+  }
+#pragma unroll
+  for (int k = 0; k < NSUM; ++k) fsh[k * 256 + slice * ch + cl] = acc[k];
+  __syncthreads();
+  if (slice == 0 && live) {
+    double sums[NSUM];
+#pragma unroll
+    for (int k = 0; k < NSUM; ++k) {
+      double t = 0.0;
+      for (int q = 0; q < nsl; ++q) t += fsh[k * 256 + q * ch + cl];
+      sums[k] = t;
+    }
+    final_fn(c, sums);
+  }
+}
+
+// Maxima: NB partial buffers [row][c] of magnitude bits -> out[b][c].  Buffers that are nullptr are skipped (uniformly).
+template <int NB>
+__device__ __forceinline__ void channel_max_finish(unsigned* const (&partial)[NB], unsigned* const (&out)[NB], int C, int lanes_c, const Fin& fin) {
+  __shared__ unsigned msh[NB * 256];
+  const int nblk = gridDim.x;
+  const int ch = lanes_c * 4, nsl = 256 / ch;
+  const int cl = threadIdx.x % ch, slice = threadIdx.x / ch;
+  const int c = blockIdx.y * ch + cl;
+  const bool live = c < C;
+  const int g = blockIdx.x / FIN_GROUP, ngroups = (nblk + FIN_GROUP - 1) / FIN_GROUP;
+  const int r0 = g * FIN_GROUP, nr = min(FIN_GROUP, nblk - r0);
+  unsigned* tk = fin.tickets + (size_t)blockIdx.y * (1 + FIN_MAXG);
+  unsigned* level1 = static_cast<unsigned*>(fin.level1);  // [NB][groups][C]
+  if (!draw_last(tk + 1 + g, (unsigned)nr)) return;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    unsigned m = 0u;
+    if (live && partial[b]) {
+#pragma unroll 8
+      for (int r = slice; r < nr; r += nsl) m = max(m, ld_agent(partial[b] + (size_t)(r0 + r) * C + c));
+    }
+    msh[b * 256 + slice * ch + cl] = m;
+  }
+  __syncthreads();
+  if (slice == 0 && live) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (!partial[b]) continue;
+      unsigned m = 0u;
+      for (int q = 0; q < nsl; ++q) m = max(m, msh[b * 256 + q * ch + cl]);
+      st_agent(level1 + ((size_t)b * ngroups + g) * C + c, m);
+    }
+  }
+  if (!draw_last(tk, (unsigned)ngroups)) return;
+#pragma unroll
+  for (int b = 0; b < NB; ++b) {
+    unsigned m = 0u;
+    if (live && partial[b]) {
+#pragma unroll 8
+      for (int q = slice; q < ngroups; q += nsl) m = max(m, ld_agent(level1 + ((size_t)b * ngroups + q) * C + c));
+    }
+    msh[b * 256 + slice * ch + cl] = m;
+  }
+  __syncthreads();
+  if (slice == 0 && live) {
+#pragma unroll
+    for (int b = 0; b < NB; ++b) {
+      if (!partial[b]) continue;
+      unsigned m = 0u;
+      for (int q = 0; q < nsl; ++q) m = max(m, msh[b * 256 + q * ch + cl]);
+      out[b][c] = m;
+    }
   }
 }
 
@@ -127,9 +283,29 @@ __device__ __forceinline__ void amax_commit(unsigned m, float* out, unsigned see
 }
 
 // ------------------------------------------------------------------ BN statistics
+// mean / invstd / running statistics of one channel from its two shifted sums (the arithmetic of bn_stats_reduce_final)
+template <class T>
+__device__ __forceinline__ void bn_stats_final(int c, double s0, double s1, const T* __restrict__ x, long long pixels, int C, float* __restrict__ stats,
+                                               float* running_mean, float* running_var, float momentum, float eps) {
+  const double n = (double)pixels;
+  const double dm = s0 / n;
+  const double mean = (double)ld1(x + c) + dm;
+  double var = s1 / n - dm * dm;
+  if (var < 0) var = 0;
+  stats[c] = (float)mean;
+  stats[C + c] = (float)(1.0 / sqrt(var + (double)eps));
+  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
+  if (running_var) {
+    const double unbiased = n > 1 ? var * n / (n - 1) : var;
+    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+  }
+}
+
 template <class T>
 __global__ __launch_bounds__(256) void bn_stats_partial(const T* __restrict__ x, long long pixels, int C, int ld,
-                                                        int lanes_c, int rows, float* __restrict__ partial) {
+                                                        int lanes_c, int rows, float* __restrict__ partial, Fin fin = Fin{nullptr, nullptr},
+                                                        float* __restrict__ stats = nullptr, float* running_mean = nullptr,
+                                                        float* running_var = nullptr, float momentum = 0.f, float eps = 0.f) {
   // shifted sums around the first pixel of each channel (stable one-pass variance)
   column_reduce<2>(
       pixels, C, lanes_c, rows, partial, [&](int cb) { return ld4(x + cb); },
@@ -139,6 +315,10 @@ __global__ __launch_bounds__(256) void bn_stats_partial(const T* __restrict__ x,
         acc[0] += d;
         acc[1] += d * d;
       });
+  if (fin.tickets)  // (uniform) the launch finishes its own rows: mean / invstd / running statistics without a second launch
+    column_finish<2>(partial, C, lanes_c, fin, [&](int c, const double* sm) {
+      bn_stats_final(c, sm[0], sm[1], x, pixels, C, stats, running_mean, running_var, momentum, eps);
+    });
 }
 
 // v = x * a + b with ONE rounding per element (fma), a = invstd * gamma, b = beta - mean * a: the pre-activation of bn_apply.  The backward
@@ -163,7 +343,8 @@ __device__ __forceinline__ void channel_max_commit(u32x4* red, const u32x4& mine
 #pragma unroll
       for (int e = 0; e < 4; ++e) m[e] = max(m[e], o[e]);
     }
-    *reinterpret_cast<u32x4*>(dst) = m;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) st_agent(dst + e, m[e]);  // (agent scope: channel_max_finish may fold this row from another workgroup)
   }
   __syncthreads();
 }
@@ -177,7 +358,8 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
                                                        const float* __restrict__ stats, const float* __restrict__ gamma,
                                                        const float* __restrict__ beta, const T* __restrict__ res, int ldres,
                                                        int act, float slope, T* __restrict__ y, int ldy, int lanes_c, int rows,
-                                                       float* __restrict__ y_amax, unsigned* __restrict__ cmax_partial) {
+                                                       float* __restrict__ y_amax, unsigned* __restrict__ cmax_partial,
+                                                       Fin fin = Fin{nullptr, nullptr}, unsigned* __restrict__ cmax_out = nullptr) {
   __shared__ u32x4 cred[256];
   const int tx = threadIdx.x % lanes_c, ty = threadIdx.x / lanes_c;
   unsigned am = 0;
@@ -212,6 +394,11 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* __restrict__ x, 
     if (cmax_partial) channel_max_commit(cred, __builtin_bit_cast(u32x4, cm), tx, ty, lanes_c, rows, live, cmax_partial + (size_t)blockIdx.x * C + cb);
   }
   if (y_amax) amax_commit(am, y_amax, seen);
+  if (fin.tickets && cmax_partial) {  // (uniform) per-channel maxima finished here: cmax_out[c], no channel_absmax_reduce launch later
+    unsigned* const pp[1] = {cmax_partial};
+    unsigned* const oo[1] = {cmax_out};
+    channel_max_finish<1>(pp, oo, C, lanes_c, fin);
+  }
 }
 
 // ------------------------------------------------------------------ BN backward
@@ -221,7 +408,8 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const T* __restrict__ gy, 
                                                       const T* __restrict__ y, int ldy, long long pixels, int C,
                                                       const float* __restrict__ stats, const float* __restrict__ gamma,
                                                       const float* __restrict__ beta, int act, float slope, int lanes_c, int rows,
-                                                      float* __restrict__ partial) {
+                                                      float* __restrict__ partial, Fin fin = Fin{nullptr, nullptr},
+                                                      float* __restrict__ sums = nullptr) {
   const bool recompute = y == nullptr && act != LHG_ACT_NONE;
   column_reduce<2>(
       pixels, C, lanes_c, rows, partial,
@@ -249,6 +437,11 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const T* __restrict__ gy, 
         acc[0] += g;
         acc[1] += g * xh;
       });
+  if (fin.tickets)  // (uniform) sums[k][c] for bn_bwd_apply without a reduce launch in between
+    column_finish<2>(partial, C, lanes_c, fin, [&](int c, const double* sm) {
+      sums[c] = (float)sm[0];
+      sums[C + c] = (float)sm[1];
+    });
 }
 
 // sums[k][c] = sum_b partial[b][k][c] in double.  grid (ceil(C/32), NSUM), block 32 channels x 32 slices; four independent
@@ -344,7 +537,9 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const T* __restrict__ gy, in
                                                     int rows, float* __restrict__ gx_amax, const float* __restrict__ beta, float invn,
                                                     unsigned* __restrict__ cmax_partial,        // as bn_apply_kernel's, of gx
                                                     unsigned* __restrict__ cmax_partial_res,    // the same of gres (null without gres)
-                                                    float* __restrict__ gres_amax = nullptr) {  // max|gres| (null: not measured)
+                                                    float* __restrict__ gres_amax = nullptr,    // max|gres| (null: not measured)
+                                                    Fin fin = Fin{nullptr, nullptr},             // in-launch finish of the two partial buffers ->
+                                                    unsigned* __restrict__ cmax_out = nullptr, unsigned* __restrict__ cmax_out_res = nullptr) {
   __shared__ u32x4 cred[256];
   const int tx = threadIdx.x % lanes_c, ty = threadIdx.x / lanes_c;
   unsigned am = 0, amr = 0;
@@ -403,6 +598,11 @@ __global__ __launch_bounds__(256) void bn_bwd_apply(const T* __restrict__ gy, in
     __syncthreads();  // amax_commit's four-word LDS scratch is reused
     amax_commit(amr, gres_amax, seen_r);
   }
+  if (fin.tickets && cmax_partial) {  // (uniform)
+    unsigned* const pp[2] = {cmax_partial, cmax_partial_res};
+    unsigned* const oo[2] = {cmax_out, cmax_out_res};
+    channel_max_finish<2>(pp, oo, C, lanes_c, fin);
+  }
 }
 
 // ------------------------------------------------------------------ BN double backward (WGAN-GP)
@@ -414,7 +614,8 @@ template <class T>
 __global__ __launch_bounds__(256) void bn_bwd2_partial(const T* __restrict__ ggx, const T* __restrict__ gy,
                                                        const T* __restrict__ x, const T* __restrict__ y, long long pixels, int C,
                                                        const float* __restrict__ stats, int act, float slope, int lanes_c, int rows,
-                                                       float* __restrict__ partial) {
+                                                       float* __restrict__ partial, Fin fin = Fin{nullptr, nullptr},
+                                                       float* __restrict__ sums = nullptr) {
   column_reduce<5>(
       pixels, C, lanes_c, rows, partial, [&](int cb) { return ld4(stats + cb); },
       [&](long long qi, int cb) {
@@ -436,6 +637,11 @@ __global__ __launch_bounds__(256) void bn_bwd2_partial(const T* __restrict__ ggx
         acc[3] += q * xc;
         acc[4] += g * q;
       });
+  if (fin.tickets)
+    column_finish<5>(partial, C, lanes_c, fin, [&](int c, const double* sm) {
+#pragma unroll
+      for (int k = 0; k < 5; ++k) sums[(size_t)k * C + c] = (float)sm[k];
+    });
 }
 
 template <class T>
@@ -482,17 +688,21 @@ __global__ __launch_bounds__(256) void bn_bwd2_apply(const T* __restrict__ ggx, 
 // ------------------------------------------------------------------ channel sums (bias gradients)
 template <class T>
 __global__ __launch_bounds__(256) void channel_sum_partial(const T* __restrict__ x, long long pixels, int C, int ld, int lanes_c, int rows,
-                                                           float* __restrict__ partial) {
+                                                           float* __restrict__ partial, Fin fin = Fin{nullptr, nullptr},
+                                                           float* __restrict__ out = nullptr, int accumulate = 0) {
   column_reduce<1>(
       pixels, C, lanes_c, rows, partial, [&](int) { return 0; }, [&](long long q, int cb) { return V1{ld4(x + (size_t)q * ld + cb)}; },
       [&](const V1& v, int, f32x4* acc) { acc[0] += v.a; });
+  if (fin.tickets)
+    column_finish<1>(partial, C, lanes_c, fin, [&](int c, const double* sm) { out[c] = accumulate ? out[c] + (float)sm[0] : (float)sm[0]; });
 }
 
 // ------------------------------------------------------------------ per-channel max|x| (scales of the fp16-split weight-gradient GEMMs)
 // Two stages like the column sums, and for the same reason: one atomicMax per channel and workgroup (2048 x C atomics on C addresses)
 // was measured at 127 us per tensor, 12 ms per train step.  partial[b][c] = max over block b's pixels; magnitude bits compare as unsigned.
 __global__ __launch_bounds__(256) void channel_absmax_partial(const float* __restrict__ x, long long pixels, int C, int ld, int lanes_c, int rows,
-                                                              unsigned* __restrict__ partial) {
+                                                              unsigned* __restrict__ partial, Fin fin = Fin{nullptr, nullptr},
+                                                              unsigned* __restrict__ out = nullptr) {
   __shared__ u32x4 red[256];
   const int tx = threadIdx.x % lanes_c, ty = threadIdx.x / lanes_c;
   const long long chunk = (pixels + gridDim.x - 1) / gridDim.x;
@@ -515,9 +725,15 @@ __global__ __launch_bounds__(256) void channel_absmax_partial(const float* __res
 #pragma unroll
         for (int e = 0; e < 4; ++e) m[e] = max(m[e], o[e]);
       }
-      *reinterpret_cast<u32x4*>(partial + (size_t)blockIdx.x * C + cb) = m;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) st_agent(partial + (size_t)blockIdx.x * C + cb + e, m[e]);
     }
     __syncthreads();
+  }
+  if (fin.tickets) {
+    unsigned* const pp[1] = {partial};
+    unsigned* const oo[1] = {out};
+    channel_max_finish<1>(pp, oo, C, lanes_c, fin);
   }
 }
 
@@ -885,6 +1101,119 @@ static int act_backward_impl(const float* g, int ldg, const float* y, int ldy, l
   return check_launch("act_backward");
 }
 
+// ---- fused calls (ABI 9): every two-stage reduction finishes inside the launch that writes its partial rows (Fin), a BatchNorm forward
+// or backward is ONE entry point.  Scratch: `ws` (LHG_FUSED_WS_FLOATS floats) and `tickets` (LHG_FUSED_TICKETS zero-initialised unsigned,
+// self-cleaning) — one persistent pair per stream, because launches of one stream never overlap and everything in them is consumed by
+// the same call.
+struct FusedWs {
+  float* partial;      // [rows][NSUM][C] floats, rows <= 2048 / gy
+  double* level1;      // [groups][NSUM][C] doubles
+  float* sums;         // [NSUM][C] floats
+  unsigned* cpart[2];  // per-channel partial maxima of the apply kernels' one or two outputs
+  unsigned* clevel1;   // [2][groups][C]
+};
+static_assert(LHG_FUSED_WS_FLOATS >= 655360 + 81920 + 20480 + 2 * 131072 + 16384, "fused workspace layout");
+static inline FusedWs fused_ws(float* ws) {
+  FusedWs w;
+  w.partial = ws;
+  w.level1 = reinterpret_cast<double*>(ws + 655360);
+  w.sums = ws + 655360 + 81920;
+  w.cpart[0] = reinterpret_cast<unsigned*>(ws + 655360 + 81920 + 20480);
+  w.cpart[1] = w.cpart[0] + 131072;
+  w.clevel1 = w.cpart[1] + 131072;
+  return w;
+}
+#define LHG_FUSED_OK(ws, tickets, C, what)                                                                                        \
+  LHG_REQUIRE((ws) != nullptr && (tickets) != nullptr && (reinterpret_cast<uintptr_t>(ws) & 15) == 0 && (C) <= 4096,              \
+              "%s: needs the fused scratch (LHG_FUSED_WS_FLOATS floats, 16-byte aligned; LHG_FUSED_TICKETS zeroed unsigned) and C <= 4096 (C=%d)", what, (int)(C))
+
+template <class T>
+static int bn_forward_train_impl(const float* x, int ldx, long long pixels, int C, const float* gamma, const float* beta, float* running_mean,
+                                 float* running_var, float momentum, float eps, const float* res, int ldres, int act, float slope, float* y, int ldy,
+                                 float* stats, float* y_absmax, float* y_chanmax, int chanmax_finish, float* ws, unsigned* tickets, lhg_stream_t s) {
+  LHG_NHWC_OK(x, C, ldx, "bn_forward_train(x)");
+  LHG_NHWC_OK(y, C, ldy, "bn_forward_train(y)");
+  if (res) LHG_NHWC_OK(res, C, ldres, "bn_forward_train(res)");
+  LHG_REQUIRE(pixels > 0 && stats != nullptr && gamma != nullptr && beta != nullptr, "bn_forward_train: empty tensor or missing statistics / affine parameters");
+  LHG_FUSED_OK(ws, tickets, C, "bn_forward_train");
+  LHG_REQUIRE(y_chanmax == nullptr || sizeof(T) == 4, "bn_forward_train: per-channel maxima are measured of fp32 tensors only");
+  const ColMap cm = col_map(C);
+  const FusedWs w = fused_ws(ws);
+  const int nblk = partial_blocks(pixels, cm.gy);
+  hipLaunchKernelGGL((bn_stats_partial<T>), dim3(nblk, cm.gy), dim3(256), 0, as_stream(s), as_act<T>(x), pixels, C, ldx, cm.lanes_c, cm.rows, w.partial,
+                     Fin{tickets, w.level1}, stats, running_mean, running_var, momentum, eps);
+  const int nb2 = apply_blocks(pixels, cm);
+  // chanmax_finish != 0: y_chanmax receives the C finished maxima (the apply launch folds its own partial rows: ~11 us longer);
+  // 0: y_chanmax IS the partial-row buffer (lhg_chanmax_partial_rows x C floats), finished later by lhg_channel_absmax_finish on whatever stream asks
+  unsigned* rows_out = y_chanmax ? (chanmax_finish ? w.cpart[0] : reinterpret_cast<unsigned*>(y_chanmax)) : nullptr;
+  hipLaunchKernelGGL((bn_apply_kernel<T>), dim3(nb2, cm.gy), dim3(256), 0, as_stream(s), as_act<T>(x), ldx, pixels, C, stats, gamma, beta, as_act<T>(res),
+                     ldres, act, slope, as_act<T>(y), ldy, cm.lanes_c, cm.rows, y_absmax, rows_out,
+                     Fin{(y_chanmax && chanmax_finish) ? tickets : nullptr, w.clevel1}, reinterpret_cast<unsigned*>(y_chanmax));
+  return check_launch("bn_forward_train");
+}
+
+template <class T>
+static int bn_backward_fused_impl(const float* gy, int ldgy, const float* x, int ldx, const float* y, int ldy, long long pixels, int C,
+                                  const float* stats, const float* gamma, const float* beta, int act, float slope, float* gx, int ldgx, float* gres,
+                                  int ldgres, float* ggamma, float* gbeta, int accumulate, float* gx_absmax, float* gres_absmax, float* gx_chanmax,
+                                  float* gres_chanmax, int chanmax_finish, float* ws, unsigned* tickets, lhg_stream_t s) {
+  LHG_NHWC_OK(gy, C, ldgy, "bn_backward_fused(gy)");
+  LHG_NHWC_OK(x, C, ldx, "bn_backward_fused(x)");
+  LHG_NHWC_OK(gx, C, ldgx, "bn_backward_fused(gx)");
+  if (act != LHG_ACT_NONE && y) LHG_NHWC_OK(y, C, ldy, "bn_backward_fused(y)");
+  if (act != LHG_ACT_NONE && !y)
+    LHG_REQUIRE(beta != nullptr && gres == nullptr && (act == LHG_ACT_RELU || act == LHG_ACT_LEAKY),
+                "bn_backward_fused: without y the mask is recomputed from x: needs beta, no residual, ReLU / LeakyReLU");
+  if (gres) LHG_NHWC_OK(gres, C, ldgres, "bn_backward_fused(gres)");
+  LHG_FUSED_OK(ws, tickets, C, "bn_backward_fused");
+  LHG_REQUIRE((gx_chanmax == nullptr && gres_chanmax == nullptr) || sizeof(T) == 4, "bn_backward_fused: per-channel maxima are measured of fp32 tensors only");
+  LHG_REQUIRE(gres_chanmax == nullptr || (gres != nullptr && gx_chanmax != nullptr), "bn_backward_fused: gres_chanmax needs gres and gx_chanmax");
+  const ColMap cm = col_map(C);
+  const FusedWs w = fused_ws(ws);
+  const int nblk = partial_blocks(pixels, cm.gy);
+  hipLaunchKernelGGL((bn_bwd_partial<T>), dim3(nblk, cm.gy), dim3(256), 0, as_stream(s), as_act<T>(gy), ldgy, as_act<T>(x), ldx, as_act<T>(y), ldy, pixels, C,
+                     stats, gamma, beta, act, slope, cm.lanes_c, cm.rows, w.partial, Fin{tickets, w.level1}, w.sums);
+  const int nb2 = apply_blocks(pixels, cm);
+  hipLaunchKernelGGL((bn_bwd_apply<T>), dim3(nb2, cm.gy), dim3(256), 0, as_stream(s), as_act<T>(gy), ldgy, as_act<T>(x), ldx, as_act<T>(y), ldy, pixels, C, stats,
+                     gamma, w.sums, act, slope, as_act<T>(gx), ldgx, as_act<T>(gres), ldgres, ggamma, gbeta, accumulate, cm.lanes_c, cm.rows, gx_absmax, beta,
+                     1.f / (float)pixels, gx_chanmax ? (chanmax_finish ? w.cpart[0] : reinterpret_cast<unsigned*>(gx_chanmax)) : nullptr,
+                     gres_chanmax ? (chanmax_finish ? w.cpart[1] : reinterpret_cast<unsigned*>(gres_chanmax)) : nullptr, gres ? gres_absmax : nullptr,
+                     Fin{(gx_chanmax && chanmax_finish) ? tickets : nullptr, w.clevel1}, reinterpret_cast<unsigned*>(gx_chanmax),
+                     reinterpret_cast<unsigned*>(gres_chanmax));
+  return check_launch("bn_backward_fused");
+}
+
+template <class T>
+static int bn_backward_backward_fused_impl(const float* ggx, const float* gy, const float* x, const float* y, long long pixels, int C,
+                                           const float* stats, const float* gamma, int act, float slope, float* ggy, float* gx2, float* ggamma2,
+                                           float* ws, unsigned* tickets, lhg_stream_t s) {
+  LHG_NHWC_OK(ggx, C, C, "bn_backward_backward_fused(ggx)");
+  LHG_REQUIRE(aligned16(gy) && aligned16(x) && aligned16(ggy) && aligned16(gx2), "bn_backward_backward_fused: unaligned tensor");
+  LHG_FUSED_OK(ws, tickets, C, "bn_backward_backward_fused");
+  const ColMap cm = col_map(C);
+  const FusedWs w = fused_ws(ws);
+  const int nblk = partial_blocks(pixels, cm.gy);
+  hipLaunchKernelGGL((bn_bwd2_partial<T>), dim3(nblk, cm.gy), dim3(256), 0, as_stream(s), as_act<T>(ggx), as_act<T>(gy), as_act<T>(x), as_act<T>(y), pixels, C,
+                     stats, act, slope, cm.lanes_c, cm.rows, w.partial, Fin{tickets, w.level1}, w.sums);
+  const int nb2 = grid_for((size_t)pixels, cm.rows * 4, std::max(1, 4096 / cm.gy));
+  hipLaunchKernelGGL((bn_bwd2_apply<T>), dim3(nb2, cm.gy), dim3(256), 0, as_stream(s), as_act<T>(ggx), as_act<T>(gy), as_act<T>(x), as_act<T>(y), pixels, C, stats,
+                     gamma, w.sums, act, slope, as_act<T>(ggy), as_act<T>(gx2), ggamma2, cm.lanes_c, cm.rows, 1.f / (float)pixels);
+  return check_launch("bn_backward_backward_fused");
+}
+
+template <class T>
+static int channel_sum_fused_impl(const float* x, long long pixels, int C, int ld, float* out, int accumulate, float* ws, unsigned* tickets, lhg_stream_t s) {
+  LHG_NHWC_OK(x, C, ld, "channel_sum_fused");
+  LHG_FUSED_OK(ws, tickets, C, "channel_sum_fused");
+  LHG_REQUIRE(pixels > 0 && out != nullptr, "channel_sum_fused: empty tensor or missing output");
+  const ColMap cm = col_map(C);
+  const FusedWs w = fused_ws(ws);
+  const int nblk = partial_blocks(pixels, cm.gy);
+  hipLaunchKernelGGL((channel_sum_partial<T>), dim3(nblk, cm.gy), dim3(256), 0, as_stream(s), as_act<T>(x), pixels, C, ld, cm.lanes_c, cm.rows, w.partial,
+                     Fin{tickets, w.level1}, out, accumulate);
+  return check_launch("channel_sum_fused");
+}
+
 extern "C" {
 
 int lhg_set_activation_dtype(int dtype) {
@@ -985,6 +1314,43 @@ int lhg_bn_backward_backward_apply(const float* ggx, const float* gy, const floa
   return LHG_ACT_CALL(bn_backward_backward_impl, ggx, gy, x, y, pixels, C, stats, gamma, act, slope, ggy, gx2, ggamma2, nullptr, s, 2,
                       const_cast<float*>(sums), inv_count);
 }
+// ---- ABI 9: fused calls (see bn_forward_train_impl)
+long long lhg_fused_workspace_floats(void) { return LHG_FUSED_WS_FLOATS; }
+int lhg_fused_ticket_count(void) { return LHG_FUSED_TICKETS; }
+int lhg_bn_forward_train(const float* x, int ldx, long long pixels, int C, const float* gamma, const float* beta, float* running_mean,
+                         float* running_var, float momentum, float eps, const float* res, int ldres, int act, float slope, float* y, int ldy,
+                         float* stats, float* y_absmax, float* y_chanmax, int chanmax_finish, float* ws, unsigned* tickets, lhg_stream_t s) {
+  return LHG_ACT_CALL(bn_forward_train_impl, x, ldx, pixels, C, gamma, beta, running_mean, running_var, momentum, eps, res, ldres, act, slope, y, ldy, stats,
+                      y_absmax, y_chanmax, chanmax_finish, ws, tickets, s);
+}
+int lhg_bn_backward_fused(const float* gy, int ldgy, const float* x, int ldx, const float* y, int ldy, long long pixels, int C, const float* stats,
+                          const float* gamma, const float* beta, int act, float slope, float* gx, int ldgx, float* gres, int ldgres, float* ggamma,
+                          float* gbeta, int accumulate, float* gx_absmax, float* gres_absmax, float* gx_chanmax, float* gres_chanmax, int chanmax_finish,
+                          float* ws, unsigned* tickets, lhg_stream_t s) {
+  return LHG_ACT_CALL(bn_backward_fused_impl, gy, ldgy, x, ldx, y, ldy, pixels, C, stats, gamma, beta, act, slope, gx, ldgx, gres, ldgres, ggamma, gbeta,
+                      accumulate, gx_absmax, gres_absmax, gx_chanmax, gres_chanmax, chanmax_finish, ws, tickets, s);
+}
+int lhg_bn_backward_backward_fused(const float* ggx, const float* gy, const float* x, const float* y, long long pixels, int C, const float* stats,
+                                   const float* gamma, int act, float slope, float* ggy, float* gx2, float* ggamma2, float* ws, unsigned* tickets,
+                                   lhg_stream_t s) {
+  return LHG_ACT_CALL(bn_backward_backward_fused_impl, ggx, gy, x, y, pixels, C, stats, gamma, act, slope, ggy, gx2, ggamma2, ws, tickets, s);
+}
+int lhg_channel_sum_fused(const float* x, long long pixels, int C, int ld, float* out, int accumulate, float* ws, unsigned* tickets, lhg_stream_t s) {
+  return LHG_ACT_CALL(channel_sum_fused_impl, x, pixels, C, ld, out, accumulate, ws, tickets, s);
+}
+int lhg_channel_absmax_fused(const float* x, long long pixels, int C, int ld, float* out, float* ws, unsigned* tickets, lhg_stream_t s) {
+  LHG_NHWC_OK(x, C, ld, "channel_absmax_fused");
+  LHG_FUSED_OK(ws, tickets, C, "channel_absmax_fused");
+  LHG_REQUIRE(pixels > 0 && out != nullptr, "channel_absmax_fused: empty tensor or missing output");
+  LHG_REQUIRE(!act_is_bf16(), "channel_absmax_fused: fp32 tensors only (the bf16 storage mode does not use it)");
+  const ColMap cm = col_map(C);
+  const FusedWs w = fused_ws(ws);
+  const int nblk = partial_blocks(pixels, cm.gy);
+  hipLaunchKernelGGL(channel_absmax_partial, dim3(nblk, cm.gy), dim3(256), 0, as_stream(s), x, pixels, C, ld, cm.lanes_c, cm.rows, w.cpart[0],
+                     Fin{tickets, w.clevel1}, reinterpret_cast<unsigned*>(out));
+  return check_launch("channel_absmax_fused");
+}
+
 int lhg_maxpool2x2_forward(const float* x, int N, int H, int W, int C, int ldx, float* y, int ldy, lhg_stream_t s) {
   return LHG_ACT_CALL(maxpool_fwd_impl, x, N, H, W, C, ldx, y, ldy, s);
 }

@@ -124,14 +124,17 @@ class OutSlot:
 class AmaxShare:
     """One max|.| slot for a buffer that several producers fill (the two halves of a skip-concatenation buffer): every producer that
     measures its output max-accumulates into ``slot`` and counts itself in; the buffer may be tagged with the slot only when all of
-    its ``parts`` producers did (a producer that cannot measure — thin convolution, another GEMM mode — simply does not count)."""
+    its ``parts`` producers did (a producer that cannot measure — thin convolution, another GEMM mode — simply does not count).
+    ``buf`` (the whole buffer): producers that measure per-channel maxima of what they write (the BatchNorm calls) do so into their
+    channel range of ONE source for the buffer (ChanMaxSource); whatever range nobody covered is measured by a pass over that slice
+    only when a weight-gradient GEMM asks (operand_chanmax)."""
 
-    __slots__ = ("slot", "parts", "writers", "cparts")
+    __slots__ = ("slot", "parts", "writers", "buf", "csrc")
 
-    def __init__(self, device, parts=2):
+    def __init__(self, device, parts=2, buf=None):
         self.slot = fused_absmax_slot(device)
         self.parts, self.writers = parts, 0
-        self.cparts = []  # (data_ptr of the slice, channels, partial maxima, pixels): producers that also left per-channel partials
+        self.buf, self.csrc = buf, None
 
     def writer(self):
         """The slot for a producer about to measure into it (None when the mode has no use for it)."""
@@ -139,11 +142,22 @@ class AmaxShare:
             self.writers += 1
         return self.slot
 
+    def chanmax_for(self, view, pixels):
+        """ChanMaxDest for the producer of ``view`` (a channel slice of the buffer), or None (no buffer known, or nobody will ask)."""
+        if self.buf is None or not chanmax_wanted(view.shape[-1]):
+            return None
+        off = (view.data_ptr() - self.buf.data_ptr()) // self.buf.element_size()
+        if off < 0 or off + view.shape[-1] > self.buf.shape[-1] or off % 4:
+            return None
+        if self.csrc is None:
+            self.csrc = ChanMaxSource(self.buf.shape[-1], self.buf.device)
+        return ChanMaxDest(self.csrc, off, view.shape[-1], pixels, shared=True)
+
     def tag(self, buf):
         if self.slot is not None and self.writers >= self.parts:
             tag_absmax(buf, self.slot)
-        if self.cparts:  # the channels no producer covered are measured by a pass over that slice only (operand_chanmax)
-            tag_chanmax_source(buf, [((p - buf.data_ptr()) // 4, cc, part, px) for p, cc, part, px in self.cparts])
+        if self.csrc is not None:  # the channels no producer covered are measured by a pass over that slice only (operand_chanmax)
+            tag_chanmax_source(buf, self.csrc)
         return buf
 
 
@@ -478,9 +492,9 @@ _FAKE_CMAX = {}
 def operand_chanmax(t):
     """Per-channel max|t| (or an upper bound) of an NHWC fp32 operand of a WEIGHT-GRADIENT GEMM as a (C,) device tensor — the
     per-channel scales of the "fp32_split_f16" mode (the contraction runs over pixels, so a scale per channel factors out of the sum
-    exactly); None in every other mode.  Sources, cheapest first: the value cached on the tensor (or on the tensor it aliases) for this
-    stream; per-workgroup partial maxima left by the kernel that wrote the tensor (tag_chanmax_source: one small launch per part);
-    lhg_channel_absmax, a pass over the tensor, for whatever channels no producer covered."""
+    exactly); None in every other mode.  Sources, cheapest first: the vector the kernel that WROTE the tensor finished on its way out
+    (tag_chanmax_source: the fused BatchNorm calls — nothing to launch here); lhg_channel_absmax_fused, one pass over the tensor, for
+    whatever channels no producer covered."""
     if _mode() != _F16_SPLIT:
         return None
     if _TIMING_FAKE_CHANMAX:  # timing experiments only: what the step costs without the per-channel maxima passes
@@ -488,19 +502,35 @@ def operand_chanmax(t):
         if key not in _FAKE_CMAX:
             _FAKE_CMAX[key] = torch.full((t.shape[-1],), float(os.environ.get("LHG_TIMING_FAKE_CHANMAX_VALUE", "64")), dtype=torch.float32, device=t.device)
         return _FAKE_CMAX[key]
-    st = stream_ptr()
     root = t.__dict__.get("_lhg_root", t)  # the tensor t is an alias of (Conv2dSharedInputFn's second output): one cache for both
     if root is not t and not (root.data_ptr() == t.data_ptr() and root.shape == t.shape and root.stride() == t.stride() and root._version == t._version):
         root = t
+    st = stream_ptr()
     known = root.__dict__.get("_lhg_cmax")
-    if known is not None and known[0] == t._version and known[1] == st:
-        return known[2]
+    if known is not None and known[0] == t._version:
+        if known[2] != st:  # another stream reads the vector now: keep its memory out of reuse until that stream is done with it
+            known[1].record_stream(torch.cuda.current_stream(t.device))
+            root.__dict__["_lhg_cmax"] = (known[0], known[1], st)
+        return known[1]
     p, N, H, W, Cc, ld = nhwc(t)
     pixels = N * H * W
-    out = torch.empty((Cc,), dtype=torch.float32, device=t.device)
     src = root.__dict__.get("_lhg_cmax_src")
-    parts = sorted(src[1], key=lambda q: q[0]) if (src is not None and src[0] == t._version and _FUSED_CHANMAX) else []
-    cur = torch.cuda.current_stream(t.device)
+    if src is not None and src[0] == t._version and _FUSED_CHANMAX and src[1].vec.shape[0] == Cc:
+        out = src[1].vec
+        for off, cc, partial, grid_pixels, rows in src[1].pending:
+            # the kernel that wrote these channels left per-workgroup partial maxima: one small launch (on the caller's stream — the
+            # weight-gradient stream, beside the main chain; the caller is ordered behind that kernel, it reads t) instead of a pass
+            partial.record_stream(torch.cuda.current_stream(t.device))
+            if rows is not None:
+                call("lhg_channel_absmax_finish_rows", ptr(partial), int(rows), cc, out.data_ptr() + 4 * off, st)
+            else:
+                call("lhg_channel_absmax_finish", ptr(partial), grid_pixels, cc, out.data_ptr() + 4 * off, st)
+            src[1].covered.append((off, cc))
+        src[1].pending.clear()
+        covered = sorted(src[1].covered)
+    else:
+        out, covered = torch.empty((Cc,), dtype=torch.float32, device=t.device), []
+    ws, tickets = fused_scratch(t.device)
 
     def measure(c0, c1):  # a pass over channels [c0, c1) of t
         CHANMAX_STATS["pass"] += 1
@@ -508,29 +538,20 @@ def operand_chanmax(t):
         if CHANMAX_PASS_LOG is not None:  # diagnostics (tools/chanmax_sites.py): who still pays a pass
             import traceback
             CHANMAX_PASS_LOG.append(((N, H, W, c1 - c0, ld), [f"{f.name}:{f.lineno}" for f in traceback.extract_stack(limit=8)[:-2]], type(t.grad_fn).__name__))
-        ws = torch.empty((2048 * (c1 - c0),), dtype=torch.float32, device=t.device)
-        call("lhg_channel_absmax", p + 4 * c0, pixels, c1 - c0, ld, out.data_ptr() + 4 * c0, ptr(ws), st)
+        call("lhg_channel_absmax_fused", p + 4 * c0, pixels, c1 - c0, ld, out.data_ptr() + 4 * c0, ws, tickets, st)
 
     at = 0
-    for entry in parts:
-        off, cc, partial, grid_pixels = entry[:4]
-        rows = entry[4] if len(entry) > 4 else None  # explicit row count: several producers' rows one behind the other (BatchNormPairTrainFn)
-        if off < at or off + cc > Cc or off % 4:
+    for off, cc in covered:
+        if off < at or off + cc > Cc:
             continue
         if off > at:
             measure(at, off)
-        # the kernel that wrote these channels left per-workgroup partial maxima: one small launch instead of a pass.  The caller's
-        # stream is ordered behind that kernel (it reads t).
-        CHANMAX_STATS["fused"] += 1
-        partial.record_stream(cur)
-        if rows is not None:
-            call("lhg_channel_absmax_finish_rows", ptr(partial), int(rows), cc, out.data_ptr() + 4 * off, st)
-        else:
-            call("lhg_channel_absmax_finish", ptr(partial), grid_pixels, cc, out.data_ptr() + 4 * off, st)
+        CHANMAX_STATS["fused"] += 1  # finished by the kernel that wrote these channels; the caller's stream is ordered behind it (it reads t)
         at = off + cc
     if at < Cc:
         measure(at, Cc)
-    root.__dict__["_lhg_cmax"] = (t._version, st, out)
+    out.record_stream(torch.cuda.current_stream(t.device))  # (written on the producer's stream, read by a GEMM of this one)
+    root.__dict__["_lhg_cmax"] = (t._version, out, st)
     return out
 
 
@@ -539,20 +560,79 @@ CHANMAX_STATS = {"fused": 0, "pass": 0, "pass_bytes": 0}  # parts finished from 
 _FUSED_CHANMAX = os.environ.get("LHG_FUSED_CHANMAX", "1") != "0"
 
 
+def chanmax_wanted(Cc) -> bool:
+    """Will a weight-gradient GEMM ask for per-channel maxima of a tensor with ``Cc`` channels written now?  (fp16-split mode, fp32 storage.)"""
+    return _mode() == _F16_SPLIT and _ACT_DTYPE == torch.float32 and _FUSED_CHANMAX and Cc % 4 == 0
+
+
+# LHG_CHANMAX_IN_LAUNCH=1: the BatchNorm apply launches fold their own partial maxima (chanmax_finish of the fused calls) instead of
+# leaving the rows to a finish launch on the stream that asks.  Measured (round 5): 84 launches fewer per step, but ~11 us more in every
+# apply launch ON THE MAIN CHAIN (27 in the backward apply with its two outputs), where the finish launches ran on the weight-gradient
+# stream beside it: the step does not get shorter.  Off by default.
+_CHANMAX_IN_LAUNCH = os.environ.get("LHG_CHANMAX_IN_LAUNCH", "0") == "1"
+
+
+class ChanMaxSource:
+    """Per-channel bounds of one tensor (or of one shared buffer): ``vec`` (C floats) with the channel ranges ``covered`` holding finished
+    maxima and ``pending`` = [(first channel, channels, partial rows, pixels of the producer's grid, explicit row count | None)] still
+    to be finished into vec by lhg_channel_absmax_finish when a weight-gradient GEMM asks (operand_chanmax)."""
+
+    __slots__ = ("vec", "covered", "pending")
+
+    def __init__(self, Cc, device):
+        self.vec = torch.empty((Cc,), dtype=torch.float32, device=device)
+        self.covered, self.pending = [], []
+
+
+class ChanMaxDest:
+    """What a producer kernel is handed for the per-channel maxima of the ``cc`` channels it writes: ``ptr`` / ``finish`` are the
+    y_chanmax / chanmax_finish arguments of the fused BatchNorm calls; ``commit(t)`` records the result once the launch is queued."""
+
+    __slots__ = ("src", "off", "cc", "pixels", "shared", "partial", "ptr", "finish")
+
+    def __init__(self, src, off, cc, pixels, shared=False):
+        self.src, self.off, self.cc, self.pixels, self.shared = src, off, cc, pixels, shared
+        self.finish = int(_CHANMAX_IN_LAUNCH)
+        if self.finish:
+            self.partial, self.ptr = None, src.vec.data_ptr() + 4 * off
+        else:
+            rows = int(native.load().lhg_chanmax_partial_rows(pixels, cc))
+            self.partial = torch.empty((rows * cc,), dtype=torch.float32, device=src.vec.device)
+            self.ptr = self.partial.data_ptr()
+
+    def commit(self, t):
+        if self.finish:
+            self.src.covered.append((self.off, self.cc))
+        else:
+            self.src.pending.append((self.off, self.cc, self.partial, self.pixels, None))
+        if not self.shared:
+            tag_chanmax_source(t, self.src)
+        return t
+
+
+def chanmax_dest(Cc, pixels, device, out=None):
+    """ChanMaxDest for a kernel about to write a tensor with ``Cc`` channels over ``pixels`` pixels, or None when nobody will ask.
+    ``out``: the op's destination — an OutSlot of a shared buffer gets its channel range of the buffer's source."""
+    if isinstance(out, OutSlot) and out.share is not None:
+        return out.share.chanmax_for(out.t, pixels)
+    if not chanmax_wanted(Cc):
+        return None
+    return ChanMaxDest(ChanMaxSource(Cc, device), 0, Cc, pixels)
+
+
 def chanmax_partial_for(pixels, Cc, device):
-    """Buffer for the per-workgroup partial maxima a BatchNorm kernel leaves of what it writes (None when nobody will ask: not the
-    fp16-split mode, bf16 storage)."""
-    if _mode() != _F16_SPLIT or _ACT_DTYPE != torch.float32 or not _FUSED_CHANMAX or Cc % 4:
+    """Buffer for the per-workgroup partial maxima of the UNFUSED calls (lhg_bn_apply_chanmax / lhg_bn_backward_chanmax: kept for the
+    C ABI's users and the operator tests; the op layer uses the fused calls)."""
+    if not chanmax_wanted(Cc):
         return None
     rows = int(native.load().lhg_chanmax_partial_rows(pixels, Cc))
     return torch.empty((rows * Cc,), dtype=torch.float32, device=device)
 
 
-def tag_chanmax_source(t, parts):
-    """Remember where per-channel bounds of t come from: parts = [(first channel, channels, partial buffer, pixels of the producer's
-    grid)], each finished by lhg_channel_absmax_finish(partial, pixels, channels) when a weight-gradient GEMM asks (operand_chanmax)."""
-    if parts:
-        t.__dict__["_lhg_cmax_src"] = (t._version, list(parts))
+def tag_chanmax_source(t, src):
+    """Remember where per-channel bounds of t come from (a ChanMaxSource, or None)."""
+    if src is not None:
+        t.__dict__["_lhg_cmax_src"] = (t._version, src)
     return t
 
 
@@ -565,6 +645,25 @@ def _inherit_chanmax(dst, src, alias=False):
     if alias:
         dst.__dict__["_lhg_root"] = src.__dict__.get("_lhg_root", src)
     return dst
+
+
+_FUSED_SCRATCH = {}
+
+
+def fused_scratch(device):
+    """(ws, tickets) data pointers of the fused calls' scratch for the current stream (include/lhg_hip.h "fused calls"): one persistent
+    pair per (device, stream, capture state) — launches of one stream never overlap, and every fused call consumes what it put there
+    before it returns the stream to the next.  The tickets are zero-filled once; every call leaves them at zero."""
+    key = (torch.device(device).index if torch.device(device).index is not None else torch.cuda.current_device(), stream_ptr(),
+           torch.cuda.is_current_stream_capturing())
+    hit = _FUSED_SCRATCH.get(key)
+    if hit is None:
+        lib = native.load()
+        dev = torch.device("cuda", key[0])
+        ws = torch.empty((int(lib.lhg_fused_workspace_floats()),), dtype=torch.float32, device=dev)
+        tickets = torch.zeros((int(lib.lhg_fused_ticket_count()),), dtype=torch.int32, device=dev)
+        hit = _FUSED_SCRATCH[key] = (ws, tickets, ws.data_ptr(), tickets.data_ptr())
+    return hit[2], hit[3]
 
 
 def fused_absmax_slot(device):
@@ -1149,8 +1248,8 @@ def channel_sum(t):
 def channel_sum_into(t, slot):
     """slot += sum over (N,H,W) of t (C % 4 == 0): the bias gradient accumulated by the reduction kernel itself."""
     p, N, H, W, Cc, ld = nhwc(t)
-    ws = torch.empty((2048 * Cc,), dtype=torch.float32, device=t.device)
-    call("lhg_channel_sum", p, N * H * W, Cc, ld, ptr(slot), 1, ptr(ws), stream_ptr())
+    ws, tickets = fused_scratch(t.device)
+    call("lhg_channel_sum_fused", p, N * H * W, Cc, ld, ptr(slot), 1, ws, tickets, stream_ptr())
 
 
 class ChannelSumFn(Function):
@@ -1159,8 +1258,8 @@ class ChannelSumFn(Function):
         p, N, H, W, Cc, ld = nhwc(t)
         ctx.shape = t.shape
         out = torch.empty((Cc,), dtype=torch.float32, device=t.device)
-        ws = torch.empty((2048 * Cc,), dtype=torch.float32, device=t.device)
-        call("lhg_channel_sum", p, N * H * W, Cc, ld, ptr(out), 0, ptr(ws), stream_ptr())
+        ws, tickets = fused_scratch(t.device)
+        call("lhg_channel_sum_fused", p, N * H * W, Cc, ld, ptr(out), 0, ws, tickets, stream_ptr())
         return out
 
     @staticmethod
@@ -1304,31 +1403,28 @@ class BatchNormTrainFn(TrackedFunction):
         stats = torch.empty((2 * Cc,), dtype=torch.float32, device=x.device)
         world = sync_world()
         ctx.world = world
-        if world > 1:  # statistics over the global batch
-            call("lhg_bn_stats", px, pixels, Cc, ldx, ptr(stats), None, None, BN_MOMENTUM, BN_EPS, ptr(_bn_ws(Cc, x.device, 4104)), stream_ptr())
-            _global_batch_stats(stats, Cc, pixels, world, running_mean, running_var)
-        else:
-            call("lhg_bn_stats", px, pixels, Cc, ldx, ptr(stats), ptr(running_mean), ptr(running_var), BN_MOMENTUM, BN_EPS,
-                 ptr(_bn_ws(Cc, x.device, 4104)), stream_ptr())
         y = _resolve_out(out, (N, H, W, Cc), x.device)
         py, _, _, _, _, ldy = nhwc(y)
         pres, ldres = (None, 0)
         if res is not None:
             pres, _, _, _, _, ldres = nhwc(res)
         y_amax = _out_amax(out, x.device)  # max|y| measured by the kernel that writes y: the next conv's GEMMs need no pass of their own
-        # the weight gradient of the conv that reads y wants per-channel maxima of it: partials on the way out (training passes only)
-        part = chanmax_partial_for(pixels, Cc, x.device) if any(ctx.needs_input_grad) else None
-        if part is not None:
-            call("lhg_bn_apply_chanmax", px, ldx, pixels, Cc, ptr(stats), ptr(gamma), ptr(beta), pres, ldres, act, float(slope), py, ldy,
-                 ptr(y_amax), ptr(part), stream_ptr())
-        else:
+        if world > 1:  # statistics over the global batch: the sums pass through the host's all-reduce between the two kernels
+            call("lhg_bn_stats", px, pixels, Cc, ldx, ptr(stats), None, None, BN_MOMENTUM, BN_EPS, ptr(_bn_ws(Cc, x.device, 4104)), stream_ptr())
+            _global_batch_stats(stats, Cc, pixels, world, running_mean, running_var)
             call("lhg_bn_apply", px, ldx, pixels, Cc, ptr(stats), ptr(gamma), ptr(beta), pres, ldres, act, float(slope), py, ldy, ptr(y_amax),
                  stream_ptr())
+        else:
+            # statistics (finished in the launch that sums them), running statistics and the apply pass behind ONE call, two launches; the
+            # weight gradient of the conv that reads y wants per-channel maxima of it: finished by the apply launch (training passes only)
+            cm = chanmax_dest(Cc, pixels, x.device, out) if any(ctx.needs_input_grad) else None
+            ws, tickets = fused_scratch(x.device)
+            call("lhg_bn_forward_train", px, ldx, pixels, Cc, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), BN_MOMENTUM, BN_EPS,
+                 pres, ldres, act, float(slope), py, ldy, ptr(stats), ptr(y_amax), cm.ptr if cm else None, cm.finish if cm else 0, ws, tickets,
+                 stream_ptr())
+            if cm is not None:
+                cm.commit(y)
         tag_absmax(y, y_amax)
-        if part is not None:
-            tag_chanmax_source(y, [(0, Cc, part, pixels)])
-            if isinstance(out, OutSlot) and out.share is not None:
-                out.share.cparts.append((y.data_ptr(), Cc, part, pixels))
         ctx.save_for_backward(x, y, gamma, stats)
         ctx.act, ctx.slope, ctx.has_res = act, slope, res is not None
         ctx.beta = beta if ctx.needs_input_grad[2] else None
@@ -1374,23 +1470,20 @@ class BatchNormPairTrainFn(TrackedFunction):
         y = new_nhwc(N, H, W, Cc, x.device)
         py, _, _, _, _, ldy = nhwc(y)
         y_amax = fused_absmax_slot(x.device)  # both halves max-accumulate into the one slot
-        rows = int(native.load().lhg_chanmax_partial_rows(half, Cc)) if any(ctx.needs_input_grad) else 0
-        part = chanmax_partial_for(half, Cc, x.device) if rows else None
-        if part is not None:
-            part = torch.empty((2 * rows * Cc,), dtype=torch.float32, device=x.device)
+        # per-channel maxima: both halves' partial rows one behind the other in ONE buffer, finished together when a weight gradient asks
+        rows = int(native.load().lhg_chanmax_partial_rows(half, Cc)) if (any(ctx.needs_input_grad) and chanmax_wanted(Cc)) else 0
+        part = torch.empty((2 * rows * Cc,), dtype=torch.float32, device=x.device) if rows else None
+        ws, tickets = fused_scratch(x.device)
         for h in range(2):
             xo, yo = px + h * half * ldx * es, py + h * half * ldy * es
-            call("lhg_bn_stats", xo, half, Cc, ldx, stats[h].data_ptr(), ptr(running_mean), ptr(running_var), BN_MOMENTUM, BN_EPS,
-                 ptr(_bn_ws(Cc, x.device, 4104)), stream_ptr())
-            if part is not None:
-                call("lhg_bn_apply_chanmax", xo, ldx, half, Cc, stats[h].data_ptr(), ptr(gamma), ptr(beta), None, 0, act, float(slope), yo, ldy,
-                     ptr(y_amax), part.data_ptr() + 4 * h * rows * Cc, stream_ptr())
-            else:
-                call("lhg_bn_apply", xo, ldx, half, Cc, stats[h].data_ptr(), ptr(gamma), ptr(beta), None, 0, act, float(slope), yo, ldy, ptr(y_amax),
-                     stream_ptr())
+            call("lhg_bn_forward_train", xo, ldx, half, Cc, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), BN_MOMENTUM, BN_EPS,
+                 None, 0, act, float(slope), yo, ldy, stats[h].data_ptr(), ptr(y_amax), None if part is None else part.data_ptr() + 4 * h * rows * Cc, 0,
+                 ws, tickets, stream_ptr())
         tag_absmax(y, y_amax)
         if part is not None:
-            tag_chanmax_source(y, [(0, Cc, part, 2 * half, 2 * rows)])
+            src = ChanMaxSource(Cc, x.device)
+            src.pending.append((0, Cc, part, 2 * half, 2 * rows))
+            tag_chanmax_source(y, src)
         ctx.save_for_backward(x, y, gamma, stats)
         ctx.act, ctx.slope = act, slope
         ctx.beta = beta if ctx.needs_input_grad[2] else None
@@ -1418,23 +1511,21 @@ class BatchNormPairTrainFn(TrackedFunction):
         gx = new_nhwc(N, H, W, Cc, gy.device)
         pgx = gx.data_ptr()
         gx_amax = fused_absmax_slot(gy.device)
-        rows = int(native.load().lhg_chanmax_partial_rows(half, Cc))
-        part = chanmax_partial_for(half, Cc, gy.device)
-        if part is not None:
-            part = torch.empty((2 * rows * Cc,), dtype=torch.float32, device=gy.device)
+        rows = int(native.load().lhg_chanmax_partial_rows(half, Cc)) if chanmax_wanted(Cc) else 0
+        part = torch.empty((2 * rows * Cc,), dtype=torch.float32, device=gy.device) if rows else None
+        ws, tickets = fused_scratch(gy.device)
         for h in range(2):
             off = h * half
             acc = 1 if (into_slots or h == 1) else 0  # the second half adds to the first's sums
-            args = (pg + off * ldg * es, ldg, px + off * ldx * es, ldx, None if mask_from_x else py + off * ldy * es, ldy, half, Cc,
-                    stats[h].data_ptr(), ptr(gamma), ctx.act, float(ctx.slope), pgx + off * Cc * es, Cc, None, Cc, ptr(ggamma), ptr(gbeta), acc,
-                    ptr(_bn_ws(Cc, gy.device)), ptr(gx_amax), ptr(ctx.beta_value) if mask_from_x else None)
-            if part is not None:
-                call("lhg_bn_backward_chanmax", *args, part.data_ptr() + 4 * h * rows * Cc, None, None, stream_ptr())
-            else:
-                call("lhg_bn_backward", *args, stream_ptr())
+            call("lhg_bn_backward_fused", pg + off * ldg * es, ldg, px + off * ldx * es, ldx, None if mask_from_x else py + off * ldy * es, ldy, half, Cc,
+                 stats[h].data_ptr(), ptr(gamma), ptr(ctx.beta_value) if mask_from_x else None, ctx.act, float(ctx.slope), pgx + off * Cc * es, Cc,
+                 None, Cc, ptr(ggamma), ptr(gbeta), acc, ptr(gx_amax), None, None if part is None else part.data_ptr() + 4 * h * rows * Cc, None, 0,
+                 ws, tickets, stream_ptr())
         tag_absmax(gx, gx_amax)
         if part is not None:
-            tag_chanmax_source(gx, [(0, Cc, part, 2 * half, 2 * rows)])
+            src = ChanMaxSource(Cc, gy.device)
+            src.pending.append((0, Cc, part, 2 * half, 2 * rows))
+            tag_chanmax_source(gx, src)
         if into_slots:
             note_contribution(gamma)
             note_contribution(ctx.beta)
@@ -1466,24 +1557,22 @@ def bn_backward_raw(gy, x, y, gamma, stats, act, slope, want_res, ggamma, gbeta,
              act, float(slope), ptr(gx), Cc, ptr(gres), Cc, ptr(gx_amax), ptr(beta), stream_ptr())
         tag_absmax(gx, gx_amax)
         return gx, gres
-    part = chanmax_partial_for(N * H * W, Cc, gy.device)  # gx is the gy operand of the preceding conv's weight gradient
-    part_res = chanmax_partial_for(N * H * W, Cc, gy.device) if (want_res and part is not None) else None  # gres: of the shortcut conv's
-    gres_amax = fused_absmax_slot(gy.device) if (want_res and part is not None) else None  # gres is the gy of the shortcut conv's input gradient
-    if part is not None:
-        call("lhg_bn_backward_chanmax", pg, ldg, px, ldx, py, ldy, N * H * W, Cc, ptr(stats), ptr(gamma), act, float(slope),
-             ptr(gx), Cc, ptr(gres), Cc, ptr(ggamma), ptr(gbeta), int(accumulate), ptr(_bn_ws(Cc, gy.device)), ptr(gx_amax), ptr(beta),
-             ptr(part), ptr(part_res), ptr(gres_amax), stream_ptr())
-    else:
-        call("lhg_bn_backward", pg, ldg, px, ldx, py, ldy, N * H * W, Cc, ptr(stats), ptr(gamma), act, float(slope),
-             ptr(gx), Cc, ptr(gres), Cc, ptr(ggamma), ptr(gbeta), int(accumulate), ptr(_bn_ws(Cc, gy.device)), ptr(gx_amax), ptr(beta),
-             stream_ptr())
+    # gx is the gy operand of the preceding conv's two backward GEMMs, gres of the shortcut conv's: the apply launch finishes max|.| and the
+    # per-channel maxima of both on its way out (one call, two launches: sums finished inside the first)
+    cm = chanmax_dest(Cc, N * H * W, gy.device)
+    cm_res = chanmax_dest(Cc, N * H * W, gy.device) if (want_res and cm is not None) else None
+    gres_amax = fused_absmax_slot(gy.device) if (want_res and cm is not None) else None
+    ws, tickets = fused_scratch(gy.device)
+    call("lhg_bn_backward_fused", pg, ldg, px, ldx, py, ldy, N * H * W, Cc, ptr(stats), ptr(gamma), ptr(beta), act, float(slope),
+         ptr(gx), Cc, ptr(gres), Cc, ptr(ggamma), ptr(gbeta), int(accumulate), ptr(gx_amax), ptr(gres_amax), cm.ptr if cm else None,
+         cm_res.ptr if cm_res else None, cm.finish if cm else 0, ws, tickets, stream_ptr())
     tag_absmax(gx, gx_amax)
     if gres_amax is not None:
         tag_absmax(gres, gres_amax)
-    if part is not None:
-        tag_chanmax_source(gx, [(0, Cc, part, N * H * W)])
-    if part_res is not None:
-        tag_chanmax_source(gres, [(0, Cc, part_res, N * H * W)])
+    if cm is not None:
+        cm.commit(gx)
+    if cm_res is not None:
+        cm_res.commit(gres)
     return gx, gres
 
 
@@ -1528,8 +1617,8 @@ class BatchNormGradFn(TrackedFunction):
         ggy = new_nhwc(N, H, W, Cc, x.device)
         gx2 = new_nhwc(N, H, W, Cc, x.device)
         ggamma2 = torch.empty((Cc,), dtype=torch.float32, device=x.device)
-        ws = _bn_ws(Cc, x.device, 5 * 4096 + 8)
         if ctx.world > 1:  # global-batch statistics: the five sums are all-reduced between the kernel's halves
+            ws = _bn_ws(Cc, x.device, 5 * 4096 + 8)
             sums = torch.empty((5 * Cc,), dtype=torch.float32, device=x.device)
             call("lhg_bn_backward_backward_sums", ptr(ggx_d), ptr(gy_d), ptr(x_d), ptr(y_d), pixels, Cc, ptr(stats), ptr(gamma), ctx.act,
                  float(ctx.slope), ptr(sums), ptr(ws), stream_ptr())
@@ -1540,8 +1629,9 @@ class BatchNormGradFn(TrackedFunction):
             # formula over the GLOBAL sums is W times the global-batch gradient on every rank; its share here is 1/W of it
             ggamma2.div_(ctx.world)
         else:
-            call("lhg_bn_backward_backward", ptr(ggx_d), ptr(gy_d), ptr(x_d), ptr(y_d), pixels, Cc, ptr(stats), ptr(gamma),
-                 ctx.act, float(ctx.slope), ptr(ggy), ptr(gx2), ptr(ggamma2), ptr(ws), stream_ptr())
+            fws, tickets = fused_scratch(x.device)
+            call("lhg_bn_backward_backward_fused", ptr(ggx_d), ptr(gy_d), ptr(x_d), ptr(y_d), pixels, Cc, ptr(stats), ptr(gamma),
+                 ctx.act, float(ctx.slope), ptr(ggy), ptr(gx2), ptr(ggamma2), fws, tickets, stream_ptr())
         if not param_grads_wanted():
             return (ggy, gx2) + nothing[2:]
         slot = _small_grad_slot(ctx.gamma)

@@ -36,7 +36,7 @@ class PackItem(C.Structure):
 
 
 # name -> argtypes (restype is int unless listed in _RESTYPE)
-ABI_VERSION = 8  # LHG_ABI_VERSION of include/lhg_hip.h this binding was written against
+ABI_VERSION = 9  # LHG_ABI_VERSION of include/lhg_hip.h this binding was written against
 
 _SIGNATURES = {
     "lhg_abi_version": [],
@@ -110,12 +110,19 @@ _SIGNATURES = {
     "lhg_conv2d_backward_weight_into": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _p, _i, _p, _sz, _p, _p, _p],
     "lhg_conv_transpose2x2_backward_weight_workspace": [_i, _i, _i, _i, _i],
     "lhg_conv_transpose2x2_backward_weight_into": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _i, _p, _sz, _p, _p, _p],
+    "lhg_fused_workspace_floats": [],
+    "lhg_fused_ticket_count": [],
+    "lhg_bn_forward_train": [_p, _i, _ll, _i, _p, _p, _p, _p, _f, _f, _p, _i, _i, _f, _p, _i, _p, _p, _p, _i, _p, _p, _p],
+    "lhg_bn_backward_fused": [_p, _i, _p, _i, _p, _i, _ll, _i, _p, _p, _p, _i, _f, _p, _i, _p, _i, _p, _p, _i, _p, _p, _p, _p, _i, _p, _p, _p],
+    "lhg_bn_backward_backward_fused": [_p, _p, _p, _p, _ll, _i, _p, _p, _i, _f, _p, _p, _p, _p, _p, _p],
+    "lhg_channel_sum_fused": [_p, _ll, _i, _i, _p, _i, _p, _p, _p],
+    "lhg_channel_absmax_fused": [_p, _ll, _i, _i, _p, _p, _p, _p],
     "lhg_wg6_force": [_i, _i, _i],
     "lhg_wg6_last_plan": [C.POINTER(C.c_int), C.POINTER(C.c_int), C.POINTER(C.c_int)],
     "lhg_wg6_variants": [],
     "lhg_wg6_variant_name": [_i],
 }
-_RESTYPE = {"lhg_last_error": C.c_char_p, "lhg_packed_weight_floats": C.c_longlong, "lhg_fft_table_floats": C.c_longlong, "lhg_chanmax_partial_rows": C.c_longlong, "lhg_conv2d_thin_wgrad_workspace": C.c_size_t, "lhg_psnr_ssim_workspace": C.c_size_t,
+_RESTYPE = {"lhg_last_error": C.c_char_p, "lhg_fused_workspace_floats": C.c_longlong, "lhg_packed_weight_floats": C.c_longlong, "lhg_fft_table_floats": C.c_longlong, "lhg_chanmax_partial_rows": C.c_longlong, "lhg_conv2d_thin_wgrad_workspace": C.c_size_t, "lhg_psnr_ssim_workspace": C.c_size_t,
             "lhg_conv2d_backward_weight_workspace": C.c_size_t, "lhg_conv_transpose2x2_backward_weight_workspace": C.c_size_t, "lhg_wg6_variant_name": C.c_char_p}
 
 _lib = None

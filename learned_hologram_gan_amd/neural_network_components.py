@@ -192,7 +192,7 @@ class UNet(nn.Module):
         new = lambda h, w, c: ops.new_nhwc(N, h, w, c, dev)  # noqa: E731  (fp32, or bf16 in the bf16 storage mode)
         buf4, buf3, buf2, buf1 = new(H, W, 128), new(H // 2, W // 2, 256), new(H // 4, W // 4, 512), new(H // 8, W // 8, 1024)
         # one max|.| slot per concatenation buffer: the encoder block and the transposed conv that fill its halves both measure into it
-        sh4, sh3, sh2, sh1 = (ops.AmaxShare(dev) for _ in range(4))
+        sh4, sh3, sh2, sh1 = (ops.AmaxShare(dev, buf=b_) for b_ in (buf4, buf3, buf2, buf1))
 
         # (an encoder output feeds the pool and the skip concatenation: maxpool2x2_with_skip hands back an alias for the skip, and the
         #  pool's backward kernel adds the skip's gradient itself)

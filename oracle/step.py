@@ -98,14 +98,25 @@ def reconstruct(st: TrainState, rgbd, target_amp, target_phs, plane_indices):
 
 
 # --------------------------------------------------------------------------- A12
-def train_step(st: TrainState, rgbd, target_amp, target_phs, w: LossWeights, plane_indices, gp_alphas):
+def _grads_of(sd):
+    return {k: v.grad.detach().clone() for k, v in sd.items() if isinstance(v, torch.Tensor) and v.requires_grad and v.grad is not None}
+
+
+def _weights_of(sd):
+    return {k: v.detach().clone() for k, v in sd.items() if isinstance(v, torch.Tensor) and v.requires_grad}
+
+
+def train_step(st: TrainState, rgbd, target_amp, target_phs, w: LossWeights, plane_indices, gp_alphas, capture: bool = False):
     """One batch of ``watermelon.train``. ref: watermelon.py:207-277.
 
-    Returns a dict of python floats (losses) plus the tensors needed for parity checks.
+    Returns a dict of python floats (losses) plus the tensors needed for parity checks.  ``capture``: also the per-parameter gradients
+    of both models as the optimisers see them — ``grads_D`` (one dict per critic update, taken between ``d_loss.backward()`` and
+    ``optimizer_D.step()``, ref: watermelon.py:252-256) and ``grads_G`` (between ``G_loss.backward()`` and ``optimizer_G.step()``,
+    ref: watermelon.py:275-277) — and the post-Adam weights ``weights_D`` / ``weights_G``.
     """
     poh, hat_amps, target_amps, hat_phs, target_phs_z = reconstruct(st, rgbd, target_amp, target_phs, plane_indices)
 
-    d_losses = []
+    d_losses, grads_D = [], []
     for it in range(w.d_ratio):
         real_v = nets.critic(st.sd_D, target_amps, True)
         fake_v = nets.critic(st.sd_D, hat_amps.detach(), True)
@@ -113,6 +124,8 @@ def train_step(st: TrainState, rgbd, target_amp, target_phs, w: LossWeights, pla
         d_loss = (-real_v.mean() + fake_v.mean()) + w.gp_lambda * gp
         st.opt_D.zero_grad()
         d_loss.backward(retain_graph=True)
+        if capture:
+            grads_D.append(_grads_of(st.sd_D))
         st.opt_D.step()
         d_losses.append((d_loss.item(), gp.item()))
 
@@ -120,9 +133,12 @@ def train_step(st: TrainState, rgbd, target_amp, target_phs, w: LossWeights, pla
     terms = generator_loss(hat_amps, target_amps, hat_phs, target_phs_z, adversarial, w)
     st.opt_G.zero_grad()
     terms["G_loss"].backward()
+    grads_G = _grads_of(st.sd_G) if capture else None
     st.opt_G.step()
 
     out = {k: v.item() for k, v in terms.items()}
+    if capture:
+        out.update(grads_D=grads_D, grads_G=grads_G, weights_D=_weights_of(st.sd_D), weights_G=_weights_of(st.sd_G))
     out["D_loss"] = sum(d for d, _ in d_losses) / max(w.d_ratio, 1)
     out["d_iters"] = d_losses
     out["POH"] = poh.detach()

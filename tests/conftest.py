@@ -51,7 +51,7 @@ def oracle_full_step():
     idx = torch.tensor([17, 3, 11, 6])
     alphas = [torch.tensor([0.2, 0.9, 0.55, 0.4]).view(B, 1, 1, 1)]
     st = step.make_state(rows, cols, pad, coef, stack, seeded.generator_state_dict(), seeded.critic_state_dict())
-    ref = step.train_step(st, rgbd, tamp, tphs, step.LossWeights(d_ratio=1), idx, alphas)
+    ref = step.train_step(st, rgbd, tamp, tphs, step.LossWeights(d_ratio=1), idx, alphas, capture=True)
     cfg = dict(rows=rows, cols=cols, pad=pad, coef=coef, stack=stack, rgbd=rgbd, tamp=tamp, tphs=tphs, idx=idx, alphas=alphas)
     return cfg, ref
 
@@ -71,11 +71,12 @@ def oracle_full_step_fp64(oracle_full_step):
     st = step.TrainState(o64, st32.H_fixed.to(torch.complex128), st32.H_stack.to(torch.complex128),
                          step.nets.as_parameters(dbl(seeded.generator_state_dict())), step.nets.as_parameters(dbl(seeded.critic_state_dict())))
     return step.train_step(st, cfg["rgbd"].double(), cfg["tamp"].double(), cfg["tphs"].double(), step.LossWeights(d_ratio=1), cfg["idx"],
-                           [a.double() for a in cfg["alphas"]])
+                           [a.double() for a in cfg["alphas"]], capture=True)
 
 
 def rel_err(a, b):
-    """max|a-b| / max|b| — the fp32 parity measure used throughout (north_star: 1e-4)."""
+    """max|a-b| / max|b| — the fp32 parity measure used throughout (north_star: 1e-4).  A MAX-NORM ratio (the largest deviation over
+    the largest reference magnitude), not an element-wise relative error: small elements are held to the tensor's scale."""
     a, b = torch.as_tensor(a), torch.as_tensor(b)
     denom = b.abs().max().clamp_min(1e-30)
     return ((a - b).abs().max() / denom).item()

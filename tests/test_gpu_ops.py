@@ -248,6 +248,115 @@ def test_bn_kernels_leave_the_per_channel_maxima_of_what_they_write(ops):
         assert all(torch.equal(a, b) for a, b in zip(*res)), (C, pixels)
 
 
+FUSED_CASES = ((64, 4 * 96 * 96, 1), (256, 4 * 24 * 24, 2), (1024, 4 * 6 * 6, 1), (32, 1000, 0), (2048, 37, 2), (64, 8 * 192 * 192, 2), (96, 70001, 1),
+               (4, 5000, 0), (512, 2 * 48 * 48, 1))
+
+
+def test_fused_batch_norm_calls_equal_the_unfused_ones(ops):
+    """ABI 9: lhg_bn_forward_train / lhg_bn_backward_fused / lhg_bn_backward_backward_fused / lhg_channel_sum_fused /
+    lhg_channel_absmax_fused finish their reductions inside the launch that writes the partial rows (two-level last-arriver fold,
+    fixed order, double accumulation).  Against the unfused entry points on the same data: statistics, sums and parameter gradients agree to
+    fp32 rounding of the final cast (<= 2 ulp; the fold order of the partial rows differs), everything element-wise (y, gx, gres) is
+    computed from them by the same kernel; per-channel maxima are EXACT; the tickets are back at zero after every call; fifty repeats of
+    each call give the same bits (the result does not depend on which workgroup arrives last)."""
+    from learned_hologram_gan_amd.native import call, load, ptr, stream_ptr
+
+    lib = load()
+    ws = torch.empty((int(lib.lhg_fused_workspace_floats()),), device=DEV)
+    tickets = torch.zeros((int(lib.lhg_fused_ticket_count()),), dtype=torch.int32, device=DEV)
+
+    def close(a, b, what, rtol=1e-6):
+        scale = b.abs().max().item() + 1e-30
+        err = (a.double() - b.double()).abs().max().item() / scale
+        assert err <= rtol, (what, err)
+
+    for C, pixels, act in FUSED_CASES:
+        torch.manual_seed(C + pixels)
+        ld = C if C % 32 else C + 32  # a channel slice of a wider buffer
+        xb = torch.randn((pixels, ld), device=DEV) * torch.logspace(-3, 2, ld, device=DEV) + torch.linspace(-5, 5, ld, device=DEV)
+        x = xb[:, :C]
+        gamma, beta = torch.randn(C, device=DEV), torch.randn(C, device=DEV)
+        res = torch.randn((pixels, C), device=DEV) if act == 1 else None
+        # ---- forward: unfused reference
+        stats0, rm0, rv0 = torch.empty(2 * C, device=DEV), torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+        y0 = torch.empty((pixels, C), device=DEV)
+        w0 = torch.empty((8192 * C,), device=DEV)
+        call("lhg_bn_stats", ptr(x), pixels, C, ld, ptr(stats0), ptr(rm0), ptr(rv0), 0.1, 1e-5, ptr(w0), stream_ptr())
+        call("lhg_bn_apply", ptr(x), ld, pixels, C, ptr(stats0), ptr(gamma), ptr(beta), ptr(res), C, act, 0.2, ptr(y0), C, None, stream_ptr())
+        outs = []
+        for rep in range(50 if pixels < 200000 else 5):
+            stats1, rm1, rv1 = torch.empty(2 * C, device=DEV), torch.zeros(C, device=DEV), torch.ones(C, device=DEV)
+            y1, amax, cvec = torch.empty((pixels, C), device=DEV), torch.zeros(1, device=DEV), torch.full((C,), 123.0, device=DEV)
+            call("lhg_bn_forward_train", ptr(x), ld, pixels, C, ptr(gamma), ptr(beta), ptr(rm1), ptr(rv1), 0.1, 1e-5, ptr(res), C, act, 0.2, ptr(y1), C,
+                 ptr(stats1), ptr(amax), ptr(cvec) if C % 4 == 0 else None, 1, ptr(ws), ptr(tickets), stream_ptr())
+            outs.append((stats1, rm1, rv1, y1, amax, cvec))
+        assert int(tickets.abs().sum().item()) == 0
+        for o in outs[1:]:
+            assert all(torch.equal(a, b) for a, b in zip(outs[0], o)), ("forward repeat", C, pixels)
+        stats1, rm1, rv1, y1, amax, cvec = outs[0]
+        close(stats1[:C], stats0[:C], ("mean", C, pixels))
+        close(stats1[C:] / stats0[C:], torch.ones_like(stats0[C:]), ("invstd", C, pixels), 1e-6)
+        close(rm1, rm0, ("running_mean", C, pixels))
+        close(rv1, rv0, ("running_var", C, pixels), 1e-6)
+        # the apply kernel is the same: with the reference's statistics it gives the reference's bits
+        call("lhg_bn_apply", ptr(x), ld, pixels, C, ptr(stats1), ptr(gamma), ptr(beta), ptr(res), C, act, 0.2, ptr(y0), C, None, stream_ptr())
+        assert torch.equal(y0, y1), (C, pixels)
+        assert amax.item() == y1.abs().max().item() and torch.equal(cvec, y1.abs().amax(dim=0)), (C, pixels)
+        if C % 4 == 0:  # chanmax_finish = 0 (the op layer's default): the apply launch leaves partial rows, a finish launch folds them later
+            rows = int(lib.lhg_chanmax_partial_rows(pixels, C))
+            part, y2, fin = torch.full((rows * C,), float("nan"), device=DEV), torch.empty_like(y1), torch.full((C,), 5.0, device=DEV)
+            call("lhg_bn_forward_train", ptr(x), ld, pixels, C, ptr(gamma), ptr(beta), None, None, 0.1, 1e-5, ptr(res), C, act, 0.2, ptr(y2), C,
+                 ptr(stats1.clone()), None, ptr(part), 0, ptr(ws), ptr(tickets), stream_ptr())
+            call("lhg_channel_absmax_finish", ptr(part), pixels, C, ptr(fin), stream_ptr())
+            assert torch.equal(y2, y1) and torch.equal(fin, cvec), (C, pixels)
+        # ---- backward
+        gy = torch.randn((pixels, C), device=DEV) * torch.logspace(2, -4, C, device=DEV)
+        want_res = res is not None
+        gx0, gr0, gg0, gb0 = torch.empty_like(y0), torch.empty_like(y0), torch.empty(C, device=DEV), torch.empty(C, device=DEV)
+        call("lhg_bn_backward", ptr(gy), C, ptr(x), ld, ptr(y1), C, pixels, C, ptr(stats1), ptr(gamma), act, 0.2, ptr(gx0), C, ptr(gr0) if want_res else None, C,
+             ptr(gg0), ptr(gb0), 0, ptr(w0), None, ptr(beta), stream_ptr())
+        outs = []
+        for rep in range(50 if pixels < 200000 else 5):
+            gx1, gr1 = torch.empty_like(y0), torch.empty_like(y0)
+            gg1, gb1 = torch.full((C,), 2.0, device=DEV), torch.full((C,), -3.0, device=DEV)  # accumulate = 1 adds to these
+            am, amr = torch.zeros(1, device=DEV), torch.zeros(1, device=DEV)
+            cv, cvr = torch.full((C,), 7.0, device=DEV), torch.full((C,), 7.0, device=DEV)
+            call("lhg_bn_backward_fused", ptr(gy), C, ptr(x), ld, ptr(y1), C, pixels, C, ptr(stats1), ptr(gamma), ptr(beta), act, 0.2, ptr(gx1), C,
+                 ptr(gr1) if want_res else None, C, ptr(gg1), ptr(gb1), 1, ptr(am), ptr(amr) if want_res else None, ptr(cv),
+                 ptr(cvr) if want_res else None, 1, ptr(ws), ptr(tickets), stream_ptr())
+            outs.append((gx1, gr1 if want_res else gx1, gg1, gb1, am, cv, cvr if want_res else cv))
+        assert int(tickets.abs().sum().item()) == 0
+        for o in outs[1:]:
+            assert all(torch.equal(a, b) for a, b in zip(outs[0], o)), ("backward repeat", C, pixels)
+        gx1, gr1, gg1, gb1, am, cv, cvr = outs[0]
+        close(gg1 - 2.0, gg0, ("ggamma", C, pixels), 2e-6)
+        close(gb1 + 3.0, gb0, ("gbeta", C, pixels), 2e-6)
+        close(gx1, gx0, ("gx", C, pixels), 2e-6)
+        assert am.item() == gx1.abs().max().item() and torch.equal(cv, gx1.abs().amax(dim=0)), (C, pixels)
+        if want_res:
+            assert torch.equal(gr1, gr0) and torch.equal(cvr, gr1.abs().amax(dim=0)), (C, pixels)
+        # ---- double backward (dense tensors)
+        if pixels < 200000:
+            xd, ggx = x.contiguous(), torch.randn((pixels, C), device=DEV)
+            r0 = [torch.empty_like(y0), torch.empty_like(y0), torch.empty(C, device=DEV)]
+            r1 = [torch.empty_like(y0), torch.empty_like(y0), torch.empty(C, device=DEV)]
+            w2 = torch.empty(((5 * 4096 + 8) * C,), device=DEV)
+            call("lhg_bn_backward_backward", ptr(ggx), ptr(gy), ptr(xd), ptr(y1), pixels, C, ptr(stats1), ptr(gamma), act, 0.2, *map(ptr, r0), ptr(w2), stream_ptr())
+            call("lhg_bn_backward_backward_fused", ptr(ggx), ptr(gy), ptr(xd), ptr(y1), pixels, C, ptr(stats1), ptr(gamma), act, 0.2, *map(ptr, r1), ptr(ws),
+                 ptr(tickets), stream_ptr())
+            for a, b, what in zip(r1, r0, ("ggy", "gx2", "ggamma2")):
+                close(a, b, (what, C, pixels), 5e-6)
+        # ---- channel sum / channel maxima in one launch
+        s0, s1 = torch.full((C,), 1.5, device=DEV), torch.full((C,), 1.5, device=DEV)
+        call("lhg_channel_sum", ptr(x), pixels, C, ld, ptr(s0), 1, ptr(w0), stream_ptr())
+        call("lhg_channel_sum_fused", ptr(x), pixels, C, ld, ptr(s1), 1, ptr(ws), ptr(tickets), stream_ptr())
+        close(s1, s0, ("channel_sum", C, pixels), 1e-6)
+        m1 = torch.full((C,), 9.0, device=DEV)
+        call("lhg_channel_absmax_fused", ptr(x), pixels, C, ld, ptr(m1), ptr(ws), ptr(tickets), stream_ptr())
+        assert torch.equal(m1, x.abs().amax(dim=0)), (C, pixels)
+        assert int(tickets.abs().sum().item()) == 0
+
+
 def test_wgrad_slab_reduce_is_the_documented_sum_bit_for_bit(ops):
     """lhg_wgrad_reduce on nine-tap slabs:
     grad[d0][d1][t] (+)= the four (small weights: sixteen) interleaved slab slices summed in ascending order and combined in order — emulated here with fp32 torch

@@ -547,6 +547,18 @@ def test_full_size_train_step_vs_oracle(oracle_full_step):
     # reconstruction quality metric of the north star: PSNR of the GPU reconstruction against the oracle reconstruction
     mse = ((out["hat_amps"].cpu() - ref["hat_amps"]) ** 2).mean()
     assert 10 * torch.log10(ref["hat_amps"].max() ** 2 / mse) > 70.0
+    # post-Adam weights of both models at the bench size, bounded as test_train_step_against_reference_loop bounds
+    # them: Adam's first step moves every weight by ~lr * sign(g), so a gradient within rounding noise of zero may come out with the other
+    # sign and its weight then differs by at most 2 lr — such weights must be few and bounded, everything else must agree
+    lr = 1e-3
+    for sd, post in ((W.discriminator.state_dict(), ref["weights_D"]), (W.generator.state_dict(), ref["weights_G"])):
+        for k, v in post.items():
+            if k.endswith(("convolution_layer_1.bias", "convolution_layer_2.bias", "block2.0.bias", "block3.0.bias", "block4.0.bias", "block5.0.bias", "block6.0.bias")):
+                continue  # analytically zero gradient (conv bias in front of a train-mode BatchNorm): Adam turns rounding noise into +-lr
+            d = (sd[k].cpu() - v).abs()
+            bad = d > 2e-4 + 1e-3 * v.abs()
+            assert bad.float().mean().item() <= max(5e-3, 6.0 / v.numel()), (k, int(bad.sum()), v.numel())
+            assert not bad.any() or d[bad].max().item() <= 2.1 * lr, (k, d[bad].max().item())
 
 
 def test_perceptual_loss_vs_oracle(tmp_path):

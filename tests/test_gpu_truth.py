@@ -21,7 +21,7 @@ DEV = "cuda:0"
 WL = torch.tensor([638e-9, 520e-9, 450e-9])
 PITCH = 3.74e-6
 # GPU fp32 error <= K x CPU fp32 error (+ a floor of a few fp32 ulps of the output scale), every (e_gpu, e_cpu) pair kept in
-# profiles/r03_truth_tests.jsonl.  Measured over the three fp32-tensor GEMM modes (exact fp32 MFMA, the default fp16x2 split, bf16x3 split):
+# profiles/r05_truth_tests.jsonl (r03 / r04: earlier builds).  Measured over the three fp32-tensor GEMM modes (exact fp32 MFMA, the default fp16x2 split, bf16x3 split):
 #   K     = 3   forward statistics that average over the tensor (hologram 99.9 % quantile, amplitudes in L2): ratios 1.2 - 2.3, one 2.96
 #   KMAX  = 8   MAX norms of forward quantities: one pixel next to a zero of the field, where two rounding realisations differ by more
 #               (0.7 - 3.6 in the exact and the default mode, 5.8 in the bf16x3 mode); the scalar losses of the step
@@ -35,11 +35,12 @@ K = 3.0
 KMAX = 8.0
 KGRAD = 5.0
 KPAR = 12.0
+KPAR_TINY = 20.0  # test_generator_tail_vs_fp64_truth: batch statistics over 72 - 256 samples (see there)
 MODES = ("fp32_split_f16", "fp32", "fp32_split")
 # written by the tests themselves; gpurun_out/ is what travels back from the GPU box, tools/collect_records.py stamps the file with the
 # revision and moves it to profiles/ (no hand copy)
 RECORD = os.path.join(os.environ.get("LHG_RECORD_DIR") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"),
-                      "r04_truth_tests.jsonl")
+                      "r05_truth_tests.jsonl")
 
 
 def _record(test, mode, notes=None, **values):
@@ -60,6 +61,36 @@ def gemm_mode(request):
         yield request.param
     finally:
         hip_ops.set_conv_precision("default")
+
+
+ZERO_BY_CONSTRUCTION = ("convolution_layer_1.bias", "convolution_layer_2.bias", "block2.0.bias", "block3.0.bias", "block4.0.bias", "block5.0.bias",
+                        "block6.0.bias")  # conv biases in front of a train-mode BatchNorm: analytically zero gradient, rounding noise in fp32
+SMALL = 16  # parameters with fewer elements than this are scored as ONE group (see _score_param_grads)
+
+
+def _score_param_grads(grad_gpu, g64, g32):
+    """Per-parameter relative L2 distance to the float64 gradient, GPU and CPU-fp32 -> (checks, ranked, rows).
+
+    Rule (KPAR): a parameter with >= SMALL elements must satisfy e_gpu <= KPAR * e_cpu + 1e-4 by itself.  The handful of parameters with
+    fewer elements — the three-tap symmetric stencils and their scalar biases (AP2POH.py:107-110), the critic head's scalar bias — are
+    sums over every pixel with heavy cancellation and ONE to three numbers each: e_cpu of such a parameter is a single draw of the rounding
+    noise, and the ratio of two single draws is heavy-tailed (the same parameter, `part2.part1.conv_g.bias` at 64^2: 5.4 in the default
+    mode and 10.9 with the exact fp32 MFMA kernels in round 4, 23.6 in round 5 after the BatchNorm sums were folded in another order — a
+    1-ulp change of the statistics).  They are therefore scored TOGETHER: root-mean-square of e_gpu over the group against KPAR times the
+    root-mean-square of e_cpu (+ 1e-4).  Every (name, e_gpu, e_cpu) is still recorded."""
+    rows = []
+    for k, t64 in g64.items():
+        if k.endswith(ZERO_BY_CONSTRUCTION) or float(t64.norm()) == 0.0 or k not in grad_gpu:
+            continue
+        rows.append((k, _l2(grad_gpu[k], t64), _l2(g32[k], t64), float(t64.double().norm()), t64.numel()))
+    big = [r for r in rows if r[4] >= SMALL]
+    small = [r for r in rows if r[4] < SMALL]
+    checks = [(k, eg, ec) for k, eg, ec, _, _ in big]
+    if small:
+        rms = lambda v: (sum(x * x for x in v) / len(v)) ** 0.5  # noqa: E731
+        checks.append(("<%d-element parameters: %s>" % (SMALL, ", ".join(r[0] for r in small)), rms([r[1] for r in small]), rms([r[2] for r in small])))
+    ranked = sorted(rows, key=lambda r: r[1] / max(r[2], 1e-12), reverse=True)
+    return checks, ranked, rows
 
 
 def _phase_dist(a, b):
@@ -114,20 +145,20 @@ def test_generator_tail_vs_fp64_truth(rows, pad, batch, gemm_mode):
            "amp_max": (rel_err(amp.detach().cpu().double(), amp64), rel_err(amp32, amp64)), "amp_l2": (_l2(amp.detach().cpu(), amp64), _l2(amp32, amp64)),
            "dx_l2": (_l2(x.grad.cpu(), dx64), _l2(dx32, dx64))}
     named = dict(G.named_parameters())
-    worst, worst_key = 0.0, None
-    for k, g64 in gw64.items():
-        if k.endswith(("convolution_layer_1.bias", "convolution_layer_2.bias")) or g64.norm() == 0:
-            continue  # analytically zero (feeds a train-mode BatchNorm)
-        e_g, e_c = _l2(named[k].grad.cpu(), g64), _l2(gw32[k], g64)
-        if e_g / max(e_c, 1e-12) > worst:
-            worst, worst_key, worst_name = e_g / max(e_c, 1e-12), (e_g, e_c), k
-    rec["param_grad_l2_worst_ratio"] = worst_key
+    checks, ranked, _ = _score_param_grads({k: p_.grad.cpu() for k, p_ in named.items() if p_.grad is not None}, gw64, gw32)
+    worst_name, worst_g, worst_c = max(checks, key=lambda c: c[1] / max(c[2], 1e-12))
+    rec["param_grad_l2_worst_ratio"] = (worst_g, worst_c)
     # the three parameters furthest from the truth relative to the CPU, by NAME (the record kept only the ratio)
-    ranked = sorted(((_l2(named[k].grad.cpu(), g64) / max(_l2(gw32[k], g64), 1e-12), k, _l2(named[k].grad.cpu(), g64), _l2(gw32[k], g64), float(g64.norm()))
-                     for k, g64 in gw64.items() if not k.endswith(("convolution_layer_1.bias", "convolution_layer_2.bias")) and g64.norm() != 0), reverse=True)[:3]
-    _record(f"generator_tail[{rows}]", gemm_mode, notes={"worst_parameters": [{"name": k, "ratio": r, "e_gpu": eg, "e_cpu": ec, "norm": nn} for r, k, eg, ec, nn in ranked]}, **rec)
-    assert worst > 0
-    assert worst_key[0] <= KPAR * worst_key[1] + 1e-4, (worst_name, worst_key)
+    _record(f"generator_tail[{rows}]", gemm_mode, notes={"worst_parameters": [{"name": k, "ratio": eg / max(ec, 1e-12), "e_gpu": eg, "e_cpu": ec, "norm": nn, "numel": ne}
+                                                                               for k, eg, ec, nn, ne in ranked[:3]], "worst_check": worst_name}, **rec)
+    # Every parameter, not only the one with the worst ratio (rounds 3 - 4 asserted KPAR for that one alone, which the + 1e-4 floor covered).
+    # At THESE sizes the deep layers normalise over 72 (96^2, batch 2) to 256 (64^2, batch 4) samples per channel, and their gradients are
+    # the worst conditioned of the net: the bottleneck block's parameters sit 12 - 16 x the CPU's error from float64 in the default mode
+    # (round 4's records already: `bottleneck.1.0.batch_norm_layer_1.bias` 16.2, `...convolution_layer_1.weight` 12.4 at 96^2), 3 - 5 x with
+    # the exact fp32 MFMA kernels.  KPAR_TINY bounds them here; the bench size (2304 samples per channel at the bottleneck) is held to KPAR
+    # by test_full_size_step_vs_fp64_truth.
+    for name, eg, ec in checks:
+        assert eg <= KPAR_TINY * ec + 1e-4, (name, eg, ec)
     assert rec["poh_q999"][0] <= K * rec["poh_q999"][1] + 1e-5, rec
     assert rec["poh_max"][0] <= KMAX * rec["poh_max"][1] + 1e-3, rec
     assert rec["amp_l2"][0] <= K * rec["amp_l2"][1] + 2e-6, rec
@@ -227,7 +258,25 @@ def test_full_size_step_vs_fp64_truth(oracle_full_step, oracle_full_step_fp64, g
         rec[key + "_l2"] = (_l2(out[key].cpu(), ref64[key]), _l2(ref32[key], ref64[key]))
     for key in ("focal_phase_gradient_loss", "pixel_loss", "TV_loss", "gan_loss", "G_loss", "D_loss"):
         rec[key] = (abs(got[key] - ref64[key]) / abs(ref64[key]), abs(ref32[key] - ref64[key]) / abs(ref64[key]))
-    _record("full_size_step", gemm_mode, **rec)
+    # ---- gradients at the BENCH size: every parameter's gradient of both models as the optimisers saw it (the flat
+    # buffers still hold them after the Adam steps), relative L2 against the float64 evaluation, next to the CPU-fp32 evaluation's
+    notes = {}
+    grad_checks = []
+    for tag, model, g64, g32 in (("G", W.generator, ref64["grads_G"], ref32["grads_G"]), ("D", W.discriminator, ref64["grads_D"][0], ref32["grads_D"][0])):
+        grads = {k: p_.grad.detach().cpu() for k, p_ in model.named_parameters() if p_.grad is not None}
+        checks, ranked, rows_ = _score_param_grads(grads, g64, g32)
+        assert len(rows_) >= (80 if tag == "G" else 12), (tag, len(rows_))
+        notes[f"worst_parameters_{tag}"] = [{"name": k, "ratio": eg / max(ec, 1e-12), "e_gpu": eg, "e_cpu": ec, "norm": nn, "numel": ne} for k, eg, ec, nn, ne in ranked[:3]]
+        flat64 = torch.cat([g64[r[0]].flatten().double() for r in rows_])
+        rec[f"grad_{tag}_l2"] = (_l2(torch.cat([grads[r[0]].flatten() for r in rows_]), flat64), _l2(torch.cat([g32[r[0]].flatten() for r in rows_]), flat64))
+        worst = max(checks, key=lambda c: c[1] / max(c[2], 1e-12))
+        rec[f"grad_{tag}_worst_parameter"] = (worst[1], worst[2])
+        grad_checks += [(tag, *c) for c in checks]
+    _record("full_size_step", gemm_mode, notes=notes, **rec)
+    for tag, name, eg, ec in grad_checks:
+        assert eg <= KPAR * ec + 1e-4, (tag, name, eg, ec)
+    for tag in ("G", "D"):  # all parameters of a model as one vector: the KGRAD rule of the input gradient
+        assert rec[f"grad_{tag}_l2"][0] <= KGRAD * rec[f"grad_{tag}_l2"][1] + 1e-5, (tag, rec[f"grad_{tag}_l2"])
     assert rec["poh_q999"][0] <= K * rec["poh_q999"][1] + 1e-5, rec
     assert rec["poh_max"][0] <= KMAX * rec["poh_max"][1] + 1e-3, rec
     for key in ("hat_amps", "target_amps"):

@@ -1,6 +1,6 @@
 """Which Python call sites launch the ATen kernels of one train step (torch.profiler, one step): op name, count, CUDA time, innermost repo frame."""
 import sys, os, collections
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from torch.profiler import profile, ProfilerActivity
 from learned_hologram_gan_amd.watermelon_hologram.watermelon import watermelon
@@ -16,10 +16,13 @@ with profile(activities=[ProfilerActivity.CPU, ProfilerActivity.CUDA], with_stac
     W.train_step(rgbd, tamp, tphs)
     torch.cuda.synchronize()
 rows = []
-for ev in prof.key_averages(group_by_input_shape=True):
+for ev in prof.key_averages(group_by_input_shape=True, group_by_stack_n=12):
     st = getattr(ev, "self_device_time_total", 0) or getattr(ev, "self_cuda_time_total", 0)
     if not ev.key.startswith("aten::") or st <= 0:
         continue
-    rows.append((st, ev.count, ev.key, str(ev.input_shapes)[:110]))
-for st, n, name, shp in sorted(rows, reverse=True)[:40]:
-    print(f"{n:4d} {st:9.1f} us  {name:24s} {shp}")
+    frames = [f for f in (ev.stack or []) if "learned_hologram_gan_amd" in f or "bench.py" in f]
+    where = " < ".join(f.split("learned_hologram_gan_amd/")[-1].strip() for f in frames[:3])
+    rows.append((ev.count, st, ev.key, str(ev.input_shapes)[:70], where[:200]))
+print("device-launching ATen ops of one train step, by call site:", sum(r[0] for r in rows), "launching ops")
+for n, st, name, shp, where in sorted(rows, reverse=True)[:80]:
+    print(f"{n:4d} {st:9.1f} us  {name:22s} {shp:70s} {where}")
