@@ -454,6 +454,15 @@ int lhg_double_phase_encode_backward(const float* g_poh, const float* mod, const
 int lhg_symconv_field_backward(const float* g_mod, const float* field, int planes, int rows, int cols, const float* taps,
                                float* g_field, float* partial, lhg_stream_t s);
 
+/* ABI 9: the pointwise Jacobians at the two ends of the (linear) angular-spectrum operator, one launch each (they were ~25 torch
+ * elementwise launches per operator call).  ref: the autograd of abs() / angle() / amp * exp(1j * phase) at angular_spectrum_method.py:374-392, 533-552.
+ *   output side: gz (n complex64) = scale * ( g_abs * z / |z| + g_angle * (-Im z, Re z) / |z|^2 ), zero where z == 0; either cotangent may be NULL;
+ *   input side:  u = a * exp(i s phi) with cotangent g = pre_scale * g_in: g_a = Re(conj(e) g), g_phi = Im(conj(e) g) * a * s, e = exp(i s phi);
+ *                phi == NULL (phase-only input u = exp(i s a)): g_a = Im(conj(e) g) * s. */
+int lhg_polar_output_cotangent(const float* z, const float* g_abs, const float* g_angle, float scale, float* gz, long long n, lhg_stream_t s);
+int lhg_polar_input_cotangent(const float* g_in, const float* a, const float* phi, float phase_scale, float pre_scale,
+                              float* g_a, float* g_phi, long long n, lhg_stream_t s);
+
 /* ------------------------------------------------------------------ reconstruction losses (A13), fused
  * (focal sin/cos phase-gradient, pixel MSE, |TV(hat) - TV(target)|) of (planes,H,W) fp32 amplitudes / phases.
  * ref: loss_func.py:66-98, 135-163; watermelon.py:418-445.  sums9: the nine global reductions (kept for backward),

@@ -24,6 +24,7 @@ from .native import (F_DIV, F_DIV_CONJ, F_MUL, F_MUL_CONJ, F_NONE, IN_COMPLEX, I
 _ADJOINT_OP = {F_NONE: F_NONE, F_MUL: F_MUL_CONJ, F_MUL_CONJ: F_MUL, F_DIV: F_DIV_CONJ, F_DIV_CONJ: F_DIV}
 
 _twiddle_cache: dict = {}
+_FUSED_JACOBIANS = os.environ.get("LHG_FUSED_JACOBIANS", "1") != "0"  # 0: the torch expressions in every backward (A/B measurements)
 
 
 def twiddles(n: int, device) -> torch.Tensor:
@@ -218,11 +219,26 @@ def from_spectrum_raw(S, spec: Spec, want_complex_copy=False):
 
 
 # --------------------------------------------------------------------------- Jacobians at the two ends
-def _output_cotangent(spec, z, g_a, g_b, g_c):
-    """Cotangent of the complex field z from the cotangents of the requested outputs
+def _fused_jacobians(*tensors) -> bool:
+    """The one-launch Jacobian kernels (lhg_polar_*_cotangent) serve plain backward passes on the GPU; a backward that is itself being
+    recorded (double backward) keeps the differentiable torch expressions below."""
+    return _FUSED_JACOBIANS and not torch.is_grad_enabled() and all(t is None or (t.is_cuda and t.dtype in (torch.float32, torch.complex64)) for t in tensors)
+
+
+def _output_cotangent(spec, z, g_a, g_b, g_c, scale=1.0):
+    """``scale`` times the cotangent of the complex field z from the cotangents of the requested outputs
     (PyTorch convention: grad of a complex tensor = dL/dRe + i dL/dIm)."""
     if spec.out_mode == OUT_COMPLEX:
-        return g_c
+        return g_c if scale == 1.0 or g_c is None else g_c * scale
+    if g_a is None and g_b is None:
+        return None
+    if _fused_jacobians(z, g_a, g_b):
+        z = z.contiguous()
+        g_a = g_a.contiguous() if g_a is not None else None
+        g_b = g_b.contiguous() if g_b is not None else None
+        gz = torch.empty_like(z)
+        call("lhg_polar_output_cotangent", ptr(torch.view_as_real(z)), ptr(g_a), ptr(g_b), float(scale), ptr(torch.view_as_real(gz)), z.numel(), stream_ptr())
+        return gz
     mag2 = z.real * z.real + z.imag * z.imag
     safe = mag2 > 0
     total = None
@@ -233,13 +249,24 @@ def _output_cotangent(spec, z, g_a, g_b, g_c):
         inv2 = torch.where(safe, 1.0 / mag2.clamp_min(1e-45), torch.zeros_like(mag2))
         t = torch.complex(-g_b * z.imag * inv2, g_b * z.real * inv2)
         total = t if total is None else total + t
-    return total
+    return total if scale == 1.0 or total is None else total * scale
 
 
-def _input_cotangent(spec, a, b, g_in):
-    """Cotangents of (a, b) from the cotangent of the complex input field."""
+def _input_cotangent(spec, a, b, g_in, pre_scale=1.0):
+    """Cotangents of (a, b) from ``pre_scale`` times the cotangent g_in of the complex input field."""
     if spec.in_mode == IN_COMPLEX:
-        return g_in, None
+        return (g_in if pre_scale == 1.0 else g_in * pre_scale), None
+    if _fused_jacobians(g_in, a, b):
+        g_in, a = g_in.contiguous(), a.contiguous()
+        polar = spec.in_mode == IN_POLAR
+        b = b.contiguous() if polar else None
+        ga = torch.empty_like(a)
+        gb = torch.empty_like(a) if polar else None
+        call("lhg_polar_input_cotangent", ptr(torch.view_as_real(g_in)), ptr(a), ptr(b), float(spec.phase_scale), float(pre_scale), ptr(ga), ptr(gb),
+             a.numel(), stream_ptr())
+        return ga, gb
+    if pre_scale != 1.0:
+        g_in = g_in * pre_scale
     phs = (b if spec.in_mode == IN_POLAR else a) * spec.phase_scale
     c, s = torch.cos(phs), torch.sin(phs)
     radial = g_in.real * c + g_in.imag * s  # Re(conj(u) g)
@@ -292,8 +319,7 @@ class ToSpectrumFn(Function):
         g = spec.geom
         adj = Spec(g, IN_COMPLEX, OUT_COMPLEX, 1.0, tuple(f.adjoint() for f in spec.factors))
         _, _, g_in = FromSpectrumFn.apply(gS.contiguous(), adj)
-        g_in = g_in * float(g.rows * g.cols)  # FFT2^H = (R*C) * IFFT2
-        ga, gb = _input_cotangent(spec, a, b, g_in)
+        ga, gb = _input_cotangent(spec, a, b, g_in, float(g.rows * g.cols))  # FFT2^H = (R*C) * IFFT2: folded into the Jacobian's launch
         return ga, (gb if b is not None else None), None
 
 
@@ -316,9 +342,10 @@ class FromSpectrumFn(Function):
         (z,) = ctx.saved_tensors
         spec = ctx.spec
         g = spec.geom
-        gz = _output_cotangent(spec, z, g_a, g_b, g_c)
+        # IFFT2^H = FFT2 / (R*C): the factor rides on the cropped cotangent (linear operator) instead of a pass over the full spectrum
+        gz = _output_cotangent(spec, z, g_a, g_b, g_c, 1.0 / float(g.rows * g.cols))
         if gz is None:
             return None, None
         adj = Spec(g, IN_COMPLEX, OUT_COMPLEX, 1.0, tuple(f.adjoint() for f in spec.factors))
-        gS = ToSpectrumFn.apply(gz.contiguous(), None, adj) / float(g.rows * g.cols)  # IFFT2^H = FFT2 / (R*C)
+        gS = ToSpectrumFn.apply(gz.contiguous(), None, adj)
         return gS, None

@@ -179,6 +179,53 @@ __global__ __launch_bounds__(256) void symconv_bwd_kernel(const float2* __restri
 
 static int plane_blocks(int rows, int cols) { return std::min(64, (rows * cols + 255) / 256); }
 
+// ------------------------------------------------------------------ polar <-> cartesian Jacobians at the two ends of the angular-spectrum operator
+// The operator itself is linear in the complex field (asm_ops.py); what its backward adds are the pointwise Jacobians of |z| / angle(z)
+// at the output and of a * exp(i s phi) at the input.  As torch expressions they were ~25 elementwise launches per operator call
+// (55 per train step); here one launch each.  Same formulas, same guards (asm_ops._output_cotangent / _input_cotangent).
+//   gz = scale * ( g_a * z / |z|  +  g_b * (-Im z, Re z) / |z|^2 ),   zero where z == 0      (PyTorch convention: dL/dRe + i dL/dIm)
+__global__ __launch_bounds__(256) void polar_out_cotangent_kernel(const float2* __restrict__ z, const float* __restrict__ g_a,
+                                                                  const float* __restrict__ g_b, float scale, float2* __restrict__ gz, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float2 v = z[i];
+    const float mag2 = v.x * v.x + v.y * v.y;
+    float2 o = make_float2(0.f, 0.f);
+    if (mag2 > 0.f) {
+      if (g_a) {
+        const float inv = rsqrtf(fmaxf(mag2, 1e-45f)), ga = g_a[i];
+        o.x = ga * v.x * inv;
+        o.y = ga * v.y * inv;
+      }
+      if (g_b) {
+        const float inv2 = 1.0f / fmaxf(mag2, 1e-45f), gb = g_b[i];
+        o.x += -gb * v.y * inv2;
+        o.y += gb * v.x * inv2;
+      }
+    }
+    gz[i] = make_float2(o.x * scale, o.y * scale);
+  }
+}
+// u = a * exp(i s phi) (polar: a amplitude, phi phase) or exp(i s a) (phase only: phi == nullptr), g = pre_scale * g_in:
+//   radial = Re(conj(e) g), tangential = Im(conj(e) g), e = exp(i s phi);   polar: (g_amp, g_phi) = (radial, tangential a s);  phase: g_a = tangential s
+__global__ __launch_bounds__(256) void polar_in_cotangent_kernel(const float2* __restrict__ g_in, const float* __restrict__ a,
+                                                                 const float* __restrict__ phi, float phase_scale, float pre_scale,
+                                                                 float* __restrict__ g_a, float* __restrict__ g_phi, size_t n) {
+  for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) {
+    const float2 g = g_in[i];
+    const float gre = g.x * pre_scale, gim = g.y * pre_scale;
+    const float av = a[i];
+    const float ph = (phi ? phi[i] : av) * phase_scale;
+    const float c = cosf(ph), sn = sinf(ph);
+    const float radial = gre * c + gim * sn, tangential = -gre * sn + gim * c;
+    if (phi) {
+      g_a[i] = radial;
+      g_phi[i] = tangential * av * phase_scale;
+    } else {
+      g_a[i] = tangential * phase_scale;
+    }
+  }
+}
+
 }  // namespace lhg
 
 using namespace lhg;
@@ -221,6 +268,23 @@ int lhg_symconv_field_backward(const float* g_mod, const float* field, int plane
                      reinterpret_cast<const float2*>(g_mod), reinterpret_cast<const float2*>(field), planes, rows, cols, taps,
                      reinterpret_cast<float2*>(g_field), partial);
   return check_launch("symconv_field_backward");
+}
+
+int lhg_polar_output_cotangent(const float* z, const float* g_abs, const float* g_angle, float scale, float* gz, long long n, lhg_stream_t s) {
+  LHG_REQUIRE(n > 0 && z != nullptr && gz != nullptr && (g_abs != nullptr || g_angle != nullptr), "polar_output_cotangent: missing tensor");
+  const int grid = (int)std::min<long long>((n + 255) / 256, 8192);
+  hipLaunchKernelGGL(polar_out_cotangent_kernel, dim3(grid), dim3(256), 0, as_stream(s), reinterpret_cast<const float2*>(z), g_abs, g_angle, scale,
+                     reinterpret_cast<float2*>(gz), (size_t)n);
+  return check_launch("polar_output_cotangent");
+}
+
+int lhg_polar_input_cotangent(const float* g_in, const float* a, const float* phi, float phase_scale, float pre_scale, float* g_a, float* g_phi,
+                              long long n, lhg_stream_t s) {
+  LHG_REQUIRE(n > 0 && g_in != nullptr && a != nullptr && g_a != nullptr && (phi == nullptr || g_phi != nullptr), "polar_input_cotangent: missing tensor");
+  const int grid = (int)std::min<long long>((n + 255) / 256, 8192);
+  hipLaunchKernelGGL(polar_in_cotangent_kernel, dim3(grid), dim3(256), 0, as_stream(s), reinterpret_cast<const float2*>(g_in), a, phi, phase_scale,
+                     pre_scale, g_a, g_phi, (size_t)n);
+  return check_launch("polar_input_cotangent");
 }
 
 }  // extern "C"

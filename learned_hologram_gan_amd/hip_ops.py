@@ -222,6 +222,7 @@ _GRAD_SLOTS: dict = {}
 _JOIN_QUEUED = False
 _SIDE_STREAMS: dict = {}
 SIDE_WGRAD = os.environ.get("LHG_SIDE_WGRAD", "1") != "0"
+_SIDE_BIAS = os.environ.get("LHG_SIDE_BIAS", "1") != "0"  # 0: bias gradients are summed on the main stream (A/B measurements)
 SLOT_ACCUMULATE = True  # False: weight gradients go back through autograd's own accumulation (A/B tests of the slot path)
 
 # Gradients that never pass through autograd's AccumulateGrad (slot-accumulated weight gradients, analytically-zero biases) are
@@ -1150,10 +1151,15 @@ def _bias_grad(bias, gy, is_zero, Co):
     slot = _small_grad_slot(bias)
     if slot is None:
         return channel_sum(gy)  # autograd accumulates it (and its post-accumulate hook reports the arrival)
-    if gy.shape[-1] % 4 == 0:
+    if gy.shape[-1] % 4 == 0 and not _SIDE_BIAS:
         channel_sum_into(gy, slot)
-    else:  # narrow heads (6 / 1 channels): a few hundred KB
-        slot.add_(gy.sum(dim=(0, 1, 2), dtype=torch.float32))
+        note_contribution(bias)
+        return None
+    if gy.shape[-1] % 4 == 0:
+        # nothing in backward waits for a bias gradient before the optimiser step: like the weight gradients it is accumulated on the
+        # second stream, beside the main chain (a pass over gy: 0.5 ms per step off the chain the step waits for)
+        return _weight_grad(bias, (gy,), lambda s_: channel_sum_into(gy, s_) if s_ is not None else channel_sum(gy))
+    slot.add_(gy.sum(dim=(0, 1, 2), dtype=torch.float32))  # narrow heads (6 / 1 channels): a few hundred KB
     note_contribution(bias)
     return None
 

@@ -99,6 +99,8 @@ _SIGNATURES = {
     "lhg_poh_partial_blocks": [_i, _i],
     "lhg_double_phase_encode_backward": [_p, _p, _p, _i, _i, _i, _p, _p, _p],
     "lhg_symconv_field_backward": [_p, _p, _i, _i, _i, _p, _p, _p, _p],
+    "lhg_polar_output_cotangent": [_p, _p, _p, _f, _p, _ll, _p],
+    "lhg_polar_input_cotangent": [_p, _p, _p, _f, _f, _p, _p, _ll, _p],
     "lhg_recon_loss_blocks": [_i, _i, _i],
     "lhg_recon_loss_forward": [_p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p],
     "lhg_recon_loss_backward": [_p, _p, _p, _p, _i, _i, _i, _p, _p, _p, _p, _p],

@@ -211,7 +211,7 @@ def test_config3_4k_generator_tail_and_eight_plane_propagation():
         poh_ref = nets.amp_phase_to_poh(sd, o, Hf, amp.cpu(), phs.cpu())
     # angle() is ill-conditioned where the field is small: the bulk tightly, the worst pixel loosely (as the 384^2 step test)
     perr = (torch.exp(1j * poh.cpu()) - torch.exp(1j * poh_ref)).abs().flatten()
-    assert torch.quantile(perr[::53], 0.999) < 1e-3 and perr.max() < 5e-2, (torch.quantile(perr[::53], 0.999).item(), perr.max().item())
+    assert torch.quantile(perr[::53], 0.999) < 2e-4 and perr.max() < 5e-2, (torch.quantile(perr[::53], 0.999).item(), perr.max().item())  # (round 4: 1e-3)
     del o, Hf
     o35 = optics.make_optics(H, W, pad, 0.35, PITCH, WL)
     with torch.no_grad():

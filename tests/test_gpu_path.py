@@ -363,10 +363,14 @@ def test_train_step_vs_oracle_fresh_inputs():
     W.discriminator.to(DEV).train()
     W.configure(1, 0.0, 1, 1e-3, 0.1, 1e-3, 1e-3, ratio, 10)
     out = W.train_step(rgbd.to(DEV), tamp.to(DEV), tphs.to(DEV), idx, [a.to(DEV) for a in alphas])
-    assert phase_err(out["POH"].cpu(), ref["POH"]) < 1e-3
-    assert rel_err(out["hat_amps"].cpu(), ref["hat_amps"]) < 1e-3
-    assert abs(out["G_loss"].item() - ref["G_loss"]) <= 1e-3 * abs(ref["G_loss"])
-    assert abs(out["D_loss"].item() - ref["D_loss"]) <= 1e-3 * abs(ref["D_loss"])
+    # bounds the float64-truth tests support (tests/test_gpu_truth.py: two fp32 evaluations of this chain are <= ~1e-4 apart at these
+    # sizes); round 4 accepted 1e-3 here.  The measured values travel with a failure.
+    e_poh, e_amp = phase_err(out["POH"].cpu(), ref["POH"]), rel_err(out["hat_amps"].cpu(), ref["hat_amps"])
+    e_g = abs(out["G_loss"].item() - ref["G_loss"]) / abs(ref["G_loss"])
+    e_d = abs(out["D_loss"].item() - ref["D_loss"]) / abs(ref["D_loss"])
+    # G_loss contains -mean D(hat) of the UPDATED critic (one Adam step of ~lr * sign(g) per weight: rounding-level differences of the critic's
+    # gradients move its output, see test_train_step_against_reference_loop): measured 9.6e-4 here; D_loss is taken before the update
+    assert e_poh < 2e-4 and e_amp < 2e-4 and e_g <= 3e-3 and e_d <= 2e-4, dict(poh=e_poh, hat_amps=e_amp, G_loss=e_g, D_loss=e_d)
 
 
 def test_config1_192_inference_and_one_plane_propagation():
@@ -386,8 +390,8 @@ def test_config1_192_inference_and_one_plane_propagation():
     with torch.no_grad():
         poh_ref = nets.generator(nets.as_parameters(seeded.generator_state_dict()), o, Hf, rgbd, False)
         amp_ref = optics.propagate_amplitudes(o35, torch.ones_like(poh_ref), poh_ref, d)
-    assert phase_err(poh.cpu(), poh_ref) < 1e-3
-    assert rel_err(amp.cpu(), amp_ref) < 1e-3
+    e_poh, e_amp = phase_err(poh.cpu(), poh_ref), rel_err(amp.cpu(), amp_ref)
+    assert e_poh < 2e-4 and e_amp < 2e-4, dict(poh=e_poh, amp=e_amp)  # (round 4: 1e-3; the eval-mode generator has no batch statistics to amplify rounding)
     assert rel_err(prop(torch.ones_like(poh), poh_ref.to(DEV), d).cpu(), amp_ref) < PARITY  # propagation alone: 1e-4
 
 
