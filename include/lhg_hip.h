@@ -227,6 +227,17 @@ int lhg_conv_transpose2x2_forward(const float* x, int N, int H, int W, int Ci, i
 int lhg_conv_transpose2x2_backward_input(const float* gy, int N, int H, int W, int Co, int ldgy,
                                          const float* wp, int rows_pad, float* gx, int Ci, int ldgx,
                                          const float* gy_absmax, lhg_stream_t s);
+/* ABI 9: the two input-gradient calls with `gx_absmax` (may be NULL; LHG_ABSMAX_WORDS zero-filled floats): max|gx| — of what is stored, the
+ * added gradient included — is max-accumulated by the GEMM epilogue, as `y_absmax` of the forward calls: gx is often the operand of the
+ * next backward GEMM (the gradient of a skip-concatenation buffer feeds the transposed conv's backward), whose tensor scale then costs
+ * no pass of its own. */
+int lhg_conv2d_backward_input_add_amax(const float* gy, int N, int H, int W, int Co, int ldgy,
+                                       const float* wp, int rows_pad, int KH, int KW, int stride,
+                                       float* gx, int Ci, int ldgx, const float* res, int ldres,
+                                       const float* gy_absmax, float* gx_absmax, lhg_stream_t s);
+int lhg_conv_transpose2x2_backward_input_amax(const float* gy, int N, int H, int W, int Co, int ldgy,
+                                              const float* wp, int rows_pad, float* gx, int Ci, int ldgx,
+                                              const float* gy_absmax, float* gx_absmax, lhg_stream_t s);
 int lhg_conv_transpose2x2_wgrad_splits(int N, int H, int W, int Ci, int Co);
 int lhg_conv_transpose2x2_backward_weight(const float* x, int N, int H, int W, int Ci, int ldx,
                                           const float* gy, int Co, int ldgy,

@@ -1432,6 +1432,12 @@ int lhg_conv2d_backward_input(const float* gy, int N, int H, int W, int Co, int 
 
 int lhg_conv2d_backward_input_add(const float* gy, int N, int H, int W, int Co, int ldgy, const float* wp, int rows_pad, int KH, int KW, int stride,
                                   float* gx, int Ci, int ldgx, const float* res, int ldres, const float* gy_absmax, lhg_stream_t s) {
+  return lhg_conv2d_backward_input_add_amax(gy, N, H, W, Co, ldgy, wp, rows_pad, KH, KW, stride, gx, Ci, ldgx, res, ldres, gy_absmax, nullptr, s);
+}
+
+int lhg_conv2d_backward_input_add_amax(const float* gy, int N, int H, int W, int Co, int ldgy, const float* wp, int rows_pad, int KH, int KW, int stride,
+                                       float* gx, int Ci, int ldgx, const float* res, int ldres, const float* gy_absmax, float* gx_absmax,
+                                       lhg_stream_t s) {
   LHG_REQUIRE(conv_args_ok(KH, KW, stride), "conv2d_backward_input: unsupported kernel %dx%d stride %d", KH, KW, stride);
   LHG_REQUIRE(res == nullptr || ldres >= Ci, "conv2d_backward_input: the added gradient has %d floats per pixel, gx has %d channels", ldres, Ci);
   const int ph = KH / 2, pw = KW / 2;
@@ -1443,6 +1449,7 @@ int lhg_conv2d_backward_input_add(const float* gy, int N, int H, int W, int Co, 
   p.in = gy; p.wp = wp; p.out = gx; p.rows_pad = rows_pad; p.act = LHG_ACT_NONE;
   p.res = res; p.ldres = ldres;  // indexed by the gx pixel in every parity class
   p.a_amax = gy_absmax; p.w_amax = weight_amax(wp, KH * KW, rows_pad, Co);
+  p.out_amax = gx_absmax;  // max|gx| (with the added gradient) max-accumulated by the epilogue: gx is the next backward GEMM's operand
   if (stride == 1) {
     g.gh = H; g.gw = W; g.oy0 = g.ox0 = 0; g.ostep = 1; g.istep = 1; g.T = KH * KW;
     for (int kh = 0; kh < KH; ++kh)
@@ -1544,8 +1551,13 @@ int lhg_conv_transpose2x2_forward(const float* x, int N, int H, int W, int Ci, i
 
 int lhg_conv_transpose2x2_backward_input(const float* gy, int N, int H, int W, int Co, int ldgy, const float* wp, int rows_pad,
                                          float* gx, int Ci, int ldgx, const float* gy_absmax, lhg_stream_t s) {
+  return lhg_conv_transpose2x2_backward_input_amax(gy, N, H, W, Co, ldgy, wp, rows_pad, gx, Ci, ldgx, gy_absmax, nullptr, s);
+}
+
+int lhg_conv_transpose2x2_backward_input_amax(const float* gy, int N, int H, int W, int Co, int ldgy, const float* wp, int rows_pad,
+                                              float* gx, int Ci, int ldgx, const float* gy_absmax, float* gx_absmax, lhg_stream_t s) {
   GGParams p{};
-  p.a_amax = gy_absmax; p.w_amax = weight_amax(wp, 4, rows_pad, Co);
+  p.a_amax = gy_absmax; p.w_amax = weight_amax(wp, 4, rows_pad, Co); p.out_amax = gx_absmax;
   Geom& g = p.g;
   g.N = N; g.Hi = 2 * H; g.Wi = 2 * W; g.Ci = Co; g.ldi = ldgy;
   g.Ho = H; g.Wo = W; g.Co = Ci; g.ldo = ldgx;

@@ -691,6 +691,7 @@ def tag_absmax(t, slot):
     return t
 
 
+_EPILOGUE_GX_AMAX = os.environ.get("LHG_EPILOGUE_GX_AMAX", "1") != "0"  # 0: input-gradient GEMMs do not measure max|gx| (A/B measurements)
 _FUSED_ABSMAX = os.environ.get("LHG_FUSED_ABSMAX", "1") != "0"  # 0: every operand is measured by lhg_absmax (A/B measurements)
 ABSMAX_WORDS = 1  # LHG_ABSMAX_WORDS: an operand's max|x| is the maximum of this many floats (include/lhg_hip.h)
 _AMAX_POOL = {}  # (device, stream, capturing) -> _SlotRing
@@ -971,7 +972,7 @@ class Conv2dFn(TrackedFunction):
         if ctx.needs_input_grad[0]:
             # the tensor scale of gy for the input-gradient GEMM (the weight gradient scales per channel: operand_chanmax)
             gy_amax = operand_absmax(gy) if gemm and gy.shape[-1] % 32 == 0 else None
-            gx = Conv2dInputGradFn.apply(gy, w, ctx.stride, x.shape[1], x.shape[2], x.shape[3], gy_amax, g_shared)
+            gx = Conv2dInputGradFn.apply(gy, w, ctx.stride, x.shape[1], x.shape[2], x.shape[3], gy_amax, g_shared, _feeds_gemm(x))
         if not param_grads_wanted():  # inside only_input_gradients(): the caller differentiates with respect to activations only
             return gx, None, None, None, None
         if ctx.needs_input_grad[1]:
@@ -1012,8 +1013,9 @@ class Conv2dInputGradFn(TrackedFunction):
     """gx = d conv2d / d x contracted with gy.  Returns (N, H, W, pad32(Ci))."""
 
     @staticmethod
-    def forward(ctx, gy, w, stride, H, W, Cx, gy_amax=None, res=None):
-        """``res``: a second gradient of the same tensor (N, H, W, >= Ci channels), added to the result in the GEMM epilogue."""
+    def forward(ctx, gy, w, stride, H, W, Cx, gy_amax=None, res=None, measure_out=False):
+        """``res``: a second gradient of the same tensor (N, H, W, >= Ci channels), added to the result in the GEMM epilogue.
+        ``measure_out``: the result is the operand of another backward GEMM (see _feeds_gemm): the epilogue measures max|gx|."""
         ctx.save_for_backward(gy, w)
         ctx.stride = stride
         note_use(w, ctx.needs_input_grad[1])
@@ -1046,9 +1048,12 @@ class Conv2dInputGradFn(TrackedFunction):
         if gy_amax is None or gyp is not gy:
             gy_amax = operand_absmax(gyp)
         pres, ldres = (nhwc(res)[0], nhwc(res)[5]) if res is not None else (None, 0)
-        call("lhg_conv2d_backward_input_add", pg, N, H, W, Cg, ldg, ptr(wp), wp.shape[1], KH, KW, stride, pgx, Ci, ldgx, pres, ldres,
-             ptr(gy_amax), stream_ptr())
-        return gx
+        # max|gx| from the epilogue (the added gradient included): gx may be the operand of the next backward GEMM — the gradient of a
+        # skip-concatenation buffer feeds the transposed conv's backward, a critic block's the previous block's — without a pass of its own
+        gx_amax = fused_absmax_slot(gy.device) if (measure_out and _EPILOGUE_GX_AMAX) else None
+        call("lhg_conv2d_backward_input_add_amax", pg, N, H, W, Cg, ldg, ptr(wp), wp.shape[1], KH, KW, stride, pgx, Ci, ldgx, pres, ldres,
+             ptr(gy_amax), ptr(gx_amax), stream_ptr())
+        return tag_absmax(gx, gx_amax)
 
     @staticmethod
     def backward(ctx, ggx):
@@ -1058,9 +1063,17 @@ class Conv2dInputGradFn(TrackedFunction):
             g_gy = Conv2dFn.apply(ggx, w, None, ctx.stride, None)
         if ctx.needs_input_grad[1] and param_grads_wanted():
             g_w = _weight_grad(w, (ggx, gy), lambda slot: conv2d_weight_grad(ggx, gy, w.shape, ctx.stride, slot))
-        n = len(ctx.needs_input_grad)  # 6 to 8 arguments were passed
-        grads = (g_gy, g_w, None, None, None, None, None, ggx if n > 7 and ctx.needs_input_grad[7] else None)
+        n = len(ctx.needs_input_grad)  # 6 to 9 arguments were passed
+        grads = (g_gy, g_w, None, None, None, None, None, ggx if n > 7 and ctx.needs_input_grad[7] else None, None)
         return grads[:n]
+
+
+def _feeds_gemm(x) -> bool:
+    """Is the gradient of ``x`` handed to another backward GEMM as it leaves the input-gradient GEMM?  True for a skip-concatenation
+    buffer (its gradient is sliced by CatViewsFn.backward: one slice is the transposed conv's gy operand) — measuring max|gx| in the
+    epilogue of EVERY input-gradient launch was tried and cost more than the four lhg_absmax passes it saves (+0.13 ms per step)."""
+    fn = getattr(x, "grad_fn", None)
+    return fn is not None and fn.name() == "CatViewsFnBackward"
 
 
 def _timing_switch(name: str) -> bool:
@@ -1222,8 +1235,10 @@ class ConvTranspose2x2Fn(TrackedFunction):
             gx = new_nhwc(N, H2 // 2, W2 // 2, Ci, gy.device)
             pgx, _, _, _, _, ldgx = nhwc(gx)
             native.count_flops(0, 2.0 * N * (H2 // 2) * (W2 // 2) * 4 * Ci * Co)
-            call("lhg_conv_transpose2x2_backward_input", pg, N, H2 // 2, W2 // 2, Cg, ldg, ptr(wp), wp.shape[1], pgx, Ci, ldgx, ptr(gy_amax),
-                 stream_ptr())
+            gx_amax = None  # (gx goes to a BatchNorm backward, which measures what it writes: nothing to measure here)
+            call("lhg_conv_transpose2x2_backward_input_amax", pg, N, H2 // 2, W2 // 2, Cg, ldg, ptr(wp), wp.shape[1], pgx, Ci, ldgx, ptr(gy_amax),
+                 ptr(gx_amax), stream_ptr())
+            tag_absmax(gx, gx_amax)
         if not param_grads_wanted():
             return gx, None, None, None
         if ctx.needs_input_grad[1]:

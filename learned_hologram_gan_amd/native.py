@@ -57,6 +57,8 @@ _SIGNATURES = {
     "lhg_conv2d_forward": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _i, _i, _f, _i, _p, _p, _p],
     "lhg_conv2d_backward_input": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p, _p],
     "lhg_conv2d_backward_input_add": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p, _i, _p, _p],
+    "lhg_conv2d_backward_input_add_amax": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p, _i, _p, _p, _p],
+    "lhg_conv_transpose2x2_backward_input_amax": [_p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _i, _p, _p, _p],
     "lhg_conv2d_wgrad_splits": [_i, _i, _i, _i, _i, _i, _i, _i],
     "lhg_conv2d_backward_weight": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _p, _p, _p],
     "lhg_conv2d_thin_supported": [_i, _i, _i, _i],

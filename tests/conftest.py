@@ -74,6 +74,25 @@ def oracle_full_step_fp64(oracle_full_step):
                            [a.double() for a in cfg["alphas"]], capture=True)
 
 
+RECORD_TAG = "r05"  # prefix of the measurement records the GPU tests append to gpurun_out/ (tools/collect_records.py moves them to profiles/)
+
+
+def record_path(name: str) -> str:
+    """gpurun_out/<RECORD_TAG>_<name> (LHG_RECORD_DIR overrides the directory)."""
+    d = os.environ.get("LHG_RECORD_DIR") or os.path.join(REPO, "gpurun_out")
+    os.makedirs(d, exist_ok=True)
+    return os.path.join(d, f"{RECORD_TAG}_{name}")
+
+
+def record_stamp() -> dict:
+    """What ties a record line to the build that produced it: the hash of the kernel sources (the GPU box has no git) and the ABI version.
+    tools/collect_records.py refuses lines whose hash is not the committed sources'."""
+    import bench
+    from learned_hologram_gan_amd import native
+
+    return {"kernel_src_sha16": bench.kernel_source_sha16(), "abi": native.ABI_VERSION}
+
+
 def rel_err(a, b):
     """max|a-b| / max|b| — the fp32 parity measure used throughout (north_star: 1e-4).  A MAX-NORM ratio (the largest deviation over
     the largest reference magnitude), not an element-wise relative error: small elements are held to the tensor's scale."""

@@ -900,13 +900,13 @@ def test_gradient_buckets_are_reduced_inside_backward_two_ranks():
     # instructions of the angular-spectrum kernels next to MFMA workgroups of another queue) and the library is built without those
     # instructions, so a pass that does not repeat is a FAILURE here — no retry.  The worker's full record (forward checksums per pass,
     # which pixels / parameters differed, a 200-call determinism probe of the operator under the same contention) is appended to
-    # gpurun_out/r03_two_rank_overlap.jsonl either way.
-    record = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r03_two_rank_overlap.jsonl")
+    # gpurun_out/<tag>_two_rank_overlap.jsonl either way (stamped with the kernel-source hash).
+    from conftest import record_path, record_stamp
+
     out = sorted(_run_dist_worker("overlap", 2), key=lambda r: r["rank"])
-    os.makedirs(os.path.dirname(record), exist_ok=True)
-    with open(record, "a") as f:
+    with open(record_path("two_rank_overlap.jsonl"), "a") as f:
         for r in out:
-            f.write(json.dumps(r) + "\n")
+            f.write(json.dumps({**record_stamp(), **r}) + "\n")
     assert [r["rank"] for r in out] == [0, 1]
     for r in out:
         assert r["forward_repeats"] and r["local_repeatable"], ("a pass did not repeat", r["forward"], r["recompute_notes"], r["diff_pass0_vs_pass2"], r["asm_probe"])
@@ -960,8 +960,10 @@ def test_sync_batch_stats_two_ranks_equal_one_process_at_twice_the_batch():
     running statistics those of the single process (ref: the single-device step, watermelon.py:207-277; loss_func.py:94-98, 152-157)."""
     out = {r["rank"]: r for r in _run_dist_worker("syncbn", 2)}
     r0 = out[0]
-    with open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "r03_syncbn.jsonl"), "a") as f:
-        f.write(json.dumps(r0) + "\n")
+    from conftest import record_path, record_stamp
+
+    with open(record_path("syncbn.jsonl"), "a") as f:
+        f.write(json.dumps({**record_stamp(), **r0}) + "\n")
     agree = r0["single_process_step_agrees_between_ranks"]
     # the two ranks' SINGLE-PROCESS reference steps are identical work without collectives: they must agree bit for bit (until round 3 the
     # non-repeat of DESIGN.md §5 could hit them; its cause is removed from the build, so a disagreement fails the test)

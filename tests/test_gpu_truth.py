@@ -37,19 +37,18 @@ KGRAD = 5.0
 KPAR = 12.0
 KPAR_TINY = 20.0  # test_generator_tail_vs_fp64_truth: batch statistics over 72 - 256 samples (see there)
 MODES = ("fp32_split_f16", "fp32", "fp32_split")
-# written by the tests themselves; gpurun_out/ is what travels back from the GPU box, tools/collect_records.py stamps the file with the
-# revision and moves it to profiles/ (no hand copy)
-RECORD = os.path.join(os.environ.get("LHG_RECORD_DIR") or os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out"),
-                      "r05_truth_tests.jsonl")
+# written by the tests themselves; gpurun_out/ is what travels back from the GPU box, tools/collect_records.py checks the stamp of every
+# line against the committed kernel sources and moves the file to profiles/ (no hand copy)
 
 
 def _record(test, mode, notes=None, **values):
     """Every measured (e_gpu, e_cpu) pair of these tests is kept: one JSON line per test and mode; ``notes``: names (the worst parameter)."""
     import json
 
-    os.makedirs(os.path.dirname(RECORD), exist_ok=True)
-    with open(RECORD, "a") as f:
-        f.write(json.dumps({"test": test, "mode": mode, **(notes or {}), **{k: [float(a), float(b)] for k, (a, b) in values.items()}}) + "\n")
+    from conftest import record_path, record_stamp
+
+    with open(record_path("truth_tests.jsonl"), "a") as f:
+        f.write(json.dumps({"test": test, "mode": mode, **record_stamp(), **(notes or {}), **{k: [float(a), float(b)] for k, (a, b) in values.items()}}) + "\n")
 
 
 @pytest.fixture(params=MODES)

@@ -2,7 +2,7 @@
 profiles/<tag>_records_manifest.json lists every collected file with its sha256, the git revision it was collected at and the hash of the
 kernel sources (bench.kernel_source_sha16) — the tests and scripts write the records, this script is the only hand in between.
 
-    python tools/collect_records.py [tag, default r04]
+    python tools/collect_records.py [tag, default r05]
 """
 import hashlib
 import json
@@ -12,7 +12,7 @@ import subprocess
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
 SOURCES = [  # (path under gpurun_out/, name under profiles/)
     (f"{TAG}_truth_tests.jsonl", f"{TAG}_truth_tests.jsonl"),
     (f"{TAG}_pmc_mfma.jsonl", f"{TAG}_pmc_mfma.jsonl"),
@@ -24,8 +24,10 @@ SOURCES = [  # (path under gpurun_out/, name under profiles/)
     (f"{TAG}_prof4k/{TAG}_4k_kernel_steady.csv", f"{TAG}_4k_kernel_steady.csv"),
     (f"{TAG}_prof4k/{TAG}_4k_pmc_traffic.json", f"{TAG}_4k_pmc_traffic.json"),
     (f"{TAG}_bench_line.json", f"{TAG}_bench_line.json"),
-    ("r03_syncbn.jsonl", f"{TAG}_syncbn.jsonl"),
-    ("r03_two_rank_overlap.jsonl", f"{TAG}_two_rank_overlap.jsonl"),
+    (f"{TAG}_syncbn.jsonl", f"{TAG}_syncbn.jsonl"),
+    (f"{TAG}_two_rank_overlap.jsonl", f"{TAG}_two_rank_overlap.jsonl"),
+    (f"{TAG}_wg6_sweep.jsonl", f"{TAG}_wg6_sweep.jsonl"),
+    (f"{TAG}_pmc_stalls.jsonl", f"{TAG}_pmc_stalls.jsonl"),
 ]
 
 
@@ -39,16 +41,23 @@ def main():
         a, b = os.path.join(REPO, "gpurun_out", src), os.path.join(REPO, "profiles", dst)
         if not os.path.exists(a):
             continue
-        if src.endswith("_truth_tests.jsonl"):  # keep the LAST record of every (test, mode): the file is appended to by every run
-            last = {}
-            for ln in open(a):
-                if ln.strip():
+        if src.endswith(("_truth_tests.jsonl", "syncbn.jsonl", "overlap.jsonl")):
+            # records the GPU tests append to: every line carries the hash of the kernel sources it was measured with (tests/conftest.py:
+            # record_stamp).  Lines of another build are REFUSED (round 4 stamped whatever file lay around with the new revision).
+            fresh = [ln for ln in open(a) if ln.strip() and json.loads(ln).get("kernel_src_sha16") == manifest["kernel_src_sha16"]]
+            stale = sum(1 for ln in open(a) if ln.strip()) - len(fresh)
+            if not fresh:
+                print(f"collect_records: {src}: no line of this build ({stale} of other builds) - skipped")
+                continue
+            if src.endswith("_truth_tests.jsonl"):  # the LAST record of every (test, mode): the file is appended to by every run
+                last = {}
+                for ln in fresh:
                     r = json.loads(ln)
                     last[(r["test"], r["mode"])] = ln
-            open(b, "w").write("".join(last.values()))
-        elif src.endswith(("syncbn.jsonl", "overlap.jsonl")):  # the newest entries (two ranks) of the rig records
-            lines = [ln for ln in open(a) if ln.strip()]
-            open(b, "w").write("".join(lines[-2:]))
+                fresh = list(last.values())
+            else:  # the newest entries (two ranks) of the rig records
+                fresh = fresh[-2:]
+            open(b, "w").write("".join(fresh))
         else:
             shutil.copyfile(a, b)
         manifest["files"][dst] = {"from": "gpurun_out/" + src, "sha256": hashlib.sha256(open(b, "rb").read()).hexdigest()[:16]}
