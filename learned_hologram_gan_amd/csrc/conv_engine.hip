@@ -995,7 +995,7 @@ static int launch_gg_split(GGParams& p, hipStream_t st) {
   const bool n128 = p.rows_pad % 128 == 0;
   // 10..19 (merged parity classes only): variant v - 10 in one launch per class — what wins on the layers whose classes are long
   // enough by themselves (512 -> 1024 @ 48^2: 493 us against 572 merged; 128 -> 256 @ 96^2: 267 against 206)
-  const int NV = ncls > 1 ? 20 : 12;  // 3, 4: eight consumer waves (two per SIMD) on the 128x128 / 128x64 tiles; 5..8: strip-staged 3x3 kernel (gg4s);
+  const int NV = ncls > 1 ? 20 : 16;  // 14, 15 (round 5): gg4s 128 x 64 / 64 x 64 with swizzled unpadded LDS rows (three / four workgroups per CU);  // 12, 13 (single class, round 5): gg4s with two taps per barrier on 128 x 64 / 64 x 64 strips (Ci % 64 == 0); 3, 4: eight consumer waves (two per SIMD) on the 128x128 / 128x64 tiles; 5..8: strip-staged 3x3 kernel (gg4s);
                           // 9: 64 pixels x 128 output channels (half the activation splits of the 64x64 tile, same pixel granularity);
                           // 10, 11 (single class only): gg4s with eight consumer waves on 256 x 128 / 256 x 64 strips, one workgroup per CU
   // gg4s_kernel: fp16 planes, full 3x3 tap set, stride 1 both ways, same extents in and out
@@ -1017,6 +1017,14 @@ static int launch_gg_split(GGParams& p, hipStream_t st) {
   const bool f16 = split_f16();
   if (f16) LHG_REQUIRE(p.a_amax != nullptr && p.w_amax != nullptr, "gather-GEMM (fp32_split_f16 mode): the operand's absmax pointer is missing (lhg_absmax)");
   auto valid = [&](int v) {
+    // 12 .. 15: round-5 experiments, bit-identical to the others, measured and NOT faster on any layer (tools/gg_tps_sweep.sh):
+    // two taps per barrier runs level with the one-tap strips (the waits of the 64-output-channel layers are not the barriers), the
+    // swizzled 128 x 64 tile reaches three workgroups per CU only by spilling 131 registers (4 x slower), the swizzled 64 x 64 tile is
+    // level with the padded one.  Offered to the tuner / a forced choice only under LHG_GG_EXPERIMENTAL=1.
+    static const bool experimental = [] { const char* e = getenv("LHG_GG_EXPERIMENTAL"); return e && atoi(e) != 0; }();
+    if (ncls == 1 && v >= 12 && !experimental) return false;
+    if (ncls == 1 && v >= 14) return f16 && strips;
+    if (ncls == 1 && v >= 12) return f16 && strips && g.Ci % 64 == 0;
     if (ncls == 1 && v >= 10) return f16 && strips && (v == 11 || n128);
     if (v >= 10) v -= 10;
     if (v == 9) return f16 && n128;
@@ -1049,6 +1057,10 @@ static int launch_gg_split(GGParams& p, hipStream_t st) {
         case 9: launch3(gg3s_kernel<64, 128, 2, 4, 32, float, 4, _Float16>, 64, 128, 512); break;
         case 10: hipLaunchKernelGGL((gg4s_kernel<256, 128, 4, 2>), dim3(blocks_strip(256, 128)), dim3(768), 0, st, p, ib, wb); break;
         case 11: hipLaunchKernelGGL((gg4s_kernel<256, 64, 4, 2>), dim3(blocks_strip(256, 64)), dim3(768), 0, st, p, ib, wb); break;
+        case 12: hipLaunchKernelGGL((gg4s_kernel<128, 64, 2, 2, 2>), dim3(blocks_strip(128, 64)), dim3(512), 0, st, p, ib, wb); break;
+        case 13: hipLaunchKernelGGL((gg4s_kernel<64, 64, 2, 2, 2>), dim3(blocks_strip(64, 64)), dim3(512), 0, st, p, ib, wb); break;
+        case 14: hipLaunchKernelGGL((gg4s_kernel<128, 64, 2, 2, 1, true>), dim3(blocks_strip(128, 64)), dim3(512), 0, st, p, ib, wb); break;
+        case 15: hipLaunchKernelGGL((gg4s_kernel<64, 64, 2, 2, 1, true>), dim3(blocks_strip(64, 64)), dim3(512), 0, st, p, ib, wb); break;
         default: break;
       }
     } else {

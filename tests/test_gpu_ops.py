@@ -1199,9 +1199,11 @@ def test_every_tiling_variant_gives_the_same_bits():
 
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
     seen = {}
-    for gv, wv in ((2, 21), (0, 18), (9, 22), (5, 25), (8, 10), (12, 13), (10, 21), (11, 18)):  # 10, 11: twelve-wave strips (single-class launches)
+    # 10, 11: twelve-wave strips (single-class launches); 12, 13 (round 5, LHG_GG_EXPERIMENTAL): strips with two taps per barrier (128 x 64 /
+    # 64 x 64; on the merged stride-2 launch the same numbers mean one launch per class of variants 2 / 3); 15: swizzled unpadded LDS rows
+    for gv, wv in ((2, 21), (0, 18), (9, 22), (5, 25), (8, 10), (12, 13), (13, 21), (15, 18), (10, 21), (11, 18)):
         # LHG_WG6=0: the per-tap weight-gradient kernels this test forces (the tap-fused kernel's variants: tests/test_gpu_wgrad6.py)
-        env = dict(os.environ, LHG_AUTOTUNE="0", LHG_GGS_VARIANT=str(gv), LHG_WG_VARIANT=str(wv), LHG_WG6="0", PYTHONPATH=root)
+        env = dict(os.environ, LHG_AUTOTUNE="0", LHG_GGS_VARIANT=str(gv), LHG_WG_VARIANT=str(wv), LHG_WG6="0", LHG_GG_EXPERIMENTAL="1", PYTHONPATH=root)
         out = subprocess.run([sys.executable, "-c", _VARIANT_CHILD], cwd=root, env=env, capture_output=True, text=True)
         lines = [ln for ln in out.stdout.splitlines() if ln.startswith("HASH")]
         assert out.returncode == 0 and lines, out.stdout[-800:] + out.stderr[-800:]
