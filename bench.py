@@ -463,7 +463,9 @@ def main():
                                    + (f"VGG19 perceptual term x{args.perceptual} with random weights" if args.perceptual > 0 else "no VGG term") + "), "
                                    + ((f"bf16 conv-GEMM operands, {hip_ops.activation_storage()} activation storage, fp32 accumulation / BatchNorm / FFT / Adam "
                                       "(informational)") if bf16 else f"fp32 tensors, conv GEMMs in the '{hip_ops.conv_precision()}' mode"),
-                       "global_batch": B * world, "parallelism": f"dp{world}"},
+                       "global_batch": B * world, "parallelism": f"dp{world}",
+                       # wire format of the gradient buckets' all-reduce (bf16 buckets are picked silently with bf16 storage)
+                       "grad_payload": getattr(W._sync_G, "payload", "fp32") if world > 1 else None},
             "roofline": r,
         }
 

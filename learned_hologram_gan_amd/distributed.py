@@ -253,8 +253,13 @@ class GradSynchronizer:
             hip_ops.reset_backward_state()
 
     def finish(self):
-        """Call after backward: launches buckets whose parameters got no gradient this pass,
-        waits for all reductions and turns sums into means."""
+        """Call after backward: launches buckets whose parameters got no gradient this pass and waits for all reductions.
+
+        Contract of the flat gradient buffer afterwards: with ``defer_scale`` (watermelon's choice) it holds the SUM over the ranks and
+        ``self.grad_scale`` = 1 / world is what turns it into the data-parallel mean — ``FusedAdam.step(grad_scale=...)`` multiplies on the
+        fly; any other reader must use ``mean_gradient()``.  Without ``defer_scale`` the buffer holds the mean and grad_scale is 1.
+        With ``payload="bf16"`` every partial sum of the ring all-reduce is rounded to bf16 (2^-9 relative, no error feedback): a wire
+        format for the bf16 configs, recorded in the bench line's ``config.grad_payload``."""
         if not self.enabled:
             self.grad_scale = 1.0  # a local pass: the buffer holds this rank's own gradient
             return
@@ -278,6 +283,10 @@ class GradSynchronizer:
             self.grad_scale = 1.0 / self.world  # applied by the optimiser kernel (lhg_adam_step_scaled)
         else:
             self.flat_grad.div_(self.world)
+
+    def mean_gradient(self):
+        """The data-parallel MEAN gradient as a new tensor (flat_grad * grad_scale): for readers other than the fused optimiser."""
+        return self.flat_grad * self.grad_scale
 
     def remove(self):
         from . import hip_ops
