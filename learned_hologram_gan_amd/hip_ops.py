@@ -571,6 +571,16 @@ def chanmax_wanted(Cc) -> bool:
 # apply launch ON THE MAIN CHAIN (27 in the backward apply with its two outputs), where the finish launches ran on the weight-gradient
 # stream beside it: the step does not get shorter.  Off by default.
 _CHANMAX_IN_LAUNCH = os.environ.get("LHG_CHANMAX_IN_LAUNCH", "0") == "1"
+# LHG_FUSED_BN=1: the BatchNorm calls of the MAIN chain finish their reductions inside the launch that writes the partial rows (ABI 9:
+# lhg_bn_forward_train / lhg_bn_backward_fused / ..._backward_backward_fused) instead of the two-launch form (partial rows, then a reduce
+# launch).  Measured, interleaved on one box (round 5, tools/ab_env3.sh, tools/ab_fused_bn.sh): ~100 launches fewer per step, and
+#   384^2 batch 4 (GPU-bound):  31.63 ms fused against 31.40 two-launch — the finish costs 12 - 20 us at the end of a launch on the chain the
+#                               step waits for (six dependent memory round trips), the reduce launch it replaces 8 - 10 us;
+#   bf16 storage (GPU-bound):   21.2 against 20.85;
+#   96^2 batch 4 (host-bound):  15.4 - 16.1 ms fused against 17.7 - 18.0 — there every launch is host time.
+# BASELINE's configurations are GPU-bound, so the default is the two-launch form; reductions that run on the weight-gradient stream
+# (bias gradients, per-channel-maxima passes) are always the one-launch form: beside the main chain their tail costs nothing.
+_FUSED_BN = os.environ.get("LHG_FUSED_BN", "0") == "1"
 
 
 class ChanMaxSource:
@@ -1269,6 +1279,9 @@ def channel_sum(t):
 def channel_sum_into(t, slot):
     """slot += sum over (N,H,W) of t (C % 4 == 0): the bias gradient accumulated by the reduction kernel itself."""
     p, N, H, W, Cc, ld = nhwc(t)
+    if not (_FUSED_BN or _SIDE_BIAS):  # on the main chain and not asked for: the two-launch form
+        call("lhg_channel_sum", p, N * H * W, Cc, ld, ptr(slot), 1, ptr(torch.empty((2048 * Cc,), dtype=torch.float32, device=t.device)), stream_ptr())
+        return
     ws, tickets = fused_scratch(t.device)
     call("lhg_channel_sum_fused", p, N * H * W, Cc, ld, ptr(slot), 1, ws, tickets, stream_ptr())
 
@@ -1439,10 +1452,20 @@ class BatchNormTrainFn(TrackedFunction):
             # statistics (finished in the launch that sums them), running statistics and the apply pass behind ONE call, two launches; the
             # weight gradient of the conv that reads y wants per-channel maxima of it: finished by the apply launch (training passes only)
             cm = chanmax_dest(Cc, pixels, x.device, out) if any(ctx.needs_input_grad) else None
-            ws, tickets = fused_scratch(x.device)
-            call("lhg_bn_forward_train", px, ldx, pixels, Cc, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), BN_MOMENTUM, BN_EPS,
-                 pres, ldres, act, float(slope), py, ldy, ptr(stats), ptr(y_amax), cm.ptr if cm else None, cm.finish if cm else 0, ws, tickets,
-                 stream_ptr())
+            if _FUSED_BN:
+                ws, tickets = fused_scratch(x.device)
+                call("lhg_bn_forward_train", px, ldx, pixels, Cc, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), BN_MOMENTUM, BN_EPS,
+                     pres, ldres, act, float(slope), py, ldy, ptr(stats), ptr(y_amax), cm.ptr if cm else None, cm.finish if cm else 0, ws, tickets,
+                     stream_ptr())
+            else:
+                call("lhg_bn_stats", px, pixels, Cc, ldx, ptr(stats), ptr(running_mean), ptr(running_var), BN_MOMENTUM, BN_EPS,
+                     ptr(_bn_ws(Cc, x.device, 4104)), stream_ptr())
+                if cm is not None:
+                    call("lhg_bn_apply_chanmax", px, ldx, pixels, Cc, ptr(stats), ptr(gamma), ptr(beta), pres, ldres, act, float(slope), py, ldy,
+                         ptr(y_amax), cm.ptr, stream_ptr())
+                else:
+                    call("lhg_bn_apply", px, ldx, pixels, Cc, ptr(stats), ptr(gamma), ptr(beta), pres, ldres, act, float(slope), py, ldy, ptr(y_amax),
+                         stream_ptr())
             if cm is not None:
                 cm.commit(y)
         tag_absmax(y, y_amax)
@@ -1494,12 +1517,22 @@ class BatchNormPairTrainFn(TrackedFunction):
         # per-channel maxima: both halves' partial rows one behind the other in ONE buffer, finished together when a weight gradient asks
         rows = int(native.load().lhg_chanmax_partial_rows(half, Cc)) if (any(ctx.needs_input_grad) and chanmax_wanted(Cc)) else 0
         part = torch.empty((2 * rows * Cc,), dtype=torch.float32, device=x.device) if rows else None
-        ws, tickets = fused_scratch(x.device)
+        ws, tickets = fused_scratch(x.device) if _FUSED_BN else (None, None)
         for h in range(2):
             xo, yo = px + h * half * ldx * es, py + h * half * ldy * es
-            call("lhg_bn_forward_train", xo, ldx, half, Cc, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), BN_MOMENTUM, BN_EPS,
-                 None, 0, act, float(slope), yo, ldy, stats[h].data_ptr(), ptr(y_amax), None if part is None else part.data_ptr() + 4 * h * rows * Cc, 0,
-                 ws, tickets, stream_ptr())
+            rows_h = None if part is None else part.data_ptr() + 4 * h * rows * Cc
+            if _FUSED_BN:
+                call("lhg_bn_forward_train", xo, ldx, half, Cc, ptr(gamma), ptr(beta), ptr(running_mean), ptr(running_var), BN_MOMENTUM, BN_EPS,
+                     None, 0, act, float(slope), yo, ldy, stats[h].data_ptr(), ptr(y_amax), rows_h, 0, ws, tickets, stream_ptr())
+                continue
+            call("lhg_bn_stats", xo, half, Cc, ldx, stats[h].data_ptr(), ptr(running_mean), ptr(running_var), BN_MOMENTUM, BN_EPS,
+                 ptr(_bn_ws(Cc, x.device, 4104)), stream_ptr())
+            if rows_h is not None:
+                call("lhg_bn_apply_chanmax", xo, ldx, half, Cc, stats[h].data_ptr(), ptr(gamma), ptr(beta), None, 0, act, float(slope), yo, ldy,
+                     ptr(y_amax), rows_h, stream_ptr())
+            else:
+                call("lhg_bn_apply", xo, ldx, half, Cc, stats[h].data_ptr(), ptr(gamma), ptr(beta), None, 0, act, float(slope), yo, ldy, ptr(y_amax),
+                     stream_ptr())
         tag_absmax(y, y_amax)
         if part is not None:
             src = ChanMaxSource(Cc, x.device)
@@ -1534,14 +1567,23 @@ class BatchNormPairTrainFn(TrackedFunction):
         gx_amax = fused_absmax_slot(gy.device)
         rows = int(native.load().lhg_chanmax_partial_rows(half, Cc)) if chanmax_wanted(Cc) else 0
         part = torch.empty((2 * rows * Cc,), dtype=torch.float32, device=gy.device) if rows else None
-        ws, tickets = fused_scratch(gy.device)
+        ws, tickets = fused_scratch(gy.device) if _FUSED_BN else (None, None)
         for h in range(2):
             off = h * half
             acc = 1 if (into_slots or h == 1) else 0  # the second half adds to the first's sums
-            call("lhg_bn_backward_fused", pg + off * ldg * es, ldg, px + off * ldx * es, ldx, None if mask_from_x else py + off * ldy * es, ldy, half, Cc,
-                 stats[h].data_ptr(), ptr(gamma), ptr(ctx.beta_value) if mask_from_x else None, ctx.act, float(ctx.slope), pgx + off * Cc * es, Cc,
-                 None, Cc, ptr(ggamma), ptr(gbeta), acc, ptr(gx_amax), None, None if part is None else part.data_ptr() + 4 * h * rows * Cc, None, 0,
-                 ws, tickets, stream_ptr())
+            rows_h = None if part is None else part.data_ptr() + 4 * h * rows * Cc
+            gyo, xo, yo = pg + off * ldg * es, px + off * ldx * es, None if mask_from_x else py + off * ldy * es
+            beta_p = ptr(ctx.beta_value) if mask_from_x else None
+            if _FUSED_BN:
+                call("lhg_bn_backward_fused", gyo, ldg, xo, ldx, yo, ldy, half, Cc, stats[h].data_ptr(), ptr(gamma), beta_p, ctx.act, float(ctx.slope),
+                     pgx + off * Cc * es, Cc, None, Cc, ptr(ggamma), ptr(gbeta), acc, ptr(gx_amax), None, rows_h, None, 0, ws, tickets, stream_ptr())
+                continue
+            args = (gyo, ldg, xo, ldx, yo, ldy, half, Cc, stats[h].data_ptr(), ptr(gamma), ctx.act, float(ctx.slope), pgx + off * Cc * es, Cc, None, Cc,
+                    ptr(ggamma), ptr(gbeta), acc, ptr(_bn_ws(Cc, gy.device)), ptr(gx_amax), beta_p)
+            if rows_h is not None:
+                call("lhg_bn_backward_chanmax", *args, rows_h, None, None, stream_ptr())
+            else:
+                call("lhg_bn_backward", *args, stream_ptr())
         tag_absmax(gx, gx_amax)
         if part is not None:
             src = ChanMaxSource(Cc, gy.device)
@@ -1583,10 +1625,19 @@ def bn_backward_raw(gy, x, y, gamma, stats, act, slope, want_res, ggamma, gbeta,
     cm = chanmax_dest(Cc, N * H * W, gy.device)
     cm_res = chanmax_dest(Cc, N * H * W, gy.device) if (want_res and cm is not None) else None
     gres_amax = fused_absmax_slot(gy.device) if (want_res and cm is not None) else None
-    ws, tickets = fused_scratch(gy.device)
-    call("lhg_bn_backward_fused", pg, ldg, px, ldx, py, ldy, N * H * W, Cc, ptr(stats), ptr(gamma), ptr(beta), act, float(slope),
-         ptr(gx), Cc, ptr(gres), Cc, ptr(ggamma), ptr(gbeta), int(accumulate), ptr(gx_amax), ptr(gres_amax), cm.ptr if cm else None,
-         cm_res.ptr if cm_res else None, cm.finish if cm else 0, ws, tickets, stream_ptr())
+    if _FUSED_BN:
+        ws, tickets = fused_scratch(gy.device)
+        call("lhg_bn_backward_fused", pg, ldg, px, ldx, py, ldy, N * H * W, Cc, ptr(stats), ptr(gamma), ptr(beta), act, float(slope),
+             ptr(gx), Cc, ptr(gres), Cc, ptr(ggamma), ptr(gbeta), int(accumulate), ptr(gx_amax), ptr(gres_amax), cm.ptr if cm else None,
+             cm_res.ptr if cm_res else None, cm.finish if cm else 0, ws, tickets, stream_ptr())
+    elif cm is not None:
+        call("lhg_bn_backward_chanmax", pg, ldg, px, ldx, py, ldy, N * H * W, Cc, ptr(stats), ptr(gamma), act, float(slope),
+             ptr(gx), Cc, ptr(gres), Cc, ptr(ggamma), ptr(gbeta), int(accumulate), ptr(_bn_ws(Cc, gy.device)), ptr(gx_amax), ptr(beta),
+             cm.ptr, cm_res.ptr if cm_res else None, ptr(gres_amax), stream_ptr())
+    else:
+        call("lhg_bn_backward", pg, ldg, px, ldx, py, ldy, N * H * W, Cc, ptr(stats), ptr(gamma), act, float(slope),
+             ptr(gx), Cc, ptr(gres), Cc, ptr(ggamma), ptr(gbeta), int(accumulate), ptr(_bn_ws(Cc, gy.device)), ptr(gx_amax), ptr(beta),
+             stream_ptr())
     tag_absmax(gx, gx_amax)
     if gres_amax is not None:
         tag_absmax(gres, gres_amax)
@@ -1650,9 +1701,13 @@ class BatchNormGradFn(TrackedFunction):
             # formula over the GLOBAL sums is W times the global-batch gradient on every rank; its share here is 1/W of it
             ggamma2.div_(ctx.world)
         else:
-            fws, tickets = fused_scratch(x.device)
-            call("lhg_bn_backward_backward_fused", ptr(ggx_d), ptr(gy_d), ptr(x_d), ptr(y_d), pixels, Cc, ptr(stats), ptr(gamma),
-                 ctx.act, float(ctx.slope), ptr(ggy), ptr(gx2), ptr(ggamma2), fws, tickets, stream_ptr())
+            if _FUSED_BN:
+                fws, tickets = fused_scratch(x.device)
+                call("lhg_bn_backward_backward_fused", ptr(ggx_d), ptr(gy_d), ptr(x_d), ptr(y_d), pixels, Cc, ptr(stats), ptr(gamma),
+                     ctx.act, float(ctx.slope), ptr(ggy), ptr(gx2), ptr(ggamma2), fws, tickets, stream_ptr())
+            else:
+                call("lhg_bn_backward_backward", ptr(ggx_d), ptr(gy_d), ptr(x_d), ptr(y_d), pixels, Cc, ptr(stats), ptr(gamma),
+                     ctx.act, float(ctx.slope), ptr(ggy), ptr(gx2), ptr(ggamma2), ptr(_bn_ws(Cc, x.device, 5 * 4096 + 8)), stream_ptr())
         if not param_grads_wanted():
             return (ggy, gx2) + nothing[2:]
         slot = _small_grad_slot(ctx.gamma)
