@@ -444,29 +444,32 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const T* __restrict__ gy, 
     });
 }
 
-// sums[k][c] = sum_b partial[b][k][c] in double.  grid (ceil(C/32), NSUM), block 32 channels x 32 slices; four independent
-// accumulators per thread keep several loads in flight (the kernel is latency-bound: 2048 partial rows, few workgroups).
-constexpr int RP_SLICES = 32;
+// sums[k][c] = sum_b partial[b][k][c] in double.  grid (ceil(C / RP_CH), NSUM), block RP_CH channels x RP_SLICES slices of the partial rows.
+// The kernel is pure latency: a handful of workgroups on the whole chip walk <= 2048 rows, and it sits on the chain the step waits for
+// (one per BatchNorm call: ~100 per train step).  Round 5: 16 channels x 64 slices with SIXTEEN rows in flight per thread (32 x 32 with four
+// in flight before: sixteen dependent round trips for 2048 rows, now two) — 10.4 -> ~6 us per call.
+constexpr int RP_SLICES = 64, RP_CH = 16, RP_UNROLL = 16;
+__device__ __forceinline__ double reduce_rows(const float* __restrict__ src, size_t stride, int nblk, int slice) {
+  double acc[4] = {0, 0, 0, 0};
+  int b = slice;
+  for (; b + (RP_UNROLL - 1) * RP_SLICES < nblk; b += RP_UNROLL * RP_SLICES) {
+    float v[RP_UNROLL];
+#pragma unroll
+    for (int u = 0; u < RP_UNROLL; ++u) v[u] = src[(size_t)(b + u * RP_SLICES) * stride];
+#pragma unroll
+    for (int u = 0; u < RP_UNROLL; ++u) acc[u & 3] += (double)v[u];
+  }
+  for (; b < nblk; b += RP_SLICES) acc[0] += (double)src[(size_t)b * stride];
+  return (acc[0] + acc[1]) + (acc[2] + acc[3]);
+}
+
 template <int NSUM>
 __global__ __launch_bounds__(1024) void reduce_partials(const float* __restrict__ partial, int nblk, int C, float* __restrict__ sums,
                                                         int accumulate = 0) {
-  __shared__ double red[RP_SLICES][32];
-  const int lane_c = threadIdx.x & 31, slice = threadIdx.x >> 5, k = blockIdx.y;
-  const int c = blockIdx.x * 32 + lane_c;
-  double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-  if (c < C) {
-    const float* src = partial + (size_t)k * C + c;
-    const size_t stride = (size_t)NSUM * C;
-    int b = slice;
-    for (; b + 3 * RP_SLICES < nblk; b += 4 * RP_SLICES) {
-      s0 += src[(size_t)b * stride];
-      s1 += src[(size_t)(b + RP_SLICES) * stride];
-      s2 += src[(size_t)(b + 2 * RP_SLICES) * stride];
-      s3 += src[(size_t)(b + 3 * RP_SLICES) * stride];
-    }
-    for (; b < nblk; b += RP_SLICES) s0 += src[(size_t)b * stride];
-  }
-  red[slice][lane_c] = (s0 + s1) + (s2 + s3);
+  __shared__ double red[RP_SLICES][RP_CH];
+  const int lane_c = threadIdx.x % RP_CH, slice = threadIdx.x / RP_CH, k = blockIdx.y;
+  const int c = blockIdx.x * RP_CH + lane_c;
+  red[slice][lane_c] = c < C ? reduce_rows(partial + (size_t)k * C + c, (size_t)NSUM * C, nblk, slice) : 0.0;
   __syncthreads();
   if (slice == 0 && c < C) {
     double s = 0;
@@ -477,32 +480,17 @@ __global__ __launch_bounds__(1024) void reduce_partials(const float* __restrict_
   }
 }
 
-// reduce_partials<2> and bn_stats_final in one launch: the 32 channels of a block sum their two shifted-sum columns over the partial
-// rows (same order and roundings as the two kernels) and slice 0 writes mean / invstd and the running statistics.
+// reduce_partials<2> and the statistics' finish in one launch: the channels of a block sum their two shifted-sum columns over the partial
+// rows and slice 0 writes mean / invstd and the running statistics (bn_stats_final).
 template <class T>
 __global__ __launch_bounds__(1024) void bn_stats_reduce_final(const float* __restrict__ partial, int nblk, const T* __restrict__ x,
                                                               long long pixels, int C, float* __restrict__ stats, float* running_mean,
                                                               float* running_var, float momentum, float eps) {
-  __shared__ double red[2][RP_SLICES][32];
-  const int lane_c = threadIdx.x & 31, slice = threadIdx.x >> 5;
-  const int c = blockIdx.x * 32 + lane_c;
+  __shared__ double red[2][RP_SLICES][RP_CH];
+  const int lane_c = threadIdx.x % RP_CH, slice = threadIdx.x / RP_CH;
+  const int c = blockIdx.x * RP_CH + lane_c;
 #pragma unroll
-  for (int k = 0; k < 2; ++k) {
-    double s0 = 0, s1 = 0, s2 = 0, s3 = 0;
-    if (c < C) {
-      const float* src = partial + (size_t)k * C + c;
-      const size_t stride = (size_t)2 * C;
-      int b = slice;
-      for (; b + 3 * RP_SLICES < nblk; b += 4 * RP_SLICES) {
-        s0 += src[(size_t)b * stride];
-        s1 += src[(size_t)(b + RP_SLICES) * stride];
-        s2 += src[(size_t)(b + 2 * RP_SLICES) * stride];
-        s3 += src[(size_t)(b + 3 * RP_SLICES) * stride];
-      }
-      for (; b < nblk; b += RP_SLICES) s0 += src[(size_t)b * stride];
-    }
-    red[k][slice][lane_c] = (s0 + s1) + (s2 + s3);
-  }
+  for (int k = 0; k < 2; ++k) red[k][slice][lane_c] = c < C ? reduce_rows(partial + (size_t)k * C + c, (size_t)2 * C, nblk, slice) : 0.0;
   __syncthreads();
   if (slice != 0 || c >= C) return;
   double sum[2];
@@ -513,18 +501,7 @@ __global__ __launch_bounds__(1024) void bn_stats_reduce_final(const float* __res
     for (int i = 0; i < RP_SLICES; ++i) s += red[k][i][lane_c];
     sum[k] = (double)(float)s;
   }
-  const double n = (double)pixels;
-  const double dm = sum[0] / n;
-  const double mean = (double)ld1(x + c) + dm;
-  double var = sum[1] / n - dm * dm;
-  if (var < 0) var = 0;
-  stats[c] = (float)mean;
-  stats[C + c] = (float)(1.0 / sqrt(var + (double)eps));
-  if (running_mean) running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * (float)mean;
-  if (running_var) {
-    const double unbiased = n > 1 ? var * n / (n - 1) : var;
-    running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
-  }
+  bn_stats_final(c, sum[0], sum[1], x, pixels, C, stats, running_mean, running_var, momentum, eps);
 }
 
 template <class T>
@@ -738,8 +715,9 @@ __global__ __launch_bounds__(256) void channel_absmax_partial(const float* __res
 }
 
 // out[c] = max_b partial[b][c]; block = 32 channels x 32 slices of the partial rows
+constexpr int CM_SLICES = 32;  // 32 channels x 32 slices per block (the sum reductions above use their own split)
 __global__ __launch_bounds__(1024) void channel_absmax_reduce(const unsigned* __restrict__ partial, int nblk, int C, unsigned* __restrict__ out) {
-  __shared__ unsigned red[RP_SLICES][32];
+  __shared__ unsigned red[CM_SLICES][32];
   const int lane_c = threadIdx.x & 31, slice = threadIdx.x >> 5;
   const int c = blockIdx.x * 32 + lane_c;
   unsigned m = 0;
@@ -747,20 +725,20 @@ __global__ __launch_bounds__(1024) void channel_absmax_reduce(const unsigned* __
     // eight rows in flight per thread: the loop is latency-bound (two to eight workgroups on the whole chip, 2048 rows: 17.5 us per
     // call with one load per iteration, 94 calls per train step)
     int b = slice;
-    for (; b + 7 * RP_SLICES < nblk; b += 8 * RP_SLICES) {
+    for (; b + 7 * CM_SLICES < nblk; b += 8 * CM_SLICES) {
       unsigned v[8];
 #pragma unroll
-      for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(b + u * RP_SLICES) * C + c];
+      for (int u = 0; u < 8; ++u) v[u] = partial[(size_t)(b + u * CM_SLICES) * C + c];
 #pragma unroll
       for (int u = 0; u < 8; ++u) m = max(m, v[u]);
     }
-    for (; b < nblk; b += RP_SLICES) m = max(m, partial[(size_t)b * C + c]);
+    for (; b < nblk; b += CM_SLICES) m = max(m, partial[(size_t)b * C + c]);
   }
   red[slice][lane_c] = m;
   __syncthreads();
   if (slice == 0 && c < C) {
 #pragma unroll
-    for (int i = 1; i < RP_SLICES; ++i) m = max(m, red[i][lane_c]);
+    for (int i = 1; i < CM_SLICES; ++i) m = max(m, red[i][lane_c]);
     out[c] = m;
   }
 }
@@ -976,7 +954,7 @@ static int channel_sum_impl(const float* x, long long pixels, int C, int ld, flo
   const ColMap cm = col_map(C);
   const int nblk = partial_blocks(pixels, cm.gy);
   hipLaunchKernelGGL((channel_sum_partial<T>), dim3(nblk, cm.gy), dim3(256), 0, as_stream(s), as_act<T>(x), pixels, C, ld, cm.lanes_c, cm.rows, ws);
-  hipLaunchKernelGGL(reduce_partials<1>, dim3((C + 31) / 32, 1), dim3(1024), 0, as_stream(s), ws, nblk, C, out, accumulate);
+  hipLaunchKernelGGL(reduce_partials<1>, dim3((C + RP_CH - 1) / RP_CH, 1), dim3(1024), 0, as_stream(s), ws, nblk, C, out, accumulate);
   return check_launch("channel_sum");
 }
 
@@ -988,7 +966,7 @@ static int bn_stats_impl(const float* x, long long pixels, int C, int ld, float*
   const ColMap cm = col_map(C);
   const int nblk = partial_blocks(pixels, cm.gy);
   hipLaunchKernelGGL((bn_stats_partial<T>), dim3(nblk, cm.gy), dim3(256), 0, as_stream(s), as_act<T>(x), pixels, C, ld, cm.lanes_c, cm.rows, ws);
-  hipLaunchKernelGGL((bn_stats_reduce_final<T>), dim3((C + 31) / 32), dim3(1024), 0, as_stream(s), ws, nblk, as_act<T>(x), pixels, C, stats,
+  hipLaunchKernelGGL((bn_stats_reduce_final<T>), dim3((C + RP_CH - 1) / RP_CH), dim3(1024), 0, as_stream(s), ws, nblk, as_act<T>(x), pixels, C, stats,
                      running_mean, running_var, momentum, eps);
   return check_launch("bn_stats");
 }
@@ -1030,7 +1008,7 @@ static int bn_backward_impl(const float* gy, int ldgy, const float* x, int ldx, 
   if (phase != 2) {
     hipLaunchKernelGGL((bn_bwd_partial<T>), dim3(nblk, cm.gy), dim3(256), 0, as_stream(s), as_act<T>(gy), ldgy, as_act<T>(x), ldx, as_act<T>(y), ldy, pixels, C,
                        stats, gamma, beta, act, slope, cm.lanes_c, cm.rows, ws);
-    hipLaunchKernelGGL(reduce_partials<2>, dim3((C + 31) / 32, 2), dim3(1024), 0, as_stream(s), ws, nblk, C, sums, 0);
+    hipLaunchKernelGGL(reduce_partials<2>, dim3((C + RP_CH - 1) / RP_CH, 2), dim3(1024), 0, as_stream(s), ws, nblk, C, sums, 0);
   }
   if (phase != 1) {
     const int nb2 = apply_blocks(pixels, cm);
@@ -1055,7 +1033,7 @@ static int bn_backward_backward_impl(const float* ggx, const float* gy, const fl
   if (phase != 2) {
     hipLaunchKernelGGL((bn_bwd2_partial<T>), dim3(nblk, cm.gy), dim3(256), 0, as_stream(s), as_act<T>(ggx), as_act<T>(gy), as_act<T>(x), as_act<T>(y), pixels, C,
                        stats, act, slope, cm.lanes_c, cm.rows, ws);
-    hipLaunchKernelGGL(reduce_partials<5>, dim3((C + 31) / 32, 5), dim3(1024), 0, as_stream(s), ws, nblk, C, sums, 0);
+    hipLaunchKernelGGL(reduce_partials<5>, dim3((C + RP_CH - 1) / RP_CH, 5), dim3(1024), 0, as_stream(s), ws, nblk, C, sums, 0);
   }
   if (phase != 1) {
     const int nb2 = grid_for((size_t)pixels, cm.rows * 4, std::max(1, 4096 / cm.gy));

@@ -23,6 +23,18 @@ for ev in prof.key_averages(group_by_input_shape=True, group_by_stack_n=12):
     frames = [f for f in (ev.stack or []) if "learned_hologram_gan_amd" in f or "bench.py" in f]
     where = " < ".join(f.split("learned_hologram_gan_amd/")[-1].strip() for f in frames[:3])
     rows.append((ev.count, st, ev.key, str(ev.input_shapes)[:70], where[:200]))
+# stacks of the LARGE accumulations (autograd adds over activation-sized tensors): per-event, since key_averages drops the frames here
+seen = collections.Counter()
+for ev in prof.events():
+    if ev.name in ("aten::add_", "aten::add", "aten::copy_", "aten::fill_", "aten::zero_") and ev.input_shapes and ev.input_shapes[0] and len(ev.input_shapes[0]) == 4:
+        n = 1
+        for d in ev.input_shapes[0]:
+            n *= d
+        if n >= 1 << 20:
+            frames = [f for f in (ev.stack or []) if "learned_hologram_gan_amd" in f or "autograd" in f][:4]
+            seen[(ev.name, tuple(ev.input_shapes[0]), " < ".join(f.split("/")[-1].strip() for f in frames))] += 1
+for (name, shp, where), n in seen.most_common(30):
+    print(f"LARGE {n:3d} {name:12s} {shp} {where}")
 print("device-launching ATen ops of one train step, by call site:", sum(r[0] for r in rows), "launching ops")
 for n, st, name, shp, where in sorted(rows, reverse=True)[:80]:
     print(f"{n:4d} {st:9.1f} us  {name:22s} {shp:70s} {where}")
