@@ -559,9 +559,13 @@ def test_full_size_train_step_vs_oracle(oracle_full_step):
         for k, v in post.items():
             if k.endswith(("convolution_layer_1.bias", "convolution_layer_2.bias", "block2.0.bias", "block3.0.bias", "block4.0.bias", "block5.0.bias", "block6.0.bias")):
                 continue  # analytically zero gradient (conv bias in front of a train-mode BatchNorm): Adam turns rounding noise into +-lr
+            # How many weights may flip: two fp32 evaluations whose gradients are eps apart (relative L2) disagree in sign where
+            # |g_i| < ~eps rms(g), i.e. for a fraction ~0.8 eps of the elements.  At this size the float64-truth test records eps up to
+            # 1e-2 for BOTH evaluations on the first layer (encoder1 conv1: e_gpu 9.3e-3, e_cpu 1.08e-2, profiles/r05_truth_tests.jsonl):
+            # up to ~1.5 % flips there (measured 0.4 - 0.6 %); the small-size reference-loop test keeps its 0.5 %.
             d = (sd[k].cpu() - v).abs()
             bad = d > 2e-4 + 1e-3 * v.abs()
-            assert bad.float().mean().item() <= max(5e-3, 6.0 / v.numel()), (k, int(bad.sum()), v.numel())
+            assert bad.float().mean().item() <= max(2e-2, 6.0 / v.numel()), (k, int(bad.sum()), v.numel())
             assert not bad.any() or d[bad].max().item() <= 2.1 * lr, (k, d[bad].max().item())
 
 
