@@ -1,7 +1,7 @@
 """Regenerate the measured numbers of DESIGN.md from the committed records under profiles/, so that the text cannot drift from them
 ("What's weak" #8).  Everything between the two marker lines of DESIGN.md is replaced.
 
-    python tools/design_numbers.py [round tag, default r04]      (run it after copying new records into profiles/)
+    python tools/design_numbers.py [round tag, default r05]      (run it after copying new records into profiles/)
 
 Inputs: profiles/<tag>_bench_line.json (one line of `python bench.py`), <tag>_kernel_steady.txt (tools/steady_profile.py),
 <tag>_pmc_traffic.json (tools/pmc_traffic.py), <tag>_truth_tests.jsonl (tests/test_gpu_truth.py), <tag>_pmc_mfma.jsonl (tools/pmc_mfma.sh).
@@ -12,7 +12,7 @@ import re
 import sys
 
 REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TAG = sys.argv[1] if len(sys.argv) > 1 else "r04"
+TAG = sys.argv[1] if len(sys.argv) > 1 else "r05"
 BEGIN, END = "<!-- BEGIN GENERATED: measurements (tools/design_numbers.py) -->", "<!-- END GENERATED -->"
 
 
@@ -146,6 +146,17 @@ def main():
             for r_ in full:
                 out.append(f"| `{r_['mode']}` | " + " | ".join(f"{r_[k][0]:.1e} / {r_[k][1]:.1e} ({r_[k][0] / max(r_[k][1], 1e-300):.2f})" for k in keys) + " |")
             out.append("")
+            if any("grad_G_l2" in r_ for r_ in full):  # round 5: every parameter's gradient at the bench size
+                gkeys = ("grad_G_l2", "grad_G_worst_parameter", "grad_D_l2", "grad_D_worst_parameter")
+                out += [f"**Parameter gradients at the bench size against float64** (same records; relative L2, GPU / CPU-fp32 (ratio); `*_l2`: all parameters of a model as "
+                        "one vector, `*_worst_parameter`: the parameter (or the group of parameters with < 16 elements) with the largest ratio):", "",
+                        "| mode | " + " | ".join(gkeys) + " | three worst by name (ratio) |", "|---|" + "---|" * (len(gkeys) + 1)]
+                for r_ in full:
+                    if "grad_G_l2" not in r_:
+                        continue
+                    names = "; ".join(f"{t_}: {w_['name']} ({w_['ratio']:.1f})" for t_ in ("G", "D") for w_ in r_.get(f"worst_parameters_{t_}", [])[:3])
+                    out.append(f"| `{r_['mode']}` | " + " | ".join(f"{r_[k][0]:.1e} / {r_[k][1]:.1e} ({r_[k][0] / max(r_[k][1], 1e-300):.2f})" for k in gkeys) + f" | {names} |")
+                out.append("")
     path = os.path.join(REPO, "profiles", f"{TAG}_pmc_mfma.jsonl")
     if os.path.exists(path):
         out += [f"**Matrix-pipe occupancy** (`profiles/{TAG}_pmc_mfma.jsonl`):", "", "| layer (tag: mode_Cin_Cout_extent) | kernel matched | us | matrix pipe busy | clock GHz |", "|---|---|---|---|---|"]
