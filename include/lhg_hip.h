@@ -424,6 +424,13 @@ int lhg_asm_propagate(const float* in_a, const float* in_b, int in_mode, float p
                       float* out_a, float* out_b, float* out_complex, int out_mode,
                       float* ws, size_t ws_bytes, const float* twiddle_rows, const float* twiddle_cols,
                       lhg_stream_t s);
+/* ABI 9: the same with `in_planes` input fields and `planes` outputs — output q = crop(ifft2(filter_q . fft2(pad(input plane_src[q])))), plane_src
+ * a device int32[planes] (NULL: one to one).  The first pass (polar -> complex, row transforms) runs once per INPUT field: the reference's
+ * multi-distance __call__ (angular_spectrum_method.py:503-522) applies D transfer functions to every field.  ws >= (in_planes + planes) * rows0 * C * 8 bytes. */
+int lhg_asm_propagate_shared(const float* in_a, const float* in_b, int in_mode, float phase_scale,
+                             int in_planes, const int* plane_src, int planes, int rows0, int cols0, int pad_r, int pad_c,
+                             const lhg_asm_filter* filt, float* out_a, float* out_b, float* out_complex, int out_mode,
+                             float* ws, size_t ws_bytes, const float* twiddle_rows, const float* twiddle_cols, lhg_stream_t s);
 /* spectrum = F1 (.) F2 (.) FFT2(pad(in)) written in full (planes, rows, cols) complex64
  * (API parity with propagate_POH2Freq_forward / filter_AP2filteredFreq). */
 int lhg_asm_to_spectrum(const float* in_a, const float* in_b, int in_mode, float phase_scale,
@@ -437,6 +444,10 @@ int lhg_asm_from_spectrum(const float* spectrum, int planes, int rows0, int cols
                           float* out_a, float* out_b, float* out_complex, int out_mode,
                           float* ws, size_t ws_bytes, const float* twiddle_rows, const float* twiddle_cols,
                           lhg_stream_t s);
+/* ABI 9: several filters of one spectrum — output q = crop(ifft2(filter_q . spectrum[plane_src[q]])), plane_src a device int32[planes] (NULL: one to one). */
+int lhg_asm_from_spectrum_shared(const float* spectrum, const int* plane_src, int planes, int rows0, int cols0, int pad_r, int pad_c,
+                                 const lhg_asm_filter* filt, float* out_a, float* out_b, float* out_complex, int out_mode,
+                                 float* ws, size_t ws_bytes, const float* twiddle_rows, const float* twiddle_cols, lhg_stream_t s);
 /* The `twiddle_rows` / `twiddle_cols` table of a transform length n: lhg_fft_table_floats(n) floats, filled by lhg_fft_twiddles.
  * n a product of 2, 3, 5, 7, 11, 13 in [16, 4096] (and <= 256 x the per-thread budget of its largest radix: 3072 with a factor 3,
  * 3328 with 13, ...): twiddle[k] = exp(-2 pi i k / n), k < n (2n floats), computed in double on the device; the transform runs on

@@ -13,13 +13,20 @@ extents take the ``torch.fft`` route on the same device (rocFFT): still GPU-only
 
 from __future__ import annotations
 
+import os
+
 import torch
 
 from . import utilities
-from .asm_ops import (Factor, FromSpectrumFn, Geometry, PropagateFn, Spec, ToSpectrumFn)
+from .asm_ops import (Factor, FromSpectrumFn, Geometry, PropagateFn, Spec, ToSpectrumFn, from_spectrum_raw, propagate_raw, to_spectrum_raw)
 from .native import F_DIV, F_MUL, IN_PHASE, IN_POLAR, OUT_ABS, OUT_ABS_ANGLE, OUT_COMPLEX
 
 _DEFAULT_WL = (639e-9, 515e-9, 473e-9)
+
+
+# multi-distance __call__: from this many distances per field on, the field's full spectrum is computed once and every distance is a filtered
+# inverse pass of it (LHG_ASM_SHARE_SPECTRUM: 0 = never; the spectrum costs R x C instead of rows0 x C per plane in HBM)
+_SHARE_SPECTRUM_FROM = int(os.environ.get("LHG_ASM_SHARE_SPECTRUM", "3")) or (1 << 30)
 
 
 class bandLimitedAngularSpectrumMethod:
@@ -293,6 +300,22 @@ class bandLimitedAngularSpectrumMethod_for_multiple_distances(bandLimitedAngular
         """(B,3,h,w) x D distances -> |g| (B*D,3,h,w), sample-major. ref: :503-522."""
         D = int(torch.as_tensor(distances).numel())
         B = amplitute_tensor.shape[0]
+        if (self._geom.supported() and amplitute_tensor.is_cuda and amplitute_tensor.shape[1] == 3
+                and not (torch.is_grad_enabled() and (amplitute_tensor.requires_grad or phase_tensor.requires_grad))):
+            # every field goes to D planes: the first pass (polar -> complex, row transforms) once per FIELD, the D filtered column / inverse
+            # passes read it by index — no (B D, 3, h, w) copies of the inputs, B 3 instead of B D 3 row-transform planes
+            key = ("src", B, D)
+            if key not in self._index_cache:
+                b_, c_ = torch.arange(B).view(B, 1, 1), torch.arange(3).view(1, 1, 3)
+                self._index_cache[key] = (b_ * 3 + c_).expand(B, D, 3).reshape(-1).to(torch.int32).to(self.device)
+            idx = self._colour_index(3 * B * D, torch.arange(D).repeat(B))
+            f = (Factor(self._masked_H_for_call(distances), F_MUL, idx),)
+            if D >= _SHARE_SPECTRUM_FROM:
+                # ... and the forward column transforms too: the fields' spectra once (B 3 planes), then D filtered inverse passes each
+                S = to_spectrum_raw(amplitute_tensor, phase_tensor, Spec(self._geom, IN_POLAR, OUT_COMPLEX, 1.0, ()))
+                return from_spectrum_raw(S, Spec(self._geom, IN_PHASE, OUT_ABS, 1.0, f), plane_src=self._index_cache[key], out_lead=(B * D, 3))[0]
+            return propagate_raw(amplitute_tensor, phase_tensor, Spec(self._geom, IN_POLAR, OUT_ABS, 1.0, f), plane_src=self._index_cache[key],
+                                 out_lead=(B * D, 3))[0]
         a = amplitute_tensor.unsqueeze(1).expand(B, D, *amplitute_tensor.shape[1:]).reshape(B * D, *amplitute_tensor.shape[1:])
         p = phase_tensor.unsqueeze(1).expand(B, D, *phase_tensor.shape[1:]).reshape(B * D, *phase_tensor.shape[1:])
         idx = self._colour_index(3 * B * D, torch.arange(D).repeat(B))

@@ -128,13 +128,22 @@ def _workspace(planes, geom, device, n_buffers):
     return torch.empty((nbytes // 4,), dtype=torch.float32, device=device), nbytes
 
 
-def propagate_raw(a, b, spec: Spec, want_complex_copy=False):
-    """Run the three passes.  a, b: real (..., rows0, cols0) (b None for IN_PHASE) or a complex for IN_COMPLEX."""
+def propagate_raw(a, b, spec: Spec, want_complex_copy=False, plane_src=None, out_lead=None):
+    """Run the three passes.  a, b: real (..., rows0, cols0) (b None for IN_PHASE) or a complex for IN_COMPLEX.
+    ``plane_src`` (int32 device tensor) + ``out_lead`` (leading shape of the outputs): several filters of ONE field — output plane q is
+    input plane plane_src[q] under filter q; the first pass runs once per input plane (lhg_asm_propagate_shared)."""
     g = spec.geom
-    lead = a.shape[:-2]
+    in_planes = 1
+    for d in a.shape[:-2]:
+        in_planes *= d
+    lead = a.shape[:-2] if out_lead is None else tuple(out_lead)
     planes = 1
     for d in lead:
         planes *= d
+    if plane_src is None and planes != in_planes:
+        raise ValueError("propagate_raw: another number of outputs than inputs needs plane_src")
+    if plane_src is not None and (plane_src.dtype != torch.int32 or plane_src.numel() != planes):
+        raise ValueError("plane_src must be int32 with one entry per output plane")
     if tuple(a.shape[-2:]) != (g.rows0, g.cols0):
         raise ValueError(f"field has extent {tuple(a.shape[-2:])}, geometry says {(g.rows0, g.cols0)}")
     dev = a.device
@@ -152,7 +161,8 @@ def propagate_raw(a, b, spec: Spec, want_complex_copy=False):
         if spec.in_mode == IN_POLAR and b is None:
             raise ValueError("IN_POLAR needs amplitude and phase")
     st, keep = _filter_struct(spec.factors, planes, g)
-    ws, nbytes = _workspace(planes, g, dev, 2)
+    nbytes = (in_planes + planes) * g.rows0 * g.cols * 8
+    ws = torch.empty((nbytes // 4,), dtype=torch.float32, device=dev)
     out_a = out_b = out_c = None
     shape = tuple(lead) + (g.rows0, g.cols0)
     if spec.out_mode == OUT_COMPLEX or want_complex_copy:
@@ -161,8 +171,8 @@ def propagate_raw(a, b, spec: Spec, want_complex_copy=False):
         out_a = torch.empty(shape, dtype=torch.float32, device=dev)
     if spec.out_mode == OUT_ABS_ANGLE:
         out_b = torch.empty(shape, dtype=torch.float32, device=dev)
-    call("lhg_asm_propagate", pa, pb, spec.in_mode, float(spec.phase_scale), planes, g.rows0, g.cols0, g.pad_r, g.pad_c,
-         ctypes.addressof(st), ptr(out_a), ptr(out_b), ptr(torch.view_as_real(out_c)) if out_c is not None else None,
+    call("lhg_asm_propagate_shared", pa, pb, spec.in_mode, float(spec.phase_scale), in_planes, ptr(plane_src), planes, g.rows0, g.cols0, g.pad_r,
+         g.pad_c, ctypes.addressof(st), ptr(out_a), ptr(out_b), ptr(torch.view_as_real(out_c)) if out_c is not None else None,
          spec.out_mode, ptr(ws), nbytes, ptr(twiddles(g.rows, dev)), ptr(twiddles(g.cols, dev)), stream_ptr())
     del keep
     return out_a, out_b, out_c
@@ -191,12 +201,15 @@ def to_spectrum_raw(a, b, spec: Spec):
     return out
 
 
-def from_spectrum_raw(S, spec: Spec, want_complex_copy=False):
+def from_spectrum_raw(S, spec: Spec, want_complex_copy=False, plane_src=None, out_lead=None):
+    """``plane_src`` + ``out_lead``: several filters of one spectrum (output plane q reads spectrum plane plane_src[q])."""
     g = spec.geom
-    lead = S.shape[:-2]
+    lead = S.shape[:-2] if out_lead is None else tuple(out_lead)
     planes = 1
     for d in lead:
         planes *= d
+    if plane_src is not None and (plane_src.dtype != torch.int32 or plane_src.numel() != planes):
+        raise ValueError("plane_src must be int32 with one entry per output plane")
     if tuple(S.shape[-2:]) != (g.rows, g.cols) or S.dtype != torch.complex64:
         raise ValueError("spectrum must be complex64 (..., rows, cols)")
     dev = S.device
@@ -211,7 +224,7 @@ def from_spectrum_raw(S, spec: Spec, want_complex_copy=False):
         out_a = torch.empty(shape, dtype=torch.float32, device=dev)
     if spec.out_mode == OUT_ABS_ANGLE:
         out_b = torch.empty(shape, dtype=torch.float32, device=dev)
-    call("lhg_asm_from_spectrum", ptr(torch.view_as_real(S)), planes, g.rows0, g.cols0, g.pad_r, g.pad_c, ctypes.addressof(st),
+    call("lhg_asm_from_spectrum_shared", ptr(torch.view_as_real(S)), ptr(plane_src), planes, g.rows0, g.cols0, g.pad_r, g.pad_c, ctypes.addressof(st),
          ptr(out_a), ptr(out_b), ptr(torch.view_as_real(out_c)) if out_c is not None else None, spec.out_mode, ptr(ws), nbytes,
          ptr(twiddles(g.rows, dev)), ptr(twiddles(g.cols, dev)), stream_ptr())
     del keep

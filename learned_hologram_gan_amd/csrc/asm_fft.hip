@@ -564,6 +564,7 @@ __global__ __launch_bounds__(MAXT) void rows_forward_kernel(const float* __restr
 // ---------------------------------------------------------------------------------------- pass 2
 struct ColsParams {
   const float2* src; int src_rows, src_off;   // rows present in src (rows0 or R) and their offset inside R
+  const int* src_index;                       // nullptr, or per output plane the plane of src it reads (several filters of one field: lhg_asm_propagate_shared)
   float2* dst; int dst_rows, dst_off;
   int planes, R, C, G;                        // G columns per workgroup
   int M;                                      // 0, or the Bluestein convolution length of R
@@ -599,7 +600,7 @@ __global__ __launch_bounds__(PRIMES ? 512 : 1024) void cols_filter_kernel(const 
   constexpr int CU = 4;
   const int total = p.R * p.G;
   {
-    const float2* srcp = p.src + (size_t)plane * p.src_rows * p.C + c0;
+    const float2* srcp = p.src + (size_t)(p.src_index ? p.src_index[plane] : plane) * p.src_rows * p.C + c0;
     int i = tid;
     for (; i + (CU - 1) * nth < total; i += CU * nth) {
       float2 z[CU];
@@ -984,17 +985,31 @@ int lhg_fft_twiddles(float* twiddle, int n, lhg_stream_t s) {
 int lhg_asm_propagate(const float* in_a, const float* in_b, int in_mode, float phase_scale, int planes, int rows0, int cols0, int pad_r,
                       int pad_c, const lhg_asm_filter* filt, float* out_a, float* out_b, float* out_complex, int out_mode, float* ws,
                       size_t ws_bytes, const float* twiddle_rows, const float* twiddle_cols, lhg_stream_t s) {
+  return lhg_asm_propagate_shared(in_a, in_b, in_mode, phase_scale, planes, nullptr, planes, rows0, cols0, pad_r, pad_c, filt, out_a, out_b, out_complex,
+                                  out_mode, ws, ws_bytes, twiddle_rows, twiddle_cols, s);
+}
+
+// `in_planes` input fields, `planes` outputs: output plane q = crop(ifft2(filter_q . fft2(pad(input plane plane_src[q])))).  The first pass
+// (polar -> complex, row transforms) runs ONCE per input field, however many filters are applied to it: the reference's multi-distance
+// __call__ (angular_spectrum_method.py:503-522) propagates every field to D planes — 8 at the 4K frame: 24 of its 27 row-transform planes
+// were the same three transformed eight times (2.8 ms of a 55 ms frame).  plane_src == nullptr: in_planes == planes, one to one.
+int lhg_asm_propagate_shared(const float* in_a, const float* in_b, int in_mode, float phase_scale, int in_planes, const int* plane_src, int planes,
+                             int rows0, int cols0, int pad_r, int pad_c, const lhg_asm_filter* filt, float* out_a, float* out_b, float* out_complex,
+                             int out_mode, float* ws, size_t ws_bytes, const float* twiddle_rows, const float* twiddle_cols, lhg_stream_t s) {
   int rc = check_geometry(planes, rows0, cols0, pad_r, pad_c, "asm_propagate");
   if (rc) return rc;
+  LHG_REQUIRE(in_planes > 0 && (plane_src != nullptr || in_planes == planes), "asm_propagate: %d input planes for %d outputs need a plane_src index", in_planes, planes);
   const int R = rows0 + 2 * pad_r, C = cols0 + 2 * pad_c;
-  const size_t tbytes = (size_t)planes * rows0 * C * sizeof(float2);
-  if (ws_bytes < 2 * tbytes) return fail(LHG_E_WORKSPACE, "asm_propagate: workspace %zu < %zu", ws_bytes, 2 * tbytes);
+  const size_t plane_bytes = (size_t)rows0 * C * sizeof(float2);
+  if (ws_bytes < (size_t)(in_planes + planes) * plane_bytes)
+    return fail(LHG_E_WORKSPACE, "asm_propagate: workspace %zu < %zu", ws_bytes, (size_t)(in_planes + planes) * plane_bytes);
   float2* t1 = reinterpret_cast<float2*>(ws);
-  float2* t2 = t1 + (size_t)planes * rows0 * C;
+  float2* t2 = t1 + (size_t)in_planes * rows0 * C;
   hipStream_t st = as_stream(s);
-  rc = run_rows_forward(in_a, in_b, in_mode, phase_scale, planes, rows0, cols0, pad_c, C, twiddle_cols, t1, st);
+  rc = run_rows_forward(in_a, in_b, in_mode, phase_scale, in_planes, rows0, cols0, pad_c, C, twiddle_cols, t1, st);
   if (rc) return rc;
   ColsParams p{};
+  p.src_index = plane_src;
   p.src = t1; p.src_rows = rows0; p.src_off = pad_r; p.dst = t2; p.dst_rows = rows0; p.dst_off = pad_r;
   p.planes = planes; p.R = R; p.C = C; p.do_fwd = 1; p.do_inv = 1; p.scale = 1.f / ((float)R * (float)C);
   p.tw = reinterpret_cast<const float2*>(twiddle_rows);
@@ -1027,6 +1042,14 @@ int lhg_asm_to_spectrum(const float* in_a, const float* in_b, int in_mode, float
 int lhg_asm_from_spectrum(const float* spectrum, int planes, int rows0, int cols0, int pad_r, int pad_c, const lhg_asm_filter* filt,
                           float* out_a, float* out_b, float* out_complex, int out_mode, float* ws, size_t ws_bytes,
                           const float* twiddle_rows, const float* twiddle_cols, lhg_stream_t s) {
+  return lhg_asm_from_spectrum_shared(spectrum, nullptr, planes, rows0, cols0, pad_r, pad_c, filt, out_a, out_b, out_complex, out_mode, ws, ws_bytes,
+                                      twiddle_rows, twiddle_cols, s);
+}
+
+// output plane q = crop(ifft2(filter_q . spectrum[plane_src[q]])): several filters of one spectrum (plane_src == nullptr: one to one)
+int lhg_asm_from_spectrum_shared(const float* spectrum, const int* plane_src, int planes, int rows0, int cols0, int pad_r, int pad_c,
+                                 const lhg_asm_filter* filt, float* out_a, float* out_b, float* out_complex, int out_mode, float* ws, size_t ws_bytes,
+                                 const float* twiddle_rows, const float* twiddle_cols, lhg_stream_t s) {
   int rc = check_geometry(planes, rows0, cols0, pad_r, pad_c, "asm_from_spectrum");
   if (rc) return rc;
   const int R = rows0 + 2 * pad_r, C = cols0 + 2 * pad_c;
@@ -1035,6 +1058,7 @@ int lhg_asm_from_spectrum(const float* spectrum, int planes, int rows0, int cols
   float2* t2 = reinterpret_cast<float2*>(ws);
   hipStream_t st = as_stream(s);
   ColsParams p{};
+  p.src_index = plane_src;
   p.src = reinterpret_cast<const float2*>(spectrum); p.src_rows = R; p.src_off = 0; p.dst = t2; p.dst_rows = rows0; p.dst_off = pad_r;
   p.planes = planes; p.R = R; p.C = C; p.do_fwd = 0; p.do_inv = 1; p.scale = 1.f / ((float)R * (float)C);
   p.tw = reinterpret_cast<const float2*>(twiddle_rows);

@@ -92,8 +92,10 @@ _SIGNATURES = {
     "lhg_maxpool2x2_backward_add": [_p, _i, _p, _i, _i, _i, _i, _i, _p, _i, _p, _i, _p],
     "lhg_act_backward": [_p, _i, _p, _i, _ll, _i, _i, _f, _p, _i, _p],
     "lhg_asm_propagate": [_p, _p, _i, _f, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _sz, _p, _p, _p],
+    "lhg_asm_propagate_shared": [_p, _p, _i, _f, _i, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _sz, _p, _p, _p],
     "lhg_asm_to_spectrum": [_p, _p, _i, _f, _i, _i, _i, _i, _i, _p, _p, _p, _sz, _p, _p, _p],
     "lhg_asm_from_spectrum": [_p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _sz, _p, _p, _p],
+    "lhg_asm_from_spectrum_shared": [_p, _p, _i, _i, _i, _i, _i, _p, _p, _p, _p, _i, _p, _sz, _p, _p, _p],
     "lhg_fft_table_floats": [_i],
     "lhg_fft_twiddles": [_p, _i, _p],
     "lhg_symconv_field": [_p, _i, _i, _i, _p, _p, _p, _p, _p],

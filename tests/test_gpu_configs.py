@@ -181,6 +181,23 @@ def test_config4_per_rank_bs1_three_plane_reconstruction_loss_384(precision):
 
 
 # ----------------------------------------------------------------------------- configs[3]: one 4K frame end to end
+def test_multi_distance_call_shares_the_first_pass_between_the_distances():
+    """``__call__`` (angular_spectrum_method.py:503-522: every field to D planes) runs the first pass — polar -> complex, row transforms —
+    once per FIELD and lets the D filtered column / inverse passes read it by index (lhg_asm_propagate_shared, round 5).  Same kernels on
+    the same values: bit-identical to the form that materialises the (B D, 3, h, w) copies, which a call that records gradients still takes."""
+    for (h, w, pad, B, D) in ((64, 96, 32, 2, 5), (192, 192, 160, 1, 3), (48, 80, 8, 3, 1)):
+        d = torch.linspace(4e-4, 10e-4, D)
+        prop = _multi(h, w, d, pad, 0.35)
+        g = torch.Generator().manual_seed(h + D)
+        amp, phs = torch.rand((B, 3, h, w), generator=g).to(DEV), (torch.rand((B, 3, h, w), generator=g) * 6.28).to(DEV)
+        with torch.no_grad():
+            shared = prop(amp, phs, d)
+        with torch.enable_grad():
+            copies = prop(amp.clone().requires_grad_(True), phs, d)
+        assert shared.shape == copies.shape == (B * D, 3, h, w)
+        assert torch.equal(shared, copies.detach()), (h, w, pad, B, D, (shared - copies.detach()).abs().max().item())
+
+
 def test_config3_4k_generator_tail_and_eight_plane_propagation():
     """BASELINE configs[3]: one 3840x2160 frame through the eval-mode Generator (pad 72 -> 2304x4096 transforms) and the hologram
     propagated to 8 planes by ``__call__`` (generatePOH.py --propagate).  The UNet is checked on a crop by
