@@ -213,6 +213,11 @@ int lhg_conv2d_thin_supported(int Ci, int Co, int k, int stride);
 int lhg_conv2d_thin_forward(const float* x, int N, int H, int W, int Ci, int ldx, const float* w, int Co, int k,
                             float* y, int ldy, const float* bias, const float* scale, const float* shift,
                             int act, float slope, int planar_out, lhg_stream_t s);
+/* ABI 9: the same with `y_absmax` (may be NULL; thin INPUT only): max|y| max-accumulated on the way out, as lhg_conv2d_forward's — the first conv of
+ * an eval-mode generator (4 -> 64, folded BatchNorm + ReLU) feeds a GEMM directly, and lhg_absmax over its output was 0.44 ms of a 4K frame. */
+int lhg_conv2d_thin_forward_amax(const float* x, int N, int H, int W, int Ci, int ldx, const float* w, int Co, int k,
+                                 float* y, int ldy, const float* bias, const float* scale, const float* shift,
+                                 int act, float slope, int planar_out, float* y_absmax, lhg_stream_t s);
 int lhg_conv2d_thin_backward_input(const float* gy, int N, int H, int W, int Co, int ldgy, const float* w, int Ci, int k,
                                    float* gx, int ldgx, lhg_stream_t s);
 /* gw (Co, Ci, k, k) written in place (deterministic two-stage sum); ws >= lhg_conv2d_thin_wgrad_workspace bytes. */

@@ -810,6 +810,15 @@ static int rows_nf(int n) {
 }
 // twiddles go to LDS next to the lines when both fit
 static bool tw_fits(size_t line_bytes, int L) { return line_bytes + (size_t)L * sizeof(float2) <= 150 * 1024; }
+// Row passes: twiddles in LDS beside the lines only while that keeps >= `min_wg` workgroups on a CU (LHG_ASM_ROWS_MIN_WG, default 4).  A
+// 4096-point row (the 4K frame) is one 32 KB line per 256-thread workgroup: with its 32 KB of twiddles in LDS as well a CU holds two
+// workgroups — eight waves to hide the latency of 70 MB planes — without them four or five; the twiddles then come from L2.
+static bool rows_tw_fits(size_t line_bytes, int L) {
+  static const int min_wg = [] { const char* e = getenv("LHG_ASM_ROWS_MIN_WG"); return e ? atoi(e) : 4; }();
+  const size_t with_tw = line_bytes + (size_t)L * sizeof(float2);
+  if (!tw_fits(line_bytes, L)) return false;
+  return min_wg <= 1 || with_tw * (size_t)min_wg <= 160 * 1024 || line_bytes * (size_t)min_wg > 160 * 1024;  // (no gain from dropping them if the lines alone do not allow min_wg)
+}
 
 static int set_dyn_lds(const void* fn, size_t bytes) {
   if (bytes > 160 * 1024) return fail(LHG_E_ARG, "asm: LDS request %zu exceeds 160 KiB", bytes);
@@ -861,7 +870,7 @@ static int run_rows_forward(const float* in_a, const float* in_b, int in_mode, f
   if (asm_reg_enabled() && cols == 256) return run_rows_forward_reg<16, 16>(in_a, in_b, in_mode, phase_scale, planes * rows0, cols0, pad_c, tw_cols, t1, st);
   const int m = bluestein_len(cols), L = m ? m : cols;
   const int nf = rows_nf(L);
-  const int tw_lds = tw_fits((size_t)nf * L * sizeof(float2), L);
+  const int tw_lds = rows_tw_fits((size_t)nf * L * sizeof(float2), L);
   const size_t lds = lds_request((size_t)((tw_lds ? L : 0) + nf * L) * sizeof(float2));
   const int total_rows = planes * rows0;
   auto launch = [&](auto kernel) {
@@ -882,7 +891,7 @@ static int run_rows_inverse(const float2* t2, int planes, int rows0, int cols0, 
   if (asm_reg_enabled() && cols == 256) return run_rows_inverse_reg<16, 16>(t2, planes * rows0, cols0, pad_c, tw_cols, out_a, out_b, out_c, out_mode, st);
   const int m = bluestein_len(cols), L = m ? m : cols;
   const int nf = rows_nf(L);
-  const int tw_lds = tw_fits((size_t)nf * L * sizeof(float2), L);
+  const int tw_lds = rows_tw_fits((size_t)nf * L * sizeof(float2), L);
   const size_t lds = lds_request((size_t)((tw_lds ? L : 0) + nf * L) * sizeof(float2));
   const int total_rows = planes * rows0;
   auto launch = [&](auto kernel) {

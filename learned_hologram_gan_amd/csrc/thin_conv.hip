@@ -37,6 +37,7 @@ struct ThinParams {
   float slope;
   int nwaves;          // wgrad: number of partial slabs
   int wpc;             // fan-out / wgrad: waves of a workgroup along the channel axis (1, 2 or 4)
+  float* out_amax;     // fan-out (may be null): max|stored value| is max-accumulated here (LHG_ABSMAX_WORDS zero-filled floats), as the GEMM epilogues' y_absmax
 };
 
 template <int T>
@@ -135,6 +136,7 @@ __global__ __launch_bounds__(256) void thin_fanout_kernel(const ThinParams p, co
 
   const int per = ((x_cnt + wpp - 1) / wpp + TP - 1) / TP * TP;
   const int xs = wp * per, xe = min(x_cnt, xs + per);
+  float amax = 0.f;
   for (int x0 = xs; x0 < xe; x0 += TP) {
     float acc[TP];
 #pragma unroll
@@ -158,8 +160,19 @@ __global__ __launch_bounds__(256) void thin_fanout_kernel(const ThinParams p, co
       float* o = out + ((long long)row * p.W + x_begin + x0) * p.ld_o + c;
 #pragma unroll
       for (int j = 0; j < TP; ++j)
-        if (x0 + j < xe) o[(long long)j * p.ld_o] = apply_act(acc[j] * sc + sh, p.act, p.slope);
+        if (x0 + j < xe) {
+          const float v = apply_act(acc[j] * sc + sh, p.act, p.slope);
+          o[(long long)j * p.ld_o] = v;
+          amax = fmaxf(amax, fabsf(v));
+        }
     }
+  }
+  if (p.out_amax) {  // (uniform) the tensor scale of the GEMM that reads this output, without an lhg_absmax pass over it (round 5: 0.44 ms of a 4K frame)
+    unsigned m = __float_as_uint(amax);
+#pragma unroll
+    for (int o_ = 32; o_ > 0; o_ >>= 1) m = max(m, (unsigned)__shfl_xor((int)m, o_, 64));
+    unsigned* slot = reinterpret_cast<unsigned*>(p.out_amax);
+    if (lane == 0 && m > *reinterpret_cast<volatile unsigned*>(slot)) atomicMax(slot, m);
   }
 }
 
@@ -250,6 +263,30 @@ __global__ __launch_bounds__(256) void thin_fanin_kernel(const ThinParams p) {
     // four / eight, whose lanes all hold that group's sum by then — the same pairs of sums as xor 4 / 8, same bits); only distances 16 and
     // 32 go through the LDS crossbar (ds_bpermute).  Measured: no change of the kernels' time — 32 permutes per four pixels were not what
     // bounds the 64 -> 6 head (120 us for 151 MB at 384^2) — kept because it takes that traffic off the LDS unit.
+    if constexpr (CT == 8) {
+      if (p.lpp >= 8) {  // (wave-uniform)
+        // Reduce-SCATTER over the low three lane bits (round 5): at each stage a lane keeps half of its values — those whose output index
+        // has the lane's bit — and hands the other half to its partner, so that after three stages lane (cl & 7) holds output cl & 7
+        // summed over its eight lanes; the remaining stages are plain exchanges of that one value.  30 vector operations instead of 64,
+        // and — what matters for the 64 -> 6 sigmoid head (1.56 ms of the 4K frame, vector-ALU bound) — every lane finishes ONE output
+        // (bias, activation, store) instead of the wave issuing all eight for the pixel's first lane.
+        const bool b0 = (cl & 1) != 0, b1 = (cl & 2) != 0, b2 = (cl & 4) != 0;
+        float s4[4], s2[2];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) s4[i] = (b0 ? acc[2 * i + 1] : acc[2 * i]) + dpp_f32<0xB1>(b0 ? acc[2 * i] : acc[2 * i + 1]);  // partner: lane ^ 1
+#pragma unroll
+        for (int i = 0; i < 2; ++i) s2[i] = (b1 ? s4[2 * i + 1] : s4[2 * i]) + dpp_f32<0x4E>(b1 ? s4[2 * i] : s4[2 * i + 1]);    // partner: lane ^ 2
+        float v = (b2 ? s2[1] : s2[0]) + __shfl_xor(b2 ? s2[0] : s2[1], 4, 64);
+        for (int m = 8; m < p.lpp; m <<= 1) v += __shfl_xor(v, m, 64);
+        const int ct = cl & 7;
+        if (live && cl < 8 && ct < p.ct_real) {
+          const int n = row / p.H;
+          float* o = p.planar ? p.out + (((long long)n * p.ct_real + ct) * p.H + y) * p.W + x : p.out + ((long long)row * p.W + x) * p.ld_o + ct;
+          *o = apply_act(v + (p.bias ? p.bias[ct] : 0.f), p.act, p.slope);
+        }
+        continue;
+      }
+    }
     if (p.lpp > 1) {
 #pragma unroll
       for (int ct = 0; ct < CT; ++ct) acc[ct] += dpp_f32<0xB1>(acc[ct]);    // quad_perm [1,0,3,2]
@@ -517,7 +554,14 @@ int lhg_conv2d_thin_supported(int Ci, int Co, int k, int stride) {
 int lhg_conv2d_thin_forward(const float* x, int N, int H, int W, int Ci, int ldx, const float* w, int Co, int k, float* y, int ldy,
                             const float* bias, const float* scale, const float* shift, int act, float slope, int planar_out,
                             lhg_stream_t s) {
+  return lhg_conv2d_thin_forward_amax(x, N, H, W, Ci, ldx, w, Co, k, y, ldy, bias, scale, shift, act, slope, planar_out, nullptr, s);
+}
+
+int lhg_conv2d_thin_forward_amax(const float* x, int N, int H, int W, int Ci, int ldx, const float* w, int Co, int k, float* y, int ldy,
+                                 const float* bias, const float* scale, const float* shift, int act, float slope, int planar_out,
+                                 float* y_absmax, lhg_stream_t s) {
   const int mode = lhg_conv2d_thin_supported(Ci, Co, k, 1);
+  LHG_REQUIRE(y_absmax == nullptr || mode == 1, "conv2d_thin_forward: max|y| is measured by the thin-INPUT kernels only (a wide output that feeds a GEMM)");
   LHG_REQUIRE(!act_is_bf16(), "conv2d_thin_forward: thin convolutions take fp32 tensors (bf16 storage routes every layer to the MFMA path)");
   LHG_REQUIRE(mode != 0, "conv2d_thin_forward: %d -> %d channels, %dx%d is not a thin convolution", Ci, Co, k, k);
   LHG_REQUIRE(N > 0 && H > 0 && W > 0 && ldx >= Ci && (planar_out || ldy >= Co), "conv2d_thin_forward: bad extents");
@@ -529,7 +573,7 @@ int lhg_conv2d_thin_forward(const float* x, int N, int H, int W, int Ci, int ldx
   const int T = k * k;
   if (mode == 1) {  // thin = x (ci), wide = y (co): W(t, ci, co) = w[co*Ci*T + ci*T + t]
     p.thin = x; p.ld_t = ldx; p.ct_real = Ci; p.out = y; p.ld_o = ldy; p.cw = Co; p.wide = y; p.ld_w = ldy;
-    p.st = T; p.sw = Ci * T;
+    p.st = T; p.sw = Ci * T; p.out_amax = y_absmax;
     return dispatch_thin(K_FANOUT, k, p, as_stream(s));
   }
   // thin = y (co), wide = x (ci): W(t, co, ci) = w[co*Ci*T + ci*T + t]

@@ -909,8 +909,12 @@ def conv2d_forward_raw(x, w, bias, stride, act=ACT_NONE, slope=0.0, scale=None, 
         else:
             y = _resolve_out(out, (N, H, W, Co), x.device)
             py, _, _, _, _, ldy = nhwc(y)
-        call("lhg_conv2d_thin_forward", px, N, H, W, Ciw, ldx, ptr(_raw_weight(w)), Co, KH, py, ldy, ptr(bias), ptr(scale), ptr(shift),
-             act, float(slope), int(planar), stream_ptr())
+        # measure_out (thin input, NHWC output that feeds a GEMM directly: eval-mode chains): the kernel measures max|y| as the GEMM epilogues do
+        y_amax = _out_amax(out, x.device) if (measure_out and mode == 1 and not planar) else None
+        call("lhg_conv2d_thin_forward_amax", px, N, H, W, Ciw, ldx, ptr(_raw_weight(w)), Co, KH, py, ldy, ptr(bias), ptr(scale), ptr(shift),
+             act, float(slope), int(planar), ptr(y_amax), stream_ptr())
+        if y_amax is not None:
+            tag_absmax(y, y_amax)
         return y
     wp = pack_weight(w, True)
     Ho, Wo = _conv_out_hw(H, W, KH, stride)

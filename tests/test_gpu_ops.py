@@ -500,6 +500,18 @@ def test_thin_conv_epilogues(ops):
     ref2 = torch.sigmoid(F.conv2d(x2, w2, b2))
     y2 = ops.conv2d_forward_raw(to_nhwc(x2), w2.to(DEV), b2.to(DEV), 1, act=ops.ACT_SIGMOID, planar=True)
     assert y2.shape == (N, 6, H, W) and rel_err(y2.cpu(), ref2) < TOL
+    # round 5: a thin-INPUT conv whose output feeds a GEMM directly (eval-mode chains) measures max|y| itself (lhg_conv2d_thin_forward_amax),
+    # and the 64 -> 6 head finishes one output per lane (reduce-scatter): odd widths, every lane count of the tail
+    if ops.conv_precision() == "fp32_split_f16":
+        ym = ops.conv2d_forward_raw(to_nhwc(x, 32), w.to(DEV), b.to(DEV), 1, act=ops.ACT_RELU, scale=sc.to(DEV), shift=sh.to(DEV), measure_out=True)
+        tag = ym.__dict__.get("_lhg_amax")
+        assert tag is not None and tag[1].item() == ym.abs().max().item() and torch.equal(ym, y)
+    for (n_, h_, w_) in ((1, 5, 3), (2, 7, 66), (1, 1, 257)):
+        x3, w3, b3 = rnd(n_, 64, h_, w_, seed=9), rnd(6, 64, 1, 1, seed=10, scale=0.3), rnd(6, seed=11)
+        for planar in (True, False):
+            y3 = ops.conv2d_forward_raw(to_nhwc(x3), w3.to(DEV), b3.to(DEV), 1, act=ops.ACT_SIGMOID, planar=planar)
+            got = y3.cpu() if planar else to_nchw(y3, 6)
+            assert rel_err(got, torch.sigmoid(F.conv2d(x3, w3, b3))) < TOL, (n_, h_, w_, planar)
 
 
 def test_thin_conv_double_backward(ops):
