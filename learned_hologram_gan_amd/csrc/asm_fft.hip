@@ -578,8 +578,11 @@ struct ColsParams {
 
 // (PRIMES: at most 512 threads, so that the 13-point butterflies keep their values in registers — with 1024 threads the 128-VGPR budget
 // spills them to scratch)
-template <bool PRIMES>
-__global__ __launch_bounds__(PRIMES ? 512 : 1024) void cols_filter_kernel(const ColsParams p) {
+// MAXT = 768 (round 5): six waves per SIMD for TWO 12-wave workgroups on a CU (<= 85 VGPRs, <= 80 KB of LDS each) — the 2304-point columns of the
+// 4K frame: with one 1024-thread workgroup per CU (four columns + twiddles = 92 KB) the load, transform and store phases of a workgroup had
+// nothing to overlap with.
+template <bool PRIMES, int MAXT = (PRIMES ? 512 : 1024)>
+__global__ __launch_bounds__(MAXT, MAXT == 768 ? 6 : 1) void cols_filter_kernel(const ColsParams p) {
   const int L = p.M ? p.M : p.R;
   float2* twl = reinterpret_cast<float2*>(lds_raw);
   float2* buf = p.tw_in_lds ? twl + L : twl;
@@ -936,6 +939,23 @@ static int run_cols(ColsParams& p, hipStream_t st) {
   while (threads > 64 && (long long)G * L <= 2ll * threads) threads >>= 1;  // small transforms: fewer idle waves
   p.G = G;
   p.tw_in_lds = tw_fits((size_t)G * (L + 1) * sizeof(float2), L);
+  // two workgroups per CU where the default leaves one (direct 2^a 3^b lengths whose line set exceeds half the LDS): the largest G whose
+  // lines fit 80 KB, twiddles from L2, <= 768 threads (LHG_ASM_COLS_2WG=0: the one-workgroup form, for A/B measurements)
+  static const bool two_wg = [] { const char* e = getenv("LHG_ASM_COLS_2WG"); return !e || atoi(e) != 0; }();
+  if (two_wg && p.M == 0 && !has_prime_radix(L) && ((size_t)G * (L + 1) + (p.tw_in_lds ? L : 0)) * sizeof(float2) > 80 * 1024) {
+    int G2 = 16;
+    while (G2 > 1 && ((size_t)G2 * (L + 1) * sizeof(float2) > 80 * 1024 || p.C % G2 != 0)) G2 >>= 1;
+    const long long t2 = (((long long)G2 * L + budget - 1) / budget + 63) / 64 * 64;
+    if (G2 >= 4 && t2 <= 768 && (size_t)G2 * (L + 1) * sizeof(float2) <= 80 * 1024) {
+      p.G = G2;
+      p.tw_in_lds = 0;
+      const size_t lds2 = lds_request((size_t)G2 * (L + 1) * sizeof(float2));
+      int rc = set_dyn_lds(reinterpret_cast<const void*>(cols_filter_kernel<false, 768>), lds2);
+      if (rc) return rc;
+      hipLaunchKernelGGL((cols_filter_kernel<false, 768>), dim3(p.planes * (p.C / G2)), dim3((unsigned)t2), lds2, st, p);
+      return check_launch("cols_filter");
+    }
+  }
   const size_t lds = lds_request(((size_t)G * (L + 1) + (p.tw_in_lds ? L : 0)) * sizeof(float2));
   auto launch = [&](auto kernel) {
     int rc = set_dyn_lds(reinterpret_cast<const void*>(kernel), lds);
@@ -943,7 +963,7 @@ static int run_cols(ColsParams& p, hipStream_t st) {
     hipLaunchKernelGGL(kernel, dim3(p.planes * (p.C / G)), dim3(threads), lds, st, p);
     return (int)LHG_OK;
   };
-  int rc = has_prime_radix(L) ? launch(cols_filter_kernel<true>) : launch(cols_filter_kernel<false>);
+  int rc = has_prime_radix(L) ? launch(cols_filter_kernel<true, 512>) : launch(cols_filter_kernel<false, 1024>);
   if (rc) return rc;
   return check_launch("cols_filter");
 }
