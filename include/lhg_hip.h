@@ -38,7 +38,7 @@
 extern "C" {
 #endif
 
-#define LHG_ABI_VERSION 9
+#define LHG_ABI_VERSION 10
 
 enum {
   LHG_OK = 0,
@@ -177,6 +177,20 @@ int lhg_conv2d_forward(const float* x, int N, int H, int W, int Ci, int ldx,
                        const float* res, int ldres, int act, float slope, int planar_out,
                        const float* x_absmax, float* y_absmax, lhg_stream_t s);
 
+/* ABI 10: lhg_conv2d_forward (bias only: no affine, residual, activation; NHWC) for a convolution whose output goes straight into a
+ * train-mode BatchNorm (ref: neural_network_components.py:27-30 conv -> bn, discriminator.py:34-39): the GEMM's epilogue leaves the
+ * FIRST STAGE of the batch statistics behind — `stat_partial[row][0][c]` = sum of (y - bias[c]), `[row][1][c]` = sum of (y - bias[c])^2
+ * over the output pixels of one consumer-wave row of the chosen tiling (fixed order: bit-repeatable for a given tiling choice; which
+ * tiling the autotuner picks decides how the pixels are grouped) — and lhg_bn_stats_finish folds the rows in double: no statistics
+ * pass over y.  `stat_partial`: >= lhg_conv2d_stats_rows_bound(N, Ho, Wo) * 2 * Co floats; `*stat_rows` (host) receives the rows
+ * written, 0 when the launch ran a kernel without this epilogue (then call lhg_bn_stats).  Every arithmetic mode. */
+long long lhg_conv2d_stats_rows_bound(int N, int Ho, int Wo);
+int lhg_conv2d_forward_stats(const float* x, int N, int H, int W, int Ci, int ldx,
+                             const float* wp, int rows_pad, int KH, int KW, int stride,
+                             float* y, int Co, int ldy, const float* bias,
+                             const float* x_absmax, float* y_absmax,
+                             float* stat_partial, int* stat_rows, lhg_stream_t s);
+
 /* gx = conv2d_backward_input(gy, W).  (H, W) are the INPUT extents of the forward conv.
  * `wp` packed with rows_from_d0 = 0.  Replaces the autograd node of the call sites above;
  * also the "double backward w.r.t. gy" of lhg_conv2d_forward.  ref: watermelon.py:466-473. */
@@ -295,6 +309,10 @@ int lhg_channel_sum(const float* x, long long pixels, int C, int ld, float* out,
 int lhg_bn_stats(const float* x, long long pixels, int C, int ld, float* stats,
                  float* running_mean, float* running_var, float momentum, float eps,
                  float* ws, lhg_stream_t s);
+/* ABI 10: lhg_bn_stats from the partial rows of lhg_conv2d_forward_stats (`rows` x 2 x C floats, sums shifted by `shift[c]` — the
+ * conv's bias, NULL: zero) instead of a pass over the tensor: stats / running_* exactly as lhg_bn_stats defines them. */
+int lhg_bn_stats_finish(const float* partial, int rows, const float* shift, long long pixels, int C, float* stats,
+                        float* running_mean, float* running_var, float momentum, float eps, lhg_stream_t s);
 /* y = act((x - mean)*invstd*gamma + beta + res).  y_absmax (may be NULL, else LHG_ABSMAX_WORDS zero-filled floats): max-accumulates max|y| on the way out — the
  * lhg_absmax of the output for free, for a following GEMM in the LHG_PRECISION_F32_SPLIT_F16 mode (zero-filled slot, fp32 storage). */
 int lhg_bn_apply(const float* x, int ldx, long long pixels, int C, const float* stats,

@@ -62,6 +62,7 @@ struct GGParams {
   const float* a_amax;  // fp16-split mode: max|in| over the gathered tensor (device, lhg_absmax) and max|w| (behind the weight panels)
   const float* w_amax;
   float* out_amax;      // fp16-split mode, optional: max-accumulates max|out| (NHWC outputs)
+  float* stat_part;     // optional: BatchNorm statistics' partial rows [consumer-wave row of the tiling][2][Co] (gg_epilogue.inc, STATS)
   int tap_of[9];        // gg4s_kernel: tap index of the 3x3 offset (dy + 1) * 3 + (dx + 1)
   int strip_rev;        // gg4s_kernel: tap_of is the reversed map (input gradient): walk the offsets downwards = taps upwards
   int prio; // gg3s_kernel: 0 no s_setprio, 1 consumers (MFMA waves) raised, 2 producers (load / split waves) raised
@@ -536,6 +537,29 @@ __global__ __launch_bounds__(256) void pack_batch_kernel(const PackBatch b) {  /
   }
 }
 
+// bf16 operand mode: pack_weight_bf16_kernel per weight of the batch (dst[t][row][k] bf16, round to nearest even), one launch for up to
+// PACK_BATCH weights — the bf16 configurations re-packed every conv weight with a launch of its own after each optimiser step (91 per
+// train step, 0.7 ms of kernel time and as many host dispatches in a host-bound step).
+__global__ __launch_bounds__(256) void pack_batch_bf16_kernel(const PackBatch b) {
+  const int i = pack_batch_find(b, blockIdx.x, false);
+  const PackItem& it = b.it[i];
+  const unsigned nblk = (i + 1 < b.n ? b.it[i + 1].blk0 : b.blocks) - it.blk0;
+  const size_t total = (size_t)it.T * it.rows_pad * it.k_pad;
+  const int rows = it.rows_from_d0 ? it.D0 : it.D1, K = it.rows_from_d0 ? it.D1 : it.D0;
+  __bf16* dst = reinterpret_cast<__bf16*>(it.dst);
+  for (size_t e = (size_t)(blockIdx.x - it.blk0) * 256 + threadIdx.x; e < total; e += (size_t)nblk * 256) {
+    const int k = (int)(e % it.k_pad);
+    const int row = (int)((e / it.k_pad) % it.rows_pad);
+    const int t = (int)(e / ((size_t)it.k_pad * it.rows_pad));
+    float v = 0.f;
+    if (row < rows && k < K) {
+      const int d0 = it.rows_from_d0 ? row : k, d1 = it.rows_from_d0 ? k : row;
+      v = it.w[((size_t)d0 * it.D1 + d1) * it.T + t];
+    }
+    dst[e] = (__bf16)v;
+  }
+}
+
 // The same panels from 32 x 32 (row, k) tiles staged through LDS: the source w[d0][d1][t] is contiguous over (d1, t), so a tile is 32
 // runs of 32 * T floats — every byte of every line used once — where pack_batch_kernel above reads with a stride of T floats (row-major
 // panels) or D1 * T floats (input-gradient panels), once per tap: 9 passes over a weight that does not fit an XCD's L2.  The stores are
@@ -661,7 +685,10 @@ struct KernelTimer {
   }
 };
 static KernelTimer g_timer[2];  // 0: gg_kernel, 1: wg_kernel
-static bool g_autotune_enabled = true;
+// LHG_AUTOTUNE=0: every launcher falls back to its fixed heuristic (until round 5 the split-mode and bf16 launchers ignored the variable).
+// With the BatchNorm statistics folded from the epilogues' partial rows the tiling choice shows in the statistics' last bits: a fixed
+// choice (this switch, or one LHG_TUNE_CACHE file shared by the processes) is what makes two PROCESSES agree bit for bit.
+static bool g_autotune_enabled = [] { const char* e = getenv("LHG_AUTOTUNE"); return e ? atoi(e) != 0 : true; }();
 static std::map<std::array<int, 12>, int> g_gg_choice, g_wg_choice;
 
 // One-time timing of the valid kernel variants for a geometry not seen before: the device is drained first (the weight-gradient
@@ -805,6 +832,12 @@ static inline bool split_f16() { return g_precision == LHG_PRECISION_F32_SPLIT_F
 static inline bool split_mode() { return g_precision == LHG_PRECISION_F32_SPLIT || g_precision == LHG_PRECISION_F32_SPLIT2 || split_f16(); }
 static inline int split_planes() { return g_precision == LHG_PRECISION_F32_SPLIT ? 3 : 2; }
 static int launch_gg(GGParams& p, hipStream_t st);
+// BatchNorm statistics from the epilogue (GGParams::stat_part): the rows the chosen tiling writes — one per consumer-wave row of every
+// M tile — handed back to lhg_conv2d_forward_stats (the finish kernel needs the count; the buffer is sized by lhg_conv2d_stats_rows_bound)
+static int g_stat_rows = 0;
+static void note_stat_rows(const GGParams& p, long long m_total, int bm, int wgm) {
+  if (p.stat_part) g_stat_rows = (int)((m_total + bm - 1) / bm) * wgm;
+}
 static bool merge_classes() {
   static const bool on = [] { const char* e = getenv("LHG_MERGE_CLASSES"); return !e || atoi(e) != 0; }();
   return on;
@@ -866,7 +899,8 @@ static int launch_gg(GGParams& p, hipStream_t st) {
 
   // tiling variants; every variant produces the same values (the K order is identical)
   constexpr int NV = 6;
-  auto valid = [&](int v) { return (v < 3 ? small : true) && ((v == 0 || v == 3) ? n128 : true); };
+  if (!small) p.stat_part = nullptr;  // gg_kernel has its own epilogue: no statistics rows (g_stat_rows stays 0, the caller runs the pass)
+  auto valid = [&](int v) { return (v < 3 ? small : p.stat_part == nullptr) && ((v == 0 || v == 3) ? n128 : true); };
   auto run = [&](int v) {
     switch (v) {
       case 0: hipLaunchKernelGGL((gg2_kernel<128, 128, 2, 2>), dim3(blocks(128, 128)), dim3(256), 0, st, p, ib, wb); break;
@@ -891,6 +925,7 @@ static int launch_gg(GGParams& p, hipStream_t st) {
     choice = autotuned_variant(g_gg_choice, key, NV, valid, run, st);
   }
   if (choice < 0) choice = heuristic();
+  if (choice < 3) note_stat_rows(p, g.M, choice == 2 ? 64 : 128, 2);
   ScopedKernelTime timed(0, st, 2.0 * g.M * (double)p.rows_pad * g.Ci * g.T);
   timed.tag(g, p.rows_pad, g.Ci, choice, 2.0 * g.M * (double)p.rows_pad * g.Ci * g.T);
   run(choice);
@@ -947,6 +982,7 @@ static int launch_gg_bf16_t(GGParams& p, hipStream_t st) {
     choice = autotuned_variant(g_gg_choice, key, NV, valid, run, st);
   }
   if (choice < 0) choice = n128 && blocks(128, 128) >= 256 ? 0 : (blocks(128, 64) >= 256 ? 1 : 2);
+  note_stat_rows(p, g.M, (choice == 2 || choice == 5 || choice == 8) ? 64 : 128, 2);  // every variant: 2 x 2 consumer waves
   ScopedKernelTime timed(0, st, 2.0 * g.M * (double)p.rows_pad * g.Ci * g.T);
   timed.tag(g, p.rows_pad, g.Ci, choice, 2.0 * g.M * (double)p.rows_pad * g.Ci * g.T);
   run(choice);
@@ -1090,6 +1126,23 @@ static int launch_gg_split(GGParams& p, hipStream_t st) {
     choice = autotuned_variant(g_gg_choice, key, NV, valid, run, st);
   }
   if (choice < 0) choice = n128 && blocks(128, 128) >= 200 ? 0 : (blocks(128, 64) >= 256 ? 1 : 2);
+  if (p.stat_part) {  // rows of the chosen tiling: (pixels per M tile, consumer-wave rows per tile, padded strip coordinates or not)
+    LHG_REQUIRE(ncls == 1, "gather-GEMM: BatchNorm statistics rows are not available for merged parity classes");
+    int bm = 128, wgm = 2;
+    bool strip = false;
+    if (NP == 3) { bm = choice == 2 ? 64 : 128; wgm = choice == 4 ? 4 : 2; }
+    else if (f16) {
+      switch (choice) {
+        case 2: case 9: bm = 64; break;
+        case 4: wgm = 4; break;
+        case 5: case 6: case 13: case 15: bm = 64; strip = true; break;
+        case 7: case 8: case 12: case 14: strip = true; break;
+        case 10: case 11: bm = 256; wgm = 4; strip = true; break;
+        default: break;  // 0, 1, 3: 128 pixels, two wave rows
+      }
+    } else bm = choice <= 1 ? 128 : 64;
+    note_stat_rows(p, strip ? (long long)g.N * g.Hi * (g.Wi + 2) : (long long)g.M, bm, wgm);
+  }
   double mt_sum = 0;  // sum over the classes of pixels x taps
   for (int c = 0; c < ncls; ++c) mt_sum += (double)cls_geom(c).M * cls_geom(c).T;
   ScopedKernelTime timed(0, st, 2.0 * mt_sum * (double)p.rows_pad * g.Ci);
@@ -1360,6 +1413,34 @@ int lhg_pack_weight(const float* w, int D0, int D1, int KH, int KW, int rows_fro
 
 int lhg_pack_weights(const lhg_pack_item* items, int n, lhg_stream_t s) {
   LHG_REQUIRE(n >= 0 && (n == 0 || items != nullptr), "pack_weights: bad item list");
+  if (g_precision == LHG_PRECISION_BF16) {  // bf16 panels: one launch per PACK_BATCH weights (no max|w|)
+    for (int first = 0; first < n; first += PACK_BATCH) {
+      PackBatch b;
+      b.n = std::min(PACK_BATCH, n - first);
+      unsigned blk = 0;
+      for (int i = 0; i < b.n; ++i) {
+        const lhg_pack_item& q = items[first + i];
+        const int rows = q.rows_from_d0 ? q.D0 : q.D1, K = q.rows_from_d0 ? q.D1 : q.D0;
+        LHG_REQUIRE(q.w && q.dst && q.D0 > 0 && q.D1 > 0 && q.KH > 0 && q.KW > 0, "pack_weights: item %d is empty", first + i);
+        LHG_REQUIRE(q.rows_pad >= rows && q.k_pad >= K && q.rows_pad % 64 == 0 && q.k_pad % 32 == 0, "pack_weights: bad padding of item %d (%d>=%d, %d>=%d)",
+                    first + i, q.rows_pad, rows, q.k_pad, K);
+        const size_t total = (size_t)q.KH * q.KW * q.rows_pad * q.k_pad;
+        PackItem& it = b.it[i];
+        it.w = q.w;
+        it.dst = reinterpret_cast<_Float16*>(q.dst);
+        it.amax = nullptr;
+        it.amax_src = nullptr;
+        it.D0 = q.D0; it.D1 = q.D1; it.T = q.KH * q.KW; it.rows_from_d0 = q.rows_from_d0; it.rows_pad = q.rows_pad; it.k_pad = q.k_pad;
+        it.blk0 = blk;
+        it.ablk0 = 0;
+        blk += (unsigned)std::min<size_t>((total + 1023) / 1024, 16384);  // 4 elements per thread
+      }
+      b.blocks = blk;
+      b.ablocks = 0;
+      hipLaunchKernelGGL(pack_batch_bf16_kernel, dim3(blk), dim3(256), 0, as_stream(s), b);
+    }
+    return check_launch("pack_weights");
+  }
   if (g_precision != LHG_PRECISION_F32_SPLIT_F16) {  // the other modes have no max|w| pass to share: one pack launch per weight
     for (int i = 0; i < n; ++i) {
       const lhg_pack_item& q = items[i];
@@ -1435,6 +1516,29 @@ int lhg_conv2d_forward(const float* x, int N, int H, int W, int Ci, int ldx, con
   p.in = x; p.wp = wp; p.out = y; p.bias = bias; p.scale = scale; p.shift = shift; p.res = res; p.ldres = ldres;
   p.rows_pad = rows_pad; p.act = act; p.slope = slope; p.planar_out = planar_out;
   return launch_gg(p, as_stream(s));
+}
+
+long long lhg_conv2d_stats_rows_bound(int N, int Ho, int Wo) {
+  // the finest tiling writes one row per 32 pixels of the PADDED pixel axis of the strip kernels (every image row two pixels longer)
+  return ((long long)N * Ho * (Wo + 2) + 31) / 32 + 8;
+}
+
+int lhg_conv2d_forward_stats(const float* x, int N, int H, int W, int Ci, int ldx, const float* wp, int rows_pad, int KH, int KW, int stride,
+                             float* y, int Co, int ldy, const float* bias, const float* x_absmax, float* y_absmax, float* stat_partial,
+                             int* stat_rows, lhg_stream_t s) {
+  LHG_REQUIRE(conv_args_ok(KH, KW, stride), "conv2d_forward_stats: unsupported kernel %dx%d stride %d", KH, KW, stride);
+  LHG_REQUIRE(stat_partial != nullptr && stat_rows != nullptr, "conv2d_forward_stats: the partial-row buffer and the row count are required");
+  GGParams p{};
+  conv_fwd_geom(p.g, N, H, W, Ci, ldx, Co, ldy, KH, KW, stride);
+  p.a_amax = x_absmax; p.w_amax = weight_amax(wp, KH * KW, rows_pad, Ci); p.out_amax = y_absmax;
+  p.in = x; p.wp = wp; p.out = y; p.bias = bias;
+  p.rows_pad = rows_pad; p.act = LHG_ACT_NONE; p.slope = 0.f; p.planar_out = 0;
+  p.stat_part = stat_partial;
+  g_stat_rows = 0;
+  const int rc = launch_gg(p, as_stream(s));
+  *stat_rows = rc == LHG_OK ? g_stat_rows : 0;  // 0: this launch left no rows (a kernel without the shared epilogue): run lhg_bn_stats
+  LHG_REQUIRE(rc != LHG_OK || (long long)*stat_rows <= lhg_conv2d_stats_rows_bound(N, p.g.Ho, p.g.Wo), "conv2d_forward_stats: %d rows exceed the bound", *stat_rows);
+  return rc;
 }
 
 int lhg_conv2d_backward_input(const float* gy, int N, int H, int W, int Co, int ldgy, const float* wp, int rows_pad, int KH, int KW, int stride,

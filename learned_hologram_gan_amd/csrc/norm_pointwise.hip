@@ -284,12 +284,18 @@ __device__ __forceinline__ void amax_commit(unsigned m, float* out, unsigned see
 
 // ------------------------------------------------------------------ BN statistics
 // mean / invstd / running statistics of one channel from its two shifted sums (the arithmetic of bn_stats_reduce_final)
+__device__ __forceinline__ void bn_stats_final_shifted(int c, double s0, double s1, double shift, long long pixels, int C, float* __restrict__ stats,
+                                                       float* running_mean, float* running_var, float momentum, float eps);
 template <class T>
 __device__ __forceinline__ void bn_stats_final(int c, double s0, double s1, const T* __restrict__ x, long long pixels, int C, float* __restrict__ stats,
                                                float* running_mean, float* running_var, float momentum, float eps) {
+  bn_stats_final_shifted(c, s0, s1, (double)ld1(x + c), pixels, C, stats, running_mean, running_var, momentum, eps);
+}
+__device__ __forceinline__ void bn_stats_final_shifted(int c, double s0, double s1, double shift, long long pixels, int C, float* __restrict__ stats,
+                                                       float* running_mean, float* running_var, float momentum, float eps) {
   const double n = (double)pixels;
   const double dm = s0 / n;
-  const double mean = (double)ld1(x + c) + dm;
+  const double mean = shift + dm;
   double var = s1 / n - dm * dm;
   if (var < 0) var = 0;
   stats[c] = (float)mean;
@@ -449,6 +455,37 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const T* __restrict__ gy, 
 // (one per BatchNorm call: ~100 per train step).  Round 5: 16 channels x 64 slices with SIXTEEN rows in flight per thread (32 x 32 with four
 // in flight before: sixteen dependent round trips for 2048 rows, now two) — 10.4 -> ~6 us per call.
 constexpr int RP_SLICES = 64, RP_CH = 16, RP_UNROLL = 16;
+// NS columns (k_stride apart) of the rows slice, slice + SL, ... summed in double.  Every batch of RP_UNROLL rows is requested before any
+// of it is used, rows past the end clamped and zeroed: ONE memory round trip per RP_UNROLL * SL rows for all NS columns.
+template <int NS, int SL>
+__device__ __forceinline__ void reduce_rows_n(const float* __restrict__ src, size_t k_stride, size_t stride, int nblk, int slice, double (&out)[NS]) {
+  double acc[NS][4];
+#pragma unroll
+  for (int k = 0; k < NS; ++k) acc[k][0] = acc[k][1] = acc[k][2] = acc[k][3] = 0.0;
+  for (int b = slice; b < nblk; b += RP_UNROLL * SL) {
+    float v[NS][RP_UNROLL];
+    // rows past the end: the load is CLAMPED to the last row and its value replaced by zero afterwards — a conditional load is a branch,
+    // and the requests would wait for each other (the empty asm keeps the compiler from sinking the load under the select again)
+#pragma unroll
+    for (int u = 0; u < RP_UNROLL; ++u) {
+      const size_t r = (size_t)min(b + u * SL, nblk - 1) * stride;
+#pragma unroll
+      for (int k = 0; k < NS; ++k) v[k][u] = src[r + k * k_stride];
+    }
+#pragma unroll
+    for (int u = 0; u < RP_UNROLL; ++u)
+#pragma unroll
+      for (int k = 0; k < NS; ++k) {
+        asm volatile("" : "+v"(v[k][u]));
+        acc[k][u & 3] += (double)(b + u * SL < nblk ? v[k][u] : 0.f);
+      }
+  }
+#pragma unroll
+  for (int k = 0; k < NS; ++k) out[k] = (acc[k][0] + acc[k][1]) + (acc[k][2] + acc[k][3]);
+}
+// One column: the round-4 loop (whole batches unpredicated, the rest one row per iteration).  The predicated one-trip form above was
+// measured against it for this kernel family (round 5, interleaved A/B of the train step on one box): 30.90 against 30.86 ms, the
+// launches 13.9 against 12.9 us under the profiler — no gain, so the single-column reductions keep the loop they had.
 __device__ __forceinline__ double reduce_rows(const float* __restrict__ src, size_t stride, int nblk, int slice) {
   double acc[4] = {0, 0, 0, 0};
   int b = slice;
@@ -489,8 +526,12 @@ __global__ __launch_bounds__(1024) void bn_stats_reduce_final(const float* __res
   __shared__ double red[2][RP_SLICES][RP_CH];
   const int lane_c = threadIdx.x % RP_CH, slice = threadIdx.x / RP_CH;
   const int c = blockIdx.x * RP_CH + lane_c;
-#pragma unroll
-  for (int k = 0; k < 2; ++k) red[k][slice][lane_c] = c < C ? reduce_rows(partial + (size_t)k * C + c, (size_t)2 * C, nblk, slice) : 0.0;
+  {
+    double two[2] = {0.0, 0.0};
+    if (c < C) reduce_rows_n<2, RP_SLICES>(partial + c, (size_t)C, (size_t)2 * C, nblk, slice, two);  // both columns' rows in one round trip
+    red[0][slice][lane_c] = two[0];
+    red[1][slice][lane_c] = two[1];
+  }
   __syncthreads();
   if (slice != 0 || c >= C) return;
   double sum[2];
@@ -502,6 +543,37 @@ __global__ __launch_bounds__(1024) void bn_stats_reduce_final(const float* __res
     sum[k] = (double)(float)s;
   }
   bn_stats_final(c, sum[0], sum[1], x, pixels, C, stats, running_mean, running_var, momentum, eps);
+}
+
+// The statistics of a tensor whose producer — a conv GEMM's epilogue (gg_epilogue.inc, STATS; lhg_conv2d_forward_stats) — left the first
+// stage behind: partial[row][2][C] floats, sums of (x - shift[c]) and their squares over the row's pixels (shift = the conv's bias, null:
+// zero).  CH channels x SL row slices per workgroup, SL chosen so that the rows are ONE round trip where possible (16 SL rows in flight
+// per channel: the kernel is pure latency, on the chain the step waits for): a 384^2 layer leaves ~9000 rows.
+template <int CH, int SL>
+__global__ __launch_bounds__(CH * SL) void bn_stats_finish_kernel(const float* __restrict__ partial, int nblk, const float* __restrict__ shift,
+                                                                  long long pixels, int C, float* __restrict__ stats, float* running_mean,
+                                                                  float* running_var, float momentum, float eps) {
+  __shared__ double red[2][SL][CH];
+  const int lane_c = threadIdx.x % CH, slice = threadIdx.x / CH;
+  const int c = blockIdx.x * CH + lane_c;
+  {
+    double two[2] = {0.0, 0.0};
+    if (c < C) reduce_rows_n<2, SL>(partial + c, (size_t)C, (size_t)2 * C, nblk, slice, two);
+    red[0][slice][lane_c] = two[0];
+    red[1][slice][lane_c] = two[1];
+  }
+  __syncthreads();
+  // the slices folded pairwise (fixed tree: the same bits whatever the timing), log2(SL) steps instead of one thread walking SL values
+#pragma unroll
+  for (int h = SL / 2; h > 0; h >>= 1) {
+    if (slice < h) {
+      red[0][slice][lane_c] += red[0][slice + h][lane_c];
+      red[1][slice][lane_c] += red[1][slice + h][lane_c];
+    }
+    __syncthreads();
+  }
+  if (slice != 0 || c >= C) return;
+  bn_stats_final_shifted(c, red[0][0][lane_c], red[1][0][lane_c], shift ? (double)shift[c] : 0.0, pixels, C, stats, running_mean, running_var, momentum, eps);
 }
 
 template <class T>
@@ -1251,6 +1323,20 @@ int lhg_bn_backward_chanmax(const float* gy, int ldgy, const float* x, int ldx, 
 int lhg_bn_stats(const float* x, long long pixels, int C, int ld, float* stats, float* running_mean, float* running_var,
                  float momentum, float eps, float* ws, lhg_stream_t s) {
   return LHG_ACT_CALL(bn_stats_impl, x, pixels, C, ld, stats, running_mean, running_var, momentum, eps, ws, s);
+}
+int lhg_bn_stats_finish(const float* partial, int rows, const float* shift, long long pixels, int C, float* stats, float* running_mean,
+                        float* running_var, float momentum, float eps, lhg_stream_t s) {
+  LHG_REQUIRE(partial != nullptr && rows > 0 && pixels > 0 && C > 0, "bn_stats_finish: empty input (rows %d, pixels %lld, C %d)", rows, pixels, C);
+  if (rows > 4096)
+    hipLaunchKernelGGL((bn_stats_finish_kernel<1, 1024>), dim3(C), dim3(1024), 0, as_stream(s), partial, rows, shift, pixels, C, stats,
+                       running_mean, running_var, momentum, eps);
+  else if (rows > 1024)
+    hipLaunchKernelGGL((bn_stats_finish_kernel<4, 256>), dim3((C + 3) / 4), dim3(1024), 0, as_stream(s), partial, rows, shift, pixels, C, stats,
+                       running_mean, running_var, momentum, eps);
+  else
+    hipLaunchKernelGGL((bn_stats_finish_kernel<16, 64>), dim3((C + 15) / 16), dim3(1024), 0, as_stream(s), partial, rows, shift, pixels, C, stats,
+                       running_mean, running_var, momentum, eps);
+  return check_launch("bn_stats_finish");
 }
 int lhg_bn_apply(const float* x, int ldx, long long pixels, int C, const float* stats, const float* gamma, const float* beta,
                  const float* res, int ldres, int act, float slope, float* y, int ldy, float* y_absmax, lhg_stream_t s) {

@@ -894,9 +894,16 @@ def _raw_weight(w):
     return wd if wd.is_contiguous() else wd.contiguous()
 
 
+# LHG_EPILOGUE_BN_STATS=0: a conv that feeds a train-mode BatchNorm does not leave the statistics' partial rows behind (lhg_bn_stats runs its
+# pass over the tensor, as before ABI 10) — for A/B measurements.
+_EPILOGUE_BN_STATS = os.environ.get("LHG_EPILOGUE_BN_STATS", "1") != "0"
+
+
 def conv2d_forward_raw(x, w, bias, stride, act=ACT_NONE, slope=0.0, scale=None, shift=None, res=None, out=None, planar=False, x_amax=None,
-                       measure_out=False):
-    """y = act((conv(x, w) + bias) * scale + shift + res); no autograd."""
+                       measure_out=False, bn_stats=False):
+    """y = act((conv(x, w) + bias) * scale + shift + res); no autograd.  ``bn_stats`` (bias-only NHWC calls): the output goes straight into a
+    train-mode BatchNorm — the GEMM's epilogue leaves the first stage of the batch statistics behind (lhg_conv2d_forward_stats) and the
+    tensor is tagged with the rows for BatchNormTrainFn (lhg_bn_stats_finish instead of a statistics pass over y)."""
     px, N, H, W, Ci, ldx = nhwc(x)
     Co, Ciw, KH, KW = w.shape
     if pad_to(Ciw, 32) != Ci and not (Ciw <= Ci and thin_mode(Ciw, Co, KH, stride)):
@@ -932,8 +939,18 @@ def conv2d_forward_raw(x, w, bias, stride, act=ACT_NONE, slope=0.0, scale=None, 
         x_amax = operand_absmax(x)
     # measure_out: the output feeds another GEMM directly (eval-mode chains, conv + activation blocks): the epilogue measures max|y|
     y_amax = _out_amax(out, x.device) if measure_out and not planar else None
-    call("lhg_conv2d_forward", px, N, H, W, Ci, ldx, ptr(wp), wp.shape[1], KH, KW, stride, py, Co, ldy,
-         ptr(bias), ptr(scale), ptr(shift), pres, ldres, act, float(slope), int(planar), ptr(x_amax), ptr(y_amax), stream_ptr())
+    if (bn_stats and _EPILOGUE_BN_STATS and not planar and act == ACT_NONE and scale is None and shift is None and res is None
+            and ldy == Co and sync_world() == 1):
+        bound = int(native.load().lhg_conv2d_stats_rows_bound(N, Ho, Wo))
+        partial = torch.empty((bound * 2 * Co,), dtype=torch.float32, device=x.device)
+        rows = ctypes.c_int(0)
+        call("lhg_conv2d_forward_stats", px, N, H, W, Ci, ldx, ptr(wp), wp.shape[1], KH, KW, stride, py, Co, ldy, ptr(bias), ptr(x_amax), ptr(y_amax),
+             ptr(partial), ctypes.byref(rows), stream_ptr())
+        if rows.value > 0:
+            y.__dict__["_lhg_bn_partial"] = (y._version, partial, rows.value, bias.detach() if bias is not None else None)
+    else:
+        call("lhg_conv2d_forward", px, N, H, W, Ci, ldx, ptr(wp), wp.shape[1], KH, KW, stride, py, Co, ldy,
+             ptr(bias), ptr(scale), ptr(shift), pres, ldres, act, float(slope), int(planar), ptr(x_amax), ptr(y_amax), stream_ptr())
     if y_amax is not None:
         tag_absmax(y, y_amax)  # (a view into a shared buffer: the slot bounds the whole buffer, hence the view)
     return y
@@ -959,7 +976,8 @@ class Conv2dFn(TrackedFunction):
 
     @staticmethod
     def forward(ctx, x, w, bias, stride, out):
-        ctx.bias_grad_is_zero = isinstance(out, str) and out == "feeds_bn"
+        ctx.bias_grad_is_zero = isinstance(out, str) and out in ("feeds_bn", "feeds_bn_pair")
+        bn_stats = ctx.bias_grad_is_zero and out == "feeds_bn"  # ("feeds_bn_pair": two stacked batches with separate statistics, BatchNormPairTrainFn)
         if ctx.bias_grad_is_zero:
             out = None
         ctx.save_for_backward(x, w)
@@ -968,7 +986,7 @@ class Conv2dFn(TrackedFunction):
         ctx.bias = bias if (bias is not None and ctx.needs_input_grad[2]) else None  # its gradient never passes through autograd
         note_use(ctx.bias)
         gemm = not (w.shape[2] == w.shape[3] and thin_mode(w.shape[1], w.shape[0], w.shape[2], stride))
-        return conv2d_forward_raw(x, w, bias, stride, out=out, x_amax=operand_absmax(x) if gemm else None)
+        return conv2d_forward_raw(x, w, bias, stride, out=out, x_amax=operand_absmax(x) if gemm else None, bn_stats=bn_stats)
 
     @staticmethod
     def backward(ctx, gy):
@@ -1462,8 +1480,13 @@ class BatchNormTrainFn(TrackedFunction):
                      pres, ldres, act, float(slope), py, ldy, ptr(stats), ptr(y_amax), cm.ptr if cm else None, cm.finish if cm else 0, ws, tickets,
                      stream_ptr())
             else:
-                call("lhg_bn_stats", px, pixels, Cc, ldx, ptr(stats), ptr(running_mean), ptr(running_var), BN_MOMENTUM, BN_EPS,
-                     ptr(_bn_ws(Cc, x.device, 4104)), stream_ptr())
+                rows = x.__dict__.get("_lhg_bn_partial")  # left by the conv GEMM that wrote x (conv2d_forward_raw, bn_stats)
+                if rows is not None and rows[0] == x._version and ldx == Cc:
+                    call("lhg_bn_stats_finish", ptr(rows[1]), rows[2], ptr(rows[3]), pixels, Cc, ptr(stats), ptr(running_mean), ptr(running_var),
+                         BN_MOMENTUM, BN_EPS, stream_ptr())
+                else:
+                    call("lhg_bn_stats", px, pixels, Cc, ldx, ptr(stats), ptr(running_mean), ptr(running_var), BN_MOMENTUM, BN_EPS,
+                         ptr(_bn_ws(Cc, x.device, 4104)), stream_ptr())
                 if cm is not None:
                     call("lhg_bn_apply_chanmax", px, ldx, pixels, Cc, ptr(stats), ptr(gamma), ptr(beta), pres, ldres, act, float(slope), py, ldy,
                          ptr(y_amax), cm.ptr, stream_ptr())

@@ -73,7 +73,7 @@ class WGANGPDiscriminator192(nn.Module):
         h = ops.ConvBiasActFn.apply(h, c1.weight, c1.bias, 1, ACT_LEAKY, 0.2)
         for blk in (self.block2, self.block3, self.block4, self.block5, self.block6):
             conv, bn = blk[0], blk[1]
-            y = ops.Conv2dFn.apply(h, conv.weight, conv.bias, conv.stride[0], "feeds_bn")
+            y = ops.Conv2dFn.apply(h, conv.weight, conv.bias, conv.stride[0], "feeds_bn_pair")
             h = ops.BatchNormPairTrainFn.apply(y, bn.weight, bn.bias, bn.running_mean, bn.running_var, ACT_LEAKY, 0.2)
             _count_batch(bn, bn)
         flush_batch_counters()

@@ -115,15 +115,19 @@ def test_critic_forward_pair_equals_two_passes():
     two calls (ref: watermelon.py:243-244): scores, BatchNorm running statistics and batch counters bit-identical (a convolution's
     output does not depend on the batch it sits in, every BatchNorm normalises the halves separately and in order); parameter
     gradients equal up to the summation order of the weight-gradient GEMM (one over 2B samples instead of two accumulated), through
-    autograd's accumulation and through the flat-buffer slots."""
+    autograd's accumulation and through the flat-buffer slots.  Bit-identity holds with the statistics PASS on both sides; since ABI 10 a
+    single pass takes its batch statistics from the conv GEMM's epilogue (sums grouped by the GEMM's tiling) while the stacked pass keeps
+    the per-half statistics pass: the two then agree to the rounding of the statistics (checked at 1e-5)."""
+    from learned_hologram_gan_amd import hip_ops
     from learned_hologram_gan_amd.optim import FlatParams
     from learned_hologram_gan_amd.watermelon_hologram.discriminator import WGANGPDiscriminator192
 
     g = torch.Generator().manual_seed(3)
     a, b = torch.rand((2, 3, 64, 64), generator=g).to(DEV), torch.rand((2, 3, 64, 64), generator=g).to(DEV)
-    for slots in (False, True):
+    for slots, epilogue_stats in ((False, False), (True, False), (True, True)):
         out = {}
         for pair in (False, True):
+            hip_ops._EPILOGUE_BN_STATS = epilogue_stats
             D = WGANGPDiscriminator192(cuda=True)
             D.load_state_dict(seeded.critic_state_dict())
             D.to(DEV).train()
@@ -137,8 +141,13 @@ def test_critic_forward_pair_equals_two_passes():
             grads = flat.grad.clone() if slots else torch.cat([(p.grad if p.grad is not None else torch.zeros_like(p)).flatten() for p in D.parameters()])
             bufs = torch.cat([t.detach().flatten().double() for t in D.buffers()])
             out[pair] = (sa.detach().clone(), sb.detach().clone(), bufs, grads)
+        hip_ops._EPILOGUE_BN_STATS = True
         (sa0, sb0, bu0, g0), (sa1, sb1, bu1, g1) = out[False], out[True]
-        assert torch.equal(sa0, sa1) and torch.equal(sb0, sb1), slots
-        assert torch.equal(bu0, bu1), slots
+        if not epilogue_stats:
+            assert torch.equal(sa0, sa1) and torch.equal(sb0, sb1), slots
+            assert torch.equal(bu0, bu1), slots
+        else:
+            close = lambda u, v: ((u.double() - v.double()).abs().max() / v.double().abs().max()).item()  # noqa: E731
+            assert max(close(sa0, sa1), close(sb0, sb1)) < 1e-5 and close(bu0, bu1) < 1e-5, (close(sa0, sa1), close(sb0, sb1), close(bu0, bu1))
         err = ((g0.double() - g1.double()).norm() / g0.double().norm()).item()
-        assert err < 2e-5, (slots, err)
+        assert err < (2e-5 if not epilogue_stats else 1e-4), (slots, epilogue_stats, err)

@@ -25,7 +25,7 @@ def test_library_exports_declared_abi():
     raw = ctypes.CDLL(native.LIB_PATH)
     for name in declared:
         assert hasattr(raw, name), name
-    assert lib.lhg_abi_version() == native.ABI_VERSION == 9
+    assert lib.lhg_abi_version() == native.ABI_VERSION == 10
 
 
 def test_host_side_size_functions_and_supported_lengths():
