@@ -191,6 +191,17 @@ int lhg_conv2d_forward_stats(const float* x, int N, int H, int W, int Ci, int ld
                              const float* x_absmax, float* y_absmax,
                              float* stat_partial, int* stat_rows, lhg_stream_t s);
 
+/* ABI 10, split K.  A gather-GEMM launch (lhg_conv2d_forward[_stats], lhg_conv2d_backward_input*) that cannot fill the chip — at most 160
+ * output tiles of 128 x 128 and at least 64 K steps: the UNet's 24^2 x 1024-channel bottleneck (neural_network_components.py:246-250) —
+ * cuts its K axis into 2 - 4 ranges of whole 32-channel chunks, a function of the geometry alone (LHG_PRECISION_F32_SPLIT_F16 mode).
+ * lhg_gather_gemm_splitk_floats: the workspace such a launch needs, 0 when it does not split — M output pixels of the launch
+ * (N*Ho*Wo; input-gradient: N*H*W), M_padded = N*H*(W+2) for a 3x3 stride-1 launch (else 0), rows_pad of its packed weight, K = the
+ * gathered tensor's (padded) channels, taps = KH*KW.  lhg_gather_gemm_workspace hands a buffer to the NEXT gather-GEMM launch of this
+ * thread (consumed by it, used or not).  Without one the library keeps a grow-only buffer per stream, which cannot grow inside a graph
+ * capture: callers that capture pass their own. */
+long long lhg_gather_gemm_splitk_floats(long long M, long long M_padded, int rows_pad, int K, int taps);
+int lhg_gather_gemm_workspace(float* ws, long long floats);
+
 /* gx = conv2d_backward_input(gy, W).  (H, W) are the INPUT extents of the forward conv.
  * `wp` packed with rows_from_d0 = 0.  Replaces the autograd node of the call sites above;
  * also the "double backward w.r.t. gy" of lhg_conv2d_forward.  ref: watermelon.py:466-473. */

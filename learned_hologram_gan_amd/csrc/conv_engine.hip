@@ -63,6 +63,12 @@ struct GGParams {
   const float* w_amax;
   float* out_amax;      // fp16-split mode, optional: max-accumulates max|out| (NHWC outputs)
   float* stat_part;     // optional: BatchNorm statistics' partial rows [consumer-wave row of the tiling][2][Co] (gg_epilogue.inc, STATS)
+  // split K (gg3s_kernel / gg4s_kernel, fp16-split mode): ks > 1 cuts the 32-channel chunks of the K axis into ks ranges of ks_chunks
+  // chunks; the grid holds ks copies of the tile grid (range-major), every workgroup leaves its RAW accumulators in
+  // ks_slab[range][tile row][rows_pad] and gg_splitk_finish_kernel sums the ranges in order and runs the epilogue.
+  int ks, ks_chunks;
+  float* ks_slab;
+  int ks_off;  // set by launch_gg_classes: one launch of several over the same output (parity classes) never splits
   int tap_of[9];        // gg4s_kernel: tap index of the 3x3 offset (dy + 1) * 3 + (dx + 1)
   int strip_rev;        // gg4s_kernel: tap_of is the reversed map (input gradient): walk the offsets downwards = taps upwards
   int prio; // gg3s_kernel: 0 no s_setprio, 1 consumers (MFMA waves) raised, 2 producers (load / split waves) raised
@@ -247,6 +253,93 @@ __global__ __launch_bounds__(256, 2) void gg_kernel(const GGParams p) {
 #include "gg2b_kernel.inc"
 #include "gg3s_kernel.inc"
 #include "gg4s_kernel.inc"
+
+// ------------------------------------------------------------------------------------ split-K finish
+// The layers at the bottom of the UNet (24^2 x 1024 channels at batch 4: 2304 pixels) have 144 output tiles of 128 x 128 for 256 CUs and
+// a K axis of 288 steps: one workgroup per tile leaves almost half of the chip idle for the whole launch.  With GGParams::ks the K axis
+// is cut into ks ranges of whole 32-channel chunks (a FUNCTION OF THE GEOMETRY, never of a timing: every tiling variant of the launch
+// sums the same ranges in the same order, so the tuner's choice still does not show in the bits), each workgroup stores raw
+// accumulators, and this kernel adds the ranges in ascending order and runs gg_epilogue's arithmetic — scales undone, + bias, * scale
+// + shift, + residual, activation, max|.| — plus, when asked (stat), the BatchNorm statistics' partial rows (one per workgroup of
+// SK_ROWS slab rows: sum and sum of squares of the bias-free value over its valid pixels, rows in ascending order).
+constexpr int SK_ROWS = 16;  // slab rows per workgroup (x 64 columns: 256 threads, four columns each)
+struct SplitKFinish {
+  const float* slab;
+  long long slab_stride;   // floats between two ranges: m_rows * rows_pad
+  int ks, m_rows, rows_pad;
+  int strip;               // rows are PADDED pixel coordinates (gg4s_kernel: every image row two pixels longer)
+  int N, H, W;             // strip: image extents (input = output extents)
+  int M, gh, gw, Ho, Wo, oy0, ox0, ostep;  // otherwise: the sub-grid of output pixels
+  float* out; int ldo, Co;
+  const float* bias; const float* scale; const float* shift; const float* res; int ldres; int act; float slope;
+  const float* a_amax; const float* w_amax; float* out_amax;
+  float* stat;             // [gridDim.x][2][Co] or null
+};
+__global__ __launch_bounds__(256) void gg_splitk_finish_kernel(const SplitKFinish q) {
+  __shared__ float red[2][SK_ROWS][64];
+  const int tx = threadIdx.x & 15, ty = threadIdx.x >> 4;
+  const int m = blockIdx.x * SK_ROWS + ty, c0 = blockIdx.y * 64 + tx * 4;
+  long long pix = -1;
+  if (m < q.m_rows) {
+    if (q.strip) {
+      const int Wp = q.W + 2;
+      const long long Mp = (long long)q.N * q.H * Wp;
+      if (m < Mp) {
+        const int n = m / (q.H * Wp), rem = m - n * (q.H * Wp);
+        const int y = rem / Wp, xp = rem - y * Wp;
+        if (xp >= 1 && xp <= q.W) pix = ((long long)n * q.Ho + y) * q.Wo + xp - 1;
+      }
+    } else if (m < q.M) {
+      const int ghw = q.gh * q.gw;
+      const int n = m / ghw, rem = m - n * ghw;
+      const int gi = rem / q.gw, gj = rem - gi * q.gw;
+      pix = ((long long)n * q.Ho + q.oy0 + q.ostep * gi) * q.Wo + q.ox0 + q.ostep * gj;
+    }
+  }
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  if (pix >= 0 && c0 < q.rows_pad) {
+    const float* src = q.slab + (size_t)m * q.rows_pad + c0;
+    for (int z = 0; z < q.ks; ++z) acc += *reinterpret_cast<const f32x4*>(src + (size_t)z * q.slab_stride);
+  }
+  const float un_a = split_unscale(operand_amax(q.a_amax)), un_w = split_unscale(*q.w_amax);
+  float d[4], amax = 0.f;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const int col = c0 + e;
+    const bool ok = pix >= 0 && col < q.Co;
+    d[e] = ok ? (acc[e] * un_a) * un_w : 0.f;
+    if (ok) {
+      float v = __builtin_fmaf(acc[e] * un_a, un_w, q.bias ? q.bias[col] : 0.f);
+      v = __builtin_fmaf(v, q.scale ? q.scale[col] : 1.f, q.shift ? q.shift[col] : 0.f);
+      if (q.res) v += q.res[(size_t)pix * q.ldres + col];
+      v = apply_act(v, q.act, q.slope);
+      q.out[(size_t)pix * q.ldo + col] = v;
+      amax = fmaxf(amax, fabsf(v));
+    }
+  }
+  if (q.out_amax) {  // (uniform)
+    unsigned mx = __float_as_uint(amax);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) mx = max(mx, (unsigned)__shfl_xor((int)mx, o, 64));
+    unsigned* slot = reinterpret_cast<unsigned*>(q.out_amax);
+    if ((threadIdx.x & 63) == 0 && mx > *reinterpret_cast<volatile unsigned*>(slot)) atomicMax(slot, mx);
+  }
+  if (q.stat) {  // (uniform)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      red[0][ty][tx * 4 + e] = d[e];
+      red[1][ty][tx * 4 + e] = d[e] * d[e];
+    }
+    __syncthreads();
+    if (threadIdx.x < 128) {
+      const int k = threadIdx.x >> 6, cl = threadIdx.x & 63, col = blockIdx.y * 64 + cl;
+      float t = 0.f;
+#pragma unroll
+      for (int r = 0; r < SK_ROWS; ++r) t += red[k][r][cl];
+      if (col < q.Co) q.stat[((size_t)blockIdx.x * 2 + k) * q.Co + col] = t;
+    }
+  }
+}
 
 // ------------------------------------------------------------------------------------ wg_kernel
 constexpr int WG_TILE = 64;
@@ -697,7 +790,7 @@ static std::map<std::array<int, 12>, int> g_gg_choice, g_wg_choice;
 // LHG_TUNE_CACHE=<file>: choices are appended to that file and read back by later processes (one line per geometry, tagged with
 // TUNE_SCHEMA so that a build with a different variant numbering ignores stale lines).
 constexpr int TUNE_RUNS = 5;
-constexpr const char* TUNE_SCHEMA = "lhg-tune-7";
+constexpr const char* TUNE_SCHEMA = "lhg-tune-8";
 static void tune_cache_load() {
   static bool done = false;
   if (done) return;
@@ -857,6 +950,7 @@ static int launch_gg_classes(GGParams& p, Geom* cls, int n, hipStream_t st) {
   for (int c = 0; c < n; ++c) {
     p.g = cls[c];
     p.ncls = 0;
+    p.ks_off = 1;
     const int rc = launch_gg(p, st);
     if (rc) return rc;
   }
@@ -993,6 +1087,51 @@ static int launch_gg_bf16(GGParams& p, hipStream_t st) {
   return act_is_bf16() ? launch_gg_bf16_t<__bf16>(p, st) : launch_gg_bf16_t<float>(p, st);
 }
 
+// The split-K rule: at most 160 tiles of 128 x 128 and at least 64 K steps (the UNet's 24^2 x 1024-channel bottleneck: 144 tiles, 288
+// steps).  The number of ranges follows from the GEOMETRY alone (about 480 workgroups, at most four ranges of whole 32-channel chunks),
+// so that every tiling variant adds the same ranges in the same order.  LHG_SPLITK=0: never.  Returns the ranges (1: no split).
+static int splitk_plan(long long M, int rows_pad, int K, int taps, int* chunks) {
+  static const bool on = [] { const char* e = getenv("LHG_SPLITK"); return !e || atoi(e) != 0; }();
+  // (measurement switches: the rule's three constants)
+  static const int max_tiles = [] { const char* e = getenv("LHG_SPLITK_TILES"); return e ? atoi(e) : 160; }();
+  static const int target = [] { const char* e = getenv("LHG_SPLITK_TARGET"); return e ? atoi(e) : 480; }();
+  static const int max_ranges = [] { const char* e = getenv("LHG_SPLITK_MAX"); return e ? atoi(e) : 4; }();
+  const long long tiles128 = ((M + 127) / 128) * ((rows_pad + 127) / 128);
+  const int kch = K / 32;
+  if (!on || g_precision != LHG_PRECISION_F32_SPLIT_F16 || M <= 0 || tiles128 > max_tiles || (long long)taps * kch < 64 || kch < 2) return 1;
+  const int want = (int)std::min<long long>(std::min<long long>(max_ranges, std::max<long long>(1, (target + tiles128 / 2) / tiles128)), kch);
+  const int c = (kch + want - 1) / want;
+  if (chunks) *chunks = c;
+  return (kch + c - 1) / c;  // no empty range
+}
+static size_t splitk_floats(int ks, long long M, long long M_padded, int rows_pad) {
+  return (size_t)ks * (size_t)((std::max(M, M_padded) + 255) / 256 * 256) * (size_t)rows_pad;
+}
+// the caller's workspace for the NEXT gather-GEMM launch (lhg_gather_gemm_workspace): consumed — used or not — by that launch
+static float* g_next_ws = nullptr;
+static size_t g_next_ws_floats = 0;
+
+// Split-K slabs without a caller's workspace: one grow-only device buffer per stream (launches of one stream are ordered: a launch's finish kernel has read the slabs
+// before the next launch's GEMM overwrites them).  hipMalloc / hipFree block, so the buffer starts at 64 MiB — the step's largest need
+// is 28 MB — and growing it waits for the stream first; never inside a graph capture (the eager warm-up steps have sized it by then).
+static float* splitk_slab(hipStream_t st, size_t floats) {
+  static std::map<hipStream_t, std::pair<float*, size_t>> pool;
+  auto& e = pool[st];
+  if (e.second >= floats) return e.first;
+  hipStreamCaptureStatus cap = hipStreamCaptureStatusNone;
+  if (hipStreamIsCapturing(st, &cap) != hipSuccess || cap != hipStreamCaptureStatusNone) return nullptr;
+  if (e.first) {
+    (void)hipStreamSynchronize(st);
+    (void)hipFree(e.first);
+    e = {nullptr, 0};
+  }
+  const size_t want = std::max(floats, (size_t)16 << 20);
+  float* ptr = nullptr;
+  if (hipMalloc(reinterpret_cast<void**>(&ptr), want * sizeof(float)) != hipSuccess) return nullptr;
+  e = {ptr, want};
+  return ptr;
+}
+
 // fp32 operands as exact sums of bf16 terms (gg3s_kernel): `p.wp` holds split panels (lhg_pack_weight in the same mode).
 static int launch_gg_split(GGParams& p, hipStream_t st) {
   const Geom& g = p.g;
@@ -1022,7 +1161,7 @@ static int launch_gg_split(GGParams& p, hipStream_t st) {
       total += (unsigned)((((c == 0 ? q->g : q->gc[c - 1]).M + bm - 1) / bm) * (q->rows_pad / bn));
     }
     q->cblk[nq] = total;
-    return total;
+    return total * (unsigned)std::max(1, q->ks);  // split K (single class): ks copies of the tile grid
   };
   auto launch3 = [&](auto kern, int bm, int bn, int threads) {
     const unsigned nb = blocks(bm, bn);
@@ -1049,8 +1188,22 @@ static int launch_gg_split(GGParams& p, hipStream_t st) {
     p.strip_rev = rev ? 1 : 0;
     strips = strips && (fwd || rev);  // any other tap numbering would accumulate in another order than gg3s_kernel does
   }
-  auto blocks_strip = [&](int bm, int bn) { return (unsigned)((((long long)g.N * g.Hi * (g.Wi + 2) + bm - 1) / bm) * (p.rows_pad / bn)); };
+  auto blocks_strip = [&](int bm, int bn) { return (unsigned)((((long long)g.N * g.Hi * (g.Wi + 2) + bm - 1) / bm) * (p.rows_pad / bn)) * (unsigned)std::max(1, p.ks); };
   const bool f16 = split_f16();
+  // Split K for launches that cannot fill the chip (splitk_plan): ranges from the geometry alone
+  p.ks = 1;
+  {
+    float* const ws = g_next_ws;
+    const size_t ws_floats = g_next_ws_floats;
+    g_next_ws = nullptr;
+    g_next_ws_floats = 0;
+    if (ncls == 1 && !p.planar_out && !p.ks_off) p.ks = splitk_plan(g.M, p.rows_pad, g.Ci, g.T, &p.ks_chunks);
+    if (p.ks > 1) {
+      const size_t floats = splitk_floats(p.ks, g.M, strips ? (long long)g.N * g.Hi * (g.Wi + 2) : 0, p.rows_pad);
+      p.ks_slab = ws_floats >= floats ? ws : splitk_slab(st, floats);
+      LHG_REQUIRE(p.ks_slab != nullptr, "gather-GEMM: no split-K workspace (%zu floats: pass one with lhg_gather_gemm_workspace — the library's own buffer cannot grow inside a graph capture)", floats);
+    }
+  }
   if (f16) LHG_REQUIRE(p.a_amax != nullptr && p.w_amax != nullptr, "gather-GEMM (fp32_split_f16 mode): the operand's absmax pointer is missing (lhg_absmax)");
   auto valid = [&](int v) {
     // 12 .. 15: round-5 experiments, bit-identical to the others, measured and NOT faster on any layer (tools/gg_tps_sweep.sh):
@@ -1059,6 +1212,7 @@ static int launch_gg_split(GGParams& p, hipStream_t st) {
     // level with the padded one.  Offered to the tuner / a forced choice only under LHG_GG_EXPERIMENTAL=1.
     static const bool experimental = [] { const char* e = getenv("LHG_GG_EXPERIMENTAL"); return e && atoi(e) != 0; }();
     if (ncls == 1 && v >= 12 && !experimental) return false;
+    if (p.ks > 1 && (v == 12 || v == 13)) return false;  // two taps per barrier need an even number of tap steps in every K range
     if (ncls == 1 && v >= 14) return f16 && strips;
     if (ncls == 1 && v >= 12) return f16 && strips && g.Ci % 64 == 0;
     if (ncls == 1 && v >= 10) return f16 && strips && (v == 11 || n128);
@@ -1126,22 +1280,25 @@ static int launch_gg_split(GGParams& p, hipStream_t st) {
     choice = autotuned_variant(g_gg_choice, key, NV, valid, run, st);
   }
   if (choice < 0) choice = n128 && blocks(128, 128) >= 200 ? 0 : (blocks(128, 64) >= 256 ? 1 : 2);
-  if (p.stat_part) {  // rows of the chosen tiling: (pixels per M tile, consumer-wave rows per tile, padded strip coordinates or not)
+  // shape of the chosen tiling: pixels per M tile, consumer-wave rows per tile, padded strip coordinates or not
+  int sh_bm = 128, sh_wgm = 2;
+  bool sh_strip = false;
+  if (NP == 3) { sh_bm = choice == 2 ? 64 : 128; sh_wgm = choice == 4 ? 4 : 2; }
+  else if (f16) {
+    switch (choice % (ncls > 1 ? 10 : 100)) {
+      case 2: case 9: sh_bm = 64; break;
+      case 4: sh_wgm = 4; break;
+      case 5: case 6: case 13: case 15: sh_bm = 64; sh_strip = true; break;
+      case 7: case 8: case 12: case 14: sh_strip = true; break;
+      case 10: case 11: sh_bm = 256; sh_wgm = 4; sh_strip = true; break;
+      default: break;  // 0, 1, 3: 128 pixels, two wave rows
+    }
+  } else sh_bm = choice <= 1 ? 128 : 64;
+  const long long sh_mtot = sh_strip ? (long long)g.N * g.Hi * (g.Wi + 2) : (long long)g.M;
+  if (p.stat_part) {
     LHG_REQUIRE(ncls == 1, "gather-GEMM: BatchNorm statistics rows are not available for merged parity classes");
-    int bm = 128, wgm = 2;
-    bool strip = false;
-    if (NP == 3) { bm = choice == 2 ? 64 : 128; wgm = choice == 4 ? 4 : 2; }
-    else if (f16) {
-      switch (choice) {
-        case 2: case 9: bm = 64; break;
-        case 4: wgm = 4; break;
-        case 5: case 6: case 13: case 15: bm = 64; strip = true; break;
-        case 7: case 8: case 12: case 14: strip = true; break;
-        case 10: case 11: bm = 256; wgm = 4; strip = true; break;
-        default: break;  // 0, 1, 3: 128 pixels, two wave rows
-      }
-    } else bm = choice <= 1 ? 128 : 64;
-    note_stat_rows(p, strip ? (long long)g.N * g.Hi * (g.Wi + 2) : (long long)g.M, bm, wgm);
+    if (p.ks > 1) g_stat_rows = (int)(((sh_mtot + sh_bm - 1) / sh_bm * sh_bm + SK_ROWS - 1) / SK_ROWS);  // written by the split-K finish kernel
+    else note_stat_rows(p, sh_mtot, sh_bm, sh_wgm);
   }
   double mt_sum = 0;  // sum over the classes of pixels x taps
   for (int c = 0; c < ncls; ++c) mt_sum += (double)cls_geom(c).M * cls_geom(c).T;
@@ -1154,6 +1311,17 @@ static int launch_gg_split(GGParams& p, hipStream_t st) {
     timed.tag(all, p.rows_pad, g.Ci, choice, 2.0 * mt_sum * (double)p.rows_pad * g.Ci);
   }
   run(choice);
+  if (p.ks > 1) {  // the ranges' raw accumulators -> the output (epilogue arithmetic, max|.|, statistics rows)
+    SplitKFinish f{};
+    f.slab = p.ks_slab; f.ks = p.ks; f.m_rows = (int)((sh_mtot + sh_bm - 1) / sh_bm * sh_bm); f.rows_pad = p.rows_pad;
+    f.slab_stride = (long long)f.m_rows * p.rows_pad;
+    f.strip = sh_strip ? 1 : 0; f.N = g.N; f.H = g.Hi; f.W = g.Wi;
+    f.M = g.M; f.gh = g.gh; f.gw = g.gw; f.Ho = g.Ho; f.Wo = g.Wo; f.oy0 = g.oy0; f.ox0 = g.ox0; f.ostep = g.ostep;
+    f.out = p.out; f.ldo = g.ldo; f.Co = g.Co;
+    f.bias = p.bias; f.scale = p.scale; f.shift = p.shift; f.res = p.res; f.ldres = p.ldres; f.act = p.act; f.slope = p.slope;
+    f.a_amax = p.a_amax; f.w_amax = p.w_amax; f.out_amax = p.out_amax; f.stat = p.stat_part;
+    hipLaunchKernelGGL(gg_splitk_finish_kernel, dim3((f.m_rows + SK_ROWS - 1) / SK_ROWS, (p.rows_pad + 63) / 64), dim3(256), 0, st, f);
+  }
   return check_launch("gg3s_kernel");
 }
 
@@ -1518,9 +1686,21 @@ int lhg_conv2d_forward(const float* x, int N, int H, int W, int Ci, int ldx, con
   return launch_gg(p, as_stream(s));
 }
 
+long long lhg_gather_gemm_splitk_floats(long long M, long long M_padded, int rows_pad, int K, int taps) {
+  const int ks = splitk_plan(M, rows_pad, K, taps, nullptr);
+  return ks > 1 ? (long long)splitk_floats(ks, M, M_padded, rows_pad) : 0;
+}
+
+int lhg_gather_gemm_workspace(float* ws, long long floats) {
+  g_next_ws = floats > 0 ? ws : nullptr;
+  g_next_ws_floats = (ws && floats > 0) ? (size_t)floats : 0;
+  return LHG_OK;
+}
+
 long long lhg_conv2d_stats_rows_bound(int N, int Ho, int Wo) {
   // the finest tiling writes one row per 32 pixels of the PADDED pixel axis of the strip kernels (every image row two pixels longer)
-  return ((long long)N * Ho * (Wo + 2) + 31) / 32 + 8;
+  // (the split-K finish kernel: one row per 16)
+  return ((long long)N * Ho * (Wo + 2) + 255) / 256 * 16 + 16;
 }
 
 int lhg_conv2d_forward_stats(const float* x, int N, int H, int W, int Ci, int ldx, const float* wp, int rows_pad, int KH, int KW, int stride,

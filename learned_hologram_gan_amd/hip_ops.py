@@ -894,6 +894,24 @@ def _raw_weight(w):
     return wd if wd.is_contiguous() else wd.contiguous()
 
 
+_SPLITK_FLOATS = {}
+
+
+def _splitk_workspace(M, M_padded, rows_pad, K, taps, device):
+    """The split-K slabs of the gather-GEMM launch that follows (lhg_gather_gemm_splitk_floats: 0 for all but the launches that cannot
+    fill the chip), allocated HERE — through torch's allocator, so that a hipGraph capture gets them from the graph's pool — and handed to
+    the library for its next launch.  Returns the tensor (keep it referenced until the launch is enqueued) or None."""
+    key = (M, M_padded, rows_pad, K, taps, _mode())
+    n = _SPLITK_FLOATS.get(key)
+    if n is None:
+        n = _SPLITK_FLOATS[key] = int(native.load().lhg_gather_gemm_splitk_floats(M, M_padded, rows_pad, K, taps))
+    if not n:
+        return None
+    ws = torch.empty((n,), dtype=torch.float32, device=device)
+    call("lhg_gather_gemm_workspace", ptr(ws), n)
+    return ws
+
+
 # LHG_EPILOGUE_BN_STATS=0: a conv that feeds a train-mode BatchNorm does not leave the statistics' partial rows behind (lhg_bn_stats runs its
 # pass over the tensor, as before ABI 10) — for A/B measurements.
 _EPILOGUE_BN_STATS = os.environ.get("LHG_EPILOGUE_BN_STATS", "1") != "0"
@@ -939,6 +957,7 @@ def conv2d_forward_raw(x, w, bias, stride, act=ACT_NONE, slope=0.0, scale=None, 
         x_amax = operand_absmax(x)
     # measure_out: the output feeds another GEMM directly (eval-mode chains, conv + activation blocks): the epilogue measures max|y|
     y_amax = _out_amax(out, x.device) if measure_out and not planar else None
+    ws = None if planar else _splitk_workspace(N * Ho * Wo, N * Ho * (Wo + 2) if (KH == 3 and KW == 3 and stride == 1) else 0, wp.shape[1], Ci, KH * KW, x.device)
     if (bn_stats and _EPILOGUE_BN_STATS and not planar and act == ACT_NONE and scale is None and shift is None and res is None
             and ldy == Co and sync_world() == 1):
         bound = int(native.load().lhg_conv2d_stats_rows_bound(N, Ho, Wo))
@@ -951,6 +970,7 @@ def conv2d_forward_raw(x, w, bias, stride, act=ACT_NONE, slope=0.0, scale=None, 
     else:
         call("lhg_conv2d_forward", px, N, H, W, Ci, ldx, ptr(wp), wp.shape[1], KH, KW, stride, py, Co, ldy,
              ptr(bias), ptr(scale), ptr(shift), pres, ldres, act, float(slope), int(planar), ptr(x_amax), ptr(y_amax), stream_ptr())
+    del ws  # (enqueued: the allocator's stream-ordered reuse takes it from here)
     if y_amax is not None:
         tag_absmax(y, y_amax)  # (a view into a shared buffer: the slot bounds the whole buffer, hence the view)
     return y
@@ -1083,6 +1103,7 @@ class Conv2dInputGradFn(TrackedFunction):
         # max|gx| from the epilogue (the added gradient included): gx may be the operand of the next backward GEMM — the gradient of a
         # skip-concatenation buffer feeds the transposed conv's backward, a critic block's the previous block's — without a pass of its own
         gx_amax = fused_absmax_slot(gy.device) if (measure_out and _EPILOGUE_GX_AMAX) else None
+        ws = _splitk_workspace(N * H * W, N * H * (W + 2) if (KH == 3 and KW == 3 and stride == 1) else 0, wp.shape[1], Cg, KH * KW, gy.device)  # noqa: F841
         call("lhg_conv2d_backward_input_add_amax", pg, N, H, W, Cg, ldg, ptr(wp), wp.shape[1], KH, KW, stride, pgx, Ci, ldgx, pres, ldres,
              ptr(gy_amax), ptr(gx_amax), stream_ptr())
         return tag_absmax(gx, gx_amax)
@@ -1268,6 +1289,7 @@ class ConvTranspose2x2Fn(TrackedFunction):
             pgx, _, _, _, _, ldgx = nhwc(gx)
             native.count_flops(0, 2.0 * N * (H2 // 2) * (W2 // 2) * 4 * Ci * Co)
             gx_amax = None  # (gx goes to a BatchNorm backward, which measures what it writes: nothing to measure here)
+            ws = _splitk_workspace(N * (H2 // 2) * (W2 // 2), 0, wp.shape[1], Cg, 4, gy.device)  # noqa: F841  (a four-tap stride-2 gather over N H W pixels)
             call("lhg_conv_transpose2x2_backward_input_amax", pg, N, H2 // 2, W2 // 2, Cg, ldg, ptr(wp), wp.shape[1], pgx, Ci, ldgx, ptr(gy_amax),
                  ptr(gx_amax), stream_ptr())
             tag_absmax(gx, gx_amax)

@@ -56,6 +56,8 @@ _SIGNATURES = {
     "lhg_pack_weights": [_p, _i, _p],
     "lhg_conv2d_forward": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _i, _i, _f, _i, _p, _p, _p],
     "lhg_conv2d_stats_rows_bound": [_i, _i, _i],
+    "lhg_gather_gemm_splitk_floats": [_ll, _ll, _i, _i, _i],
+    "lhg_gather_gemm_workspace": [_p, _ll],
     "lhg_conv2d_forward_stats": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, C.POINTER(C.c_int), _p],
     "lhg_bn_stats_finish": [_p, _i, _p, _ll, _i, _p, _p, _p, _f, _f, _p],
     "lhg_conv2d_backward_input": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p, _p],
@@ -132,7 +134,7 @@ _SIGNATURES = {
     "lhg_wg6_variants": [],
     "lhg_wg6_variant_name": [_i],
 }
-_RESTYPE = {"lhg_last_error": C.c_char_p, "lhg_fused_workspace_floats": C.c_longlong, "lhg_packed_weight_floats": C.c_longlong, "lhg_fft_table_floats": C.c_longlong, "lhg_chanmax_partial_rows": C.c_longlong, "lhg_conv2d_stats_rows_bound": C.c_longlong, "lhg_conv2d_thin_wgrad_workspace": C.c_size_t, "lhg_psnr_ssim_workspace": C.c_size_t,
+_RESTYPE = {"lhg_last_error": C.c_char_p, "lhg_fused_workspace_floats": C.c_longlong, "lhg_packed_weight_floats": C.c_longlong, "lhg_fft_table_floats": C.c_longlong, "lhg_chanmax_partial_rows": C.c_longlong, "lhg_conv2d_stats_rows_bound": C.c_longlong, "lhg_gather_gemm_splitk_floats": C.c_longlong, "lhg_conv2d_thin_wgrad_workspace": C.c_size_t, "lhg_psnr_ssim_workspace": C.c_size_t,
             "lhg_conv2d_backward_weight_workspace": C.c_size_t, "lhg_conv_transpose2x2_backward_weight_workspace": C.c_size_t, "lhg_wg6_variant_name": C.c_char_p}
 
 _lib = None
