@@ -12,6 +12,8 @@
 // iteration) and keeps its T x CT x CH x 4 weights (or weight-gradient accumulators) in registers while it walks along an image
 // row segment; wide tensors are touched with 16-byte lanes, 64 consecutive lanes = 1 KiB contiguous.  All reductions have a
 // fixed order (xor-shuffle trees, then a slab reduce): results are run-to-run identical.
+#include <type_traits>
+
 #include "common.h"
 
 namespace lhg {
@@ -124,7 +126,10 @@ __global__ __launch_bounds__(256) void thin_fanout_kernel(const ThinParams p, co
   __syncthreads();
 
   const int wc = wave % p.wpc, wp = wave / p.wpc, wpp = 4 / p.wpc;
-  const int c = (blockIdx.y * p.wpc + wc) * 64 + lane;
+  // at most 32 wide channels (RGB -> 32, the critic's first layer): the two halves of a wave take the same channels and different pixel
+  // ranges — with a lane per channel half of the wave idled through every multiply-add (round 5: 118 -> 108 us at 384^2 x 8, 72 -> 62 at x 4)
+  const int halves = p.cw <= 32 ? 2 : 1;
+  const int c = halves == 2 ? (lane & 31) : (blockIdx.y * p.wpc + wc) * 64 + lane;
   const bool live = c < p.cw;
   const int cc = live ? c : p.cw - 1;
   float wr[T][CT];
@@ -134,8 +139,9 @@ __global__ __launch_bounds__(256) void thin_fanout_kernel(const ThinParams p, co
     for (int ct = 0; ct < CT; ++ct) wr[t][ct] = ct < p.ct_real ? p.w[ct * p.st + cc * p.sw + (p.sign > 0 ? t : T - 1 - t)] : 0.f;
   const float bias = p.bias ? p.bias[cc] : 0.f, sc = p.scale ? p.scale[cc] : 1.f, sh = p.shift ? p.shift[cc] : 0.f;
 
-  const int per = ((x_cnt + wpp - 1) / wpp + TP - 1) / TP * TP;
-  const int xs = wp * per, xe = min(x_cnt, xs + per);
+  const int parts = wpp * halves;
+  const int per = ((x_cnt + parts - 1) / parts + TP - 1) / TP * TP;
+  const int xs = (wp * halves + (halves == 2 ? lane >> 5 : 0)) * per, xe = min(x_cnt, xs + per);
   float amax = 0.f;
   for (int x0 = xs; x0 < xe; x0 += TP) {
     float acc[TP];
@@ -157,14 +163,37 @@ __global__ __launch_bounds__(256) void thin_fanout_kernel(const ThinParams p, co
           for (int ct = 0; ct < CT; ++ct) acc[j] = fmaf(s[j + kx][ct], wr[r * ROWS + kx][ct], acc[j]);
     }
     if (live) {
+      // the activation and "all TP pixels inside the range" are decided ONCE per iteration (wave-uniform), so that the TP elements are
+      // straight-line code: with the run-time activation switch and the bounds test per element the epilogue's instructions outnumbered
+      // the 3x3 contraction's (round 5 timing ablations on a matrix-pipe variant of this kernel: no stores 98 us, no strip 87, one
+      // multiply step instead of eighteen 75 — of 86; a straight-line epilogue: 69).  Same arithmetic, same bits.
       float* o = out + ((long long)row * p.W + x_begin + x0) * p.ld_o + c;
+      const bool full = halves == 1 && x0 + TP <= xe;  // (two pixel ranges per wave: the test stays per lane)
+      auto emit = [&](auto act_tag, auto full_tag) {
+        constexpr int ACT = decltype(act_tag)::value;
+        constexpr bool FULL = decltype(full_tag)::value;
 #pragma unroll
-      for (int j = 0; j < TP; ++j)
-        if (x0 + j < xe) {
-          const float v = apply_act(acc[j] * sc + sh, p.act, p.slope);
-          o[(long long)j * p.ld_o] = v;
-          amax = fmaxf(amax, fabsf(v));
+        for (int j = 0; j < TP; ++j) {
+          float v = acc[j] * sc + sh;
+          if constexpr (ACT == LHG_ACT_RELU) v = v > 0.f ? v : 0.f;
+          else if constexpr (ACT == LHG_ACT_LEAKY) v = v > 0.f ? v : v * p.slope;
+          else if constexpr (ACT == LHG_ACT_SIGMOID) v = 1.f / (1.f + expf(-v));
+          if (FULL || x0 + j < xe) {
+            o[j * p.ld_o] = v;  // (32-bit offset: TP pixels x ld_o)
+            amax = fmaxf(amax, fabsf(v));
+          }
         }
+      };
+      auto by_full = [&](auto act_tag) {
+        if (full) emit(act_tag, std::true_type{});
+        else emit(act_tag, std::false_type{});
+      };
+      switch (p.act) {  // wave-uniform
+        case LHG_ACT_RELU: by_full(std::integral_constant<int, LHG_ACT_RELU>{}); break;
+        case LHG_ACT_LEAKY: by_full(std::integral_constant<int, LHG_ACT_LEAKY>{}); break;
+        case LHG_ACT_SIGMOID: by_full(std::integral_constant<int, LHG_ACT_SIGMOID>{}); break;
+        default: by_full(std::integral_constant<int, LHG_ACT_NONE>{}); break;
+      }
     }
   }
   if (p.out_amax) {  // (uniform) the tensor scale of the GEMM that reads this output, without an lhg_absmax pass over it (round 5: 0.44 ms of a 4K frame)
