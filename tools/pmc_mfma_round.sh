@@ -13,4 +13,5 @@ run wgrad_stride2_512_1024_96 wg6_kernel 512 1024 96 3 2 wgrad 12
 run dgrad_stride2_1024_512 gg 512 1024 96 3 2 dgrad 12
 run fwd_64_64_384 gg 64 64 384 3 1 fwd 12
 run fwd_1x1_256_128_192 gg 256 128 192 1 1 fwd 12
+run fwd_1024_1024_24 gg 1024 1024 24 3 1 fwd 12   # the split-K launch of the UNet bottleneck (three K ranges)
 cat $out
