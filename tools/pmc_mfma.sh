@@ -10,11 +10,11 @@ python3 - "$tag" "$kern" <<'PY'
 import csv,glob,collections,sys,json
 tag,kern=sys.argv[1],sys.argv[2]
 f=glob.glob(f"gpurun_out/_pmcm_{tag}/**/*counter_collection.csv",recursive=True)
-rows=[r for r in csv.DictReader(open(f[0])) if kern in r["Kernel_Name"]]
+rows=[r for r in csv.DictReader(open(f[0])) if kern in r["Kernel_Name"] and "finish" not in r["Kernel_Name"]]  # (not the split-K finish kernel)
 d=collections.defaultdict(list)
 for r in rows: d[r["Counter_Name"]].append(float(r["Counter_Value"]))
 t=glob.glob(f"gpurun_out/_pmcm_{tag}/**/*kernel_trace.csv",recursive=True)
-us=[(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3 for r in csv.DictReader(open(t[0])) if kern in r["Kernel_Name"]]
+us=[(int(r["End_Timestamp"])-int(r["Start_Timestamp"]))/1e3 for r in csv.DictReader(open(t[0])) if kern in r["Kernel_Name"] and "finish" not in r["Kernel_Name"]]
 avg={k: sum(v[-4:])/len(v[-4:]) for k,v in d.items()}
 out={"tag":tag,"kernel":kern,"args":sys.argv[3:],"counters":{k:round(v) for k,v in avg.items()},"us_under_pmc":[round(x,1) for x in us[-3:]]}
 if avg.get("GRBM_GUI_ACTIVE"):
