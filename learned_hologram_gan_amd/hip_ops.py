@@ -897,6 +897,24 @@ def _raw_weight(w):
 _SPLITK_FLOATS = {}
 
 
+_STATS_ROWS_BOUND = {}
+
+
+def _stats_rows_bound(N, Ho, Wo):
+    key = (N, Ho, Wo)
+    n = _STATS_ROWS_BOUND.get(key)
+    if n is None:
+        n = _STATS_ROWS_BOUND[key] = int(native.load().lhg_conv2d_stats_rows_bound(N, Ho, Wo))
+    return n
+
+
+def _splitk_release(ws):
+    """After the launch the workspace was meant for — or after the call failed before reaching it: the library must not keep the pointer
+    (a later launch would write through it into memory the allocator has handed to somebody else)."""
+    if ws is not None:
+        call("lhg_gather_gemm_workspace", None, 0)
+
+
 def _splitk_workspace(M, M_padded, rows_pad, K, taps, device):
     """The split-K slabs of the gather-GEMM launch that follows (lhg_gather_gemm_splitk_floats: 0 for all but the launches that cannot
     fill the chip), allocated HERE — through torch's allocator, so that a hipGraph capture gets them from the graph's pool — and handed to
@@ -958,19 +976,21 @@ def conv2d_forward_raw(x, w, bias, stride, act=ACT_NONE, slope=0.0, scale=None, 
     # measure_out: the output feeds another GEMM directly (eval-mode chains, conv + activation blocks): the epilogue measures max|y|
     y_amax = _out_amax(out, x.device) if measure_out and not planar else None
     ws = None if planar else _splitk_workspace(N * Ho * Wo, N * Ho * (Wo + 2) if (KH == 3 and KW == 3 and stride == 1) else 0, wp.shape[1], Ci, KH * KW, x.device)
-    if (bn_stats and _EPILOGUE_BN_STATS and not planar and act == ACT_NONE and scale is None and shift is None and res is None
-            and ldy == Co and sync_world() == 1):
-        bound = int(native.load().lhg_conv2d_stats_rows_bound(N, Ho, Wo))
-        partial = torch.empty((bound * 2 * Co,), dtype=torch.float32, device=x.device)
-        rows = ctypes.c_int(0)
-        call("lhg_conv2d_forward_stats", px, N, H, W, Ci, ldx, ptr(wp), wp.shape[1], KH, KW, stride, py, Co, ldy, ptr(bias), ptr(x_amax), ptr(y_amax),
-             ptr(partial), ctypes.byref(rows), stream_ptr())
-        if rows.value > 0:
-            y.__dict__["_lhg_bn_partial"] = (y._version, partial, rows.value, bias.detach() if bias is not None else None)
-    else:
-        call("lhg_conv2d_forward", px, N, H, W, Ci, ldx, ptr(wp), wp.shape[1], KH, KW, stride, py, Co, ldy,
-             ptr(bias), ptr(scale), ptr(shift), pres, ldres, act, float(slope), int(planar), ptr(x_amax), ptr(y_amax), stream_ptr())
-    del ws  # (enqueued: the allocator's stream-ordered reuse takes it from here)
+    try:
+        if (bn_stats and _EPILOGUE_BN_STATS and not planar and act == ACT_NONE and scale is None and shift is None and res is None
+                and ldy == Co and sync_world() == 1):
+            bound = _stats_rows_bound(N, Ho, Wo)
+            partial = torch.empty((bound * 2 * Co,), dtype=torch.float32, device=x.device)
+            rows = ctypes.c_int(0)
+            call("lhg_conv2d_forward_stats", px, N, H, W, Ci, ldx, ptr(wp), wp.shape[1], KH, KW, stride, py, Co, ldy, ptr(bias), ptr(x_amax), ptr(y_amax),
+                 ptr(partial), ctypes.byref(rows), stream_ptr())
+            if rows.value > 0:
+                y.__dict__["_lhg_bn_partial"] = (y._version, partial, rows.value, bias.detach() if bias is not None else None)
+        else:
+            call("lhg_conv2d_forward", px, N, H, W, Ci, ldx, ptr(wp), wp.shape[1], KH, KW, stride, py, Co, ldy,
+                 ptr(bias), ptr(scale), ptr(shift), pres, ldres, act, float(slope), int(planar), ptr(x_amax), ptr(y_amax), stream_ptr())
+    finally:
+        _splitk_release(ws)
     if y_amax is not None:
         tag_absmax(y, y_amax)  # (a view into a shared buffer: the slot bounds the whole buffer, hence the view)
     return y
@@ -1103,9 +1123,12 @@ class Conv2dInputGradFn(TrackedFunction):
         # max|gx| from the epilogue (the added gradient included): gx may be the operand of the next backward GEMM — the gradient of a
         # skip-concatenation buffer feeds the transposed conv's backward, a critic block's the previous block's — without a pass of its own
         gx_amax = fused_absmax_slot(gy.device) if (measure_out and _EPILOGUE_GX_AMAX) else None
-        ws = _splitk_workspace(N * H * W, N * H * (W + 2) if (KH == 3 and KW == 3 and stride == 1) else 0, wp.shape[1], Cg, KH * KW, gy.device)  # noqa: F841
-        call("lhg_conv2d_backward_input_add_amax", pg, N, H, W, Cg, ldg, ptr(wp), wp.shape[1], KH, KW, stride, pgx, Ci, ldgx, pres, ldres,
-             ptr(gy_amax), ptr(gx_amax), stream_ptr())
+        ws = _splitk_workspace(N * H * W, N * H * (W + 2) if (KH == 3 and KW == 3 and stride == 1) else 0, wp.shape[1], Cg, KH * KW, gy.device)
+        try:
+            call("lhg_conv2d_backward_input_add_amax", pg, N, H, W, Cg, ldg, ptr(wp), wp.shape[1], KH, KW, stride, pgx, Ci, ldgx, pres, ldres,
+                 ptr(gy_amax), ptr(gx_amax), stream_ptr())
+        finally:
+            _splitk_release(ws)
         return tag_absmax(gx, gx_amax)
 
     @staticmethod
@@ -1289,9 +1312,12 @@ class ConvTranspose2x2Fn(TrackedFunction):
             pgx, _, _, _, _, ldgx = nhwc(gx)
             native.count_flops(0, 2.0 * N * (H2 // 2) * (W2 // 2) * 4 * Ci * Co)
             gx_amax = None  # (gx goes to a BatchNorm backward, which measures what it writes: nothing to measure here)
-            ws = _splitk_workspace(N * (H2 // 2) * (W2 // 2), 0, wp.shape[1], Cg, 4, gy.device)  # noqa: F841  (a four-tap stride-2 gather over N H W pixels)
-            call("lhg_conv_transpose2x2_backward_input_amax", pg, N, H2 // 2, W2 // 2, Cg, ldg, ptr(wp), wp.shape[1], pgx, Ci, ldgx, ptr(gy_amax),
-                 ptr(gx_amax), stream_ptr())
+            ws = _splitk_workspace(N * (H2 // 2) * (W2 // 2), 0, wp.shape[1], Cg, 4, gy.device)  # (a four-tap stride-2 gather over N H W pixels)
+            try:
+                call("lhg_conv_transpose2x2_backward_input_amax", pg, N, H2 // 2, W2 // 2, Cg, ldg, ptr(wp), wp.shape[1], pgx, Ci, ldgx, ptr(gy_amax),
+                     ptr(gx_amax), stream_ptr())
+            finally:
+                _splitk_release(ws)
             tag_absmax(gx, gx_amax)
         if not param_grads_wanted():
             return gx, None, None, None

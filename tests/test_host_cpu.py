@@ -62,6 +62,37 @@ def test_host_side_size_functions_and_supported_lengths():
         lib.lhg_set_conv_precision(mode)
 
 
+def test_split_k_rule_and_statistics_row_bound_are_functions_of_the_geometry():
+    """Pure host functions of ABI 10 (no kernel launch).  lhg_gather_gemm_splitk_floats: the UNet bottleneck (2304 pixels x 1024 -> 1024
+    channels, 3x3: 144 tiles of 128 x 128, 288 K steps) splits into three ranges of whole 32-channel chunks, its slabs cover the padded
+    pixel axis of the strip kernels rounded to the largest tile; launches that fill the chip, short K axes and the other arithmetic
+    modes do not split.  lhg_conv2d_stats_rows_bound covers the finest grouping (one row per 16 padded pixels: the split-K finish kernel)."""
+    from learned_hologram_gan_amd import native
+
+    lib = native.load()
+    assert lib.lhg_get_conv_precision() == native_precision_f16_split()
+    M, Mp = 4 * 24 * 24, 4 * 24 * 26
+    assert lib.lhg_gather_gemm_splitk_floats(M, Mp, 1024, 1024, 9) == 3 * 2560 * 1024      # 144 tiles -> 3 ranges (11 + 11 + 10 chunks)
+    assert lib.lhg_gather_gemm_splitk_floats(M, Mp, 512, 1024, 9) == 4 * 2560 * 512        # 72 tiles -> capped at 4 ranges
+    assert lib.lhg_gather_gemm_splitk_floats(M, 0, 1024, 1024, 1) == 0                     # 1x1: 32 K steps, too short
+    assert lib.lhg_gather_gemm_splitk_floats(4 * 48 * 48, 4 * 48 * 50, 512, 512, 9) == 0   # 288 tiles: the chip is full enough
+    assert lib.lhg_gather_gemm_splitk_floats(4 * 384 * 384, 4 * 384 * 386, 64, 64, 9) == 0
+    assert lib.lhg_gather_gemm_splitk_floats(192, 0, 64, 2080, 1) == 4 * 256 * 64          # a long 1x1 K axis on a small image: 65 chunks -> 4 ranges
+    lib.lhg_set_conv_precision(0)  # exact fp32 kernels: no split
+    try:
+        assert lib.lhg_gather_gemm_splitk_floats(M, Mp, 1024, 1024, 9) == 0
+    finally:
+        lib.lhg_set_conv_precision(lib.lhg_default_conv_precision())
+    for N, Ho, Wo in ((4, 384, 384), (4, 24, 24), (1, 17, 23), (1, 2160, 3840)):
+        mp = N * Ho * (Wo + 2)
+        bound = lib.lhg_conv2d_stats_rows_bound(N, Ho, Wo)
+        assert bound >= (mp + 255) // 256 * 16 and bound >= (mp + 31) // 32 + 4 and bound <= mp // 16 + 64
+
+
+def native_precision_f16_split():
+    return 4  # LHG_PRECISION_F32_SPLIT_F16 (include/lhg_hip.h)
+
+
 def test_library_is_gfx950_code_object():
     from learned_hologram_gan_amd import native
 
