@@ -941,7 +941,7 @@ static bool merge_classes() {
 static int launch_gg_classes(GGParams& p, Geom* cls, int n, hipStream_t st) {
   if (n <= 0) return LHG_OK;
   std::stable_sort(cls, cls + n, [](const Geom& a, const Geom& b) { return (long long)a.M * a.T > (long long)b.M * b.T; });
-  if (n > 1 && n <= 4 && merge_classes() && g_precision == LHG_PRECISION_F32_SPLIT_F16 && !act_is_bf16()) {
+  if (n > 1 && n <= 4 && merge_classes() && ((g_precision == LHG_PRECISION_F32_SPLIT_F16 && !act_is_bf16()) || g_precision == LHG_PRECISION_BF16)) {
     p.g = cls[0];
     for (int c = 1; c < n; ++c) p.gc[c - 1] = cls[c];
     p.ncls = n;
@@ -1036,15 +1036,28 @@ static int launch_gg_bf16_t(GGParams& p, hipStream_t st) {
   LHG_REQUIRE((g.ldi * ES) % 16 == 0 && (reinterpret_cast<uintptr_t>(p.in) & 15) == 0, "gather-GEMM: input must be 16-byte aligned (ld %d)", g.ldi);
   LHG_REQUIRE((reinterpret_cast<uintptr_t>(p.wp) & 15) == 0, "gather-GEMM: packed weights must be 16-byte aligned");
   LHG_REQUIRE(p.rows_pad % 64 == 0 && p.rows_pad >= g.Co, "gather-GEMM: rows_pad %d must be a multiple of 64 covering Co=%d", p.rows_pad, g.Co);
+  // merged output-parity classes (round 5, second session: the bf16 modes launched every class of a stride-2 input gradient / transposed
+  // conv by itself — 6 extra launches per such operator in a host-bound step): gg3s_kernel's class logic does not depend on the planes
+  const int ncls = std::max(1, p.ncls);
+  auto cls_geom = [&](int c) -> const Geom& { return c == 0 ? p.g : p.gc[c - 1]; };
   int max_ws = 0;
-  for (int t = 0; t < g.T; ++t) max_ws = std::max(max_ws, g.ws[t]);
+  for (int c = 0; c < ncls; ++c)
+    for (int t = 0; t < cls_geom(c).T; ++t) max_ws = std::max(max_ws, cls_geom(c).ws[t]);
   const unsigned long long in_bytes = (((unsigned long long)g.N * g.Hi * g.Wi - 1) * g.ldi + g.Ci) * (unsigned long long)ES;
   const unsigned long long wp_bytes = (unsigned long long)(max_ws + 1) * p.rows_pad * g.Ci * 2ull;
   LHG_REQUIRE(wp_bytes < (1ull << 32) - 64, "gather-GEMM (bf16 mode): weight panels of 4 GiB and more are not supported");
   LHG_REQUIRE(p.planar_out || epilogue_window_fits(g, p.res ? p.ldres : 0, ES), "gather-GEMM: an output tile spans 1 GiB or more (Wo %d, ld %d)", g.Wo, g.ldo);
   const unsigned long long ib = in_bytes;
   const unsigned wb = (unsigned)wp_bytes;
-  auto blocks = [&](int bm, int bn) { return (unsigned)(((g.M + bm - 1) / bm) * (p.rows_pad / bn)); };
+  auto blocks = [&](int bm, int bn) {  // also the classes' first workgroups (written into p before it is copied to the kernel)
+    unsigned total = 0;
+    for (int c = 0; c < ncls; ++c) {
+      p.cblk[c] = total;
+      total += (unsigned)(((cls_geom(c).M + bm - 1) / bm) * (p.rows_pad / bn));
+    }
+    p.cblk[ncls] = total;
+    return total;
+  };
   const bool n128 = p.rows_pad % 128 == 0;
   // 0..2: 32-k steps; 3..5: 64-k steps (half the barriers and address arithmetic per flop; Ci % 64 == 0); 6..9: the 8-wave
   // producer / consumer kernel (gg3s_kernel with one bf16 plane): 128x128 / 128x64 / 64x64 tiles with 64-k steps, 128x128 with 32-k
@@ -1052,9 +1065,13 @@ static int launch_gg_bf16_t(GGParams& p, hipStream_t st) {
   const bool k64 = g.Ci % 64 == 0;
   auto valid = [&](int v) {
     if (v >= 6) return (v == 6 || v == 9 ? n128 : true) && (v == 9 || k64);
+    if (ncls > 1) return false;  // gg2b_kernel knows one geometry
     return (v % 3 == 0 ? n128 : true) && (v < 3 || k64);
   };
   auto run = [&](int v) {
+    // (the grid first: blocks() writes the class offsets into p, which the launch then copies)
+    const unsigned nb = v == 6 || v == 9 || v == 0 || v == 3 ? blocks(128, 128) : (v == 7 || v == 1 || v == 4 ? blocks(128, 64) : blocks(64, 64));
+    (void)nb;
     switch (v) {
       case 6: hipLaunchKernelGGL((gg3s_kernel<128, 128, 1, 4, 64, TA>), dim3(blocks(128, 128)), dim3(512), 0, st, p, ib, wb); break;
       case 7: hipLaunchKernelGGL((gg3s_kernel<128, 64, 1, 4, 64, TA>), dim3(blocks(128, 64)), dim3(512), 0, st, p, ib, wb); break;
@@ -1072,13 +1089,25 @@ static int launch_gg_bf16_t(GGParams& p, hipStream_t st) {
   static const int forced = [] { const char* e = getenv("LHG_GGB_VARIANT"); return e ? atoi(e) : -1; }();
   int choice = (forced >= 0 && forced < NV && valid(forced)) ? forced : -1;
   if (choice < 0 && g_autotune_enabled) {
-    const std::array<int, 12> key = {g.M, p.rows_pad, g.Ci, g.Co, g.T, g.istep, g.ostep, g.Hi, g.Wi, g.ldi, g.ldo, p.planar_out + 2 + 16 * ES};
+    const std::array<int, 12> key = {g.M, p.rows_pad, g.Ci, g.Co, g.T, g.istep, g.ostep, g.Hi, g.Wi, g.ldi, g.ldo, p.planar_out + 2 + 16 * ES + 256 * ncls};
     choice = autotuned_variant(g_gg_choice, key, NV, valid, run, st);
   }
-  if (choice < 0) choice = n128 && blocks(128, 128) >= 256 ? 0 : (blocks(128, 64) >= 256 ? 1 : 2);
-  note_stat_rows(p, g.M, (choice == 2 || choice == 5 || choice == 8) ? 64 : 128, 2);  // every variant: 2 x 2 consumer waves
-  ScopedKernelTime timed(0, st, 2.0 * g.M * (double)p.rows_pad * g.Ci * g.T);
-  timed.tag(g, p.rows_pad, g.Ci, choice, 2.0 * g.M * (double)p.rows_pad * g.Ci * g.T);
+  if (choice < 0) {
+    if (ncls > 1) choice = k64 ? (n128 && blocks(128, 128) >= 256 ? 6 : (blocks(128, 64) >= 256 ? 7 : 8)) : 9;
+    else choice = n128 && blocks(128, 128) >= 256 ? 0 : (blocks(128, 64) >= 256 ? 1 : 2);
+  }
+  LHG_REQUIRE(valid(choice), "gather-GEMM (bf16 mode): no kernel for this launch (%d parity classes, rows_pad %d, Ci %d)", ncls, p.rows_pad, g.Ci);
+  if (ncls == 1) note_stat_rows(p, g.M, (choice == 2 || choice == 5 || choice == 8) ? 64 : 128, 2);  // every variant: 2 x 2 consumer waves
+  double mt_sum = 0;  // sum over the classes of pixels x taps
+  for (int c = 0; c < ncls; ++c) mt_sum += (double)cls_geom(c).M * cls_geom(c).T;
+  ScopedKernelTime timed(0, st, 2.0 * mt_sum * (double)p.rows_pad * g.Ci);
+  if (ncls == 1) timed.tag(g, p.rows_pad, g.Ci, choice, 2.0 * mt_sum * (double)p.rows_pad * g.Ci);
+  else {
+    Geom all = g;  // logged as one launch: total pixels, total taps
+    all.M = 0; all.T = 0;
+    for (int c = 0; c < ncls; ++c) { all.M += cls_geom(c).M; all.T += cls_geom(c).T; }
+    timed.tag(all, p.rows_pad, g.Ci, choice, 2.0 * mt_sum * (double)p.rows_pad * g.Ci);
+  }
   run(choice);
   return check_launch("gg2b_kernel");
 }
