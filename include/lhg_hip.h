@@ -243,6 +243,12 @@ int lhg_conv2d_thin_forward(const float* x, int N, int H, int W, int Ci, int ldx
 int lhg_conv2d_thin_forward_amax(const float* x, int N, int H, int W, int Ci, int ldx, const float* w, int Co, int k,
                                  float* y, int ldy, const float* bias, const float* scale, const float* shift,
                                  int act, float slope, int planar_out, float* y_absmax, lhg_stream_t s);
+/* ABI 10: the thin-INPUT form reading the reference's NCHW input tensor as it is (x_nchw: (N, Ci, H, W) fp32) — the RGBD frame of
+ * generatePOH.py:41-70 goes into the first two convs of the generator (3x3 and the 1x1 shortcut, neural_network_components.py:22-31)
+ * without the NCHW -> NHWC(32) conversion pass: 1 GB written and read twice per 4K frame. */
+int lhg_conv2d_thin_forward_nchw(const float* x_nchw, int N, int H, int W, int Ci, const float* w, int Co, int k,
+                                 float* y, int ldy, const float* bias, const float* scale, const float* shift,
+                                 int act, float slope, float* y_absmax, lhg_stream_t s);
 int lhg_conv2d_thin_backward_input(const float* gy, int N, int H, int W, int Co, int ldgy, const float* w, int Ci, int k,
                                    float* gx, int ldgx, lhg_stream_t s);
 /* gw (Co, Ci, k, k) written in place (deterministic two-stage sum); ws >= lhg_conv2d_thin_wgrad_workspace bytes. */

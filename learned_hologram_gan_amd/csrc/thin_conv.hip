@@ -27,6 +27,7 @@ struct ThinParams {
   const float* scale;  // fan-out epilogue: v = (acc + bias) * scale + shift (eval-mode BN folded in), or null
   const float* shift;
   int thin_vec;        // thin rows are 16-byte aligned with ld >= CT: read them with float4 loads
+  int thin_planar;     // fan-out only: `thin` is (N, ct_real, H, W) — the reference's NCHW input read as it is (lhg_conv2d_thin_forward_nchw)
   int planar;          // fan-in: thin output written as (N, ct_real, H, W)
   int N, H, W;
   int ld_t, ld_w, ld_o;
@@ -93,7 +94,15 @@ __device__ __forceinline__ void stage_strip(const ThinParams& p, const float* __
     const bool ok = (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
     const float* q = thin + ((long long)(row + (ok ? dy : 0)) * p.W + (ok ? xx : x_begin)) * p.ld_t;  // always a valid pixel
     float v[CT];
-    if (CT >= 4 && p.thin_vec) {
+    if (p.thin_planar) {  // NCHW: channel planes H W floats apart, consecutive strip pixels are consecutive floats of each plane
+      const int n = row / p.H;
+      const float* qp = thin + (((long long)n * p.ct_real) * p.H + (ok ? yy : y)) * p.W + (ok ? xx : x_begin);
+#pragma unroll
+      for (int c = 0; c < CT; ++c) {
+        const float u = qp[(long long)(c < p.ct_real ? c : 0) * p.H * p.W];
+        v[c] = (ok && c < p.ct_real) ? u : 0.f;
+      }
+    } else if (CT >= 4 && p.thin_vec) {
 #pragma unroll
       for (int g = 0; g < CT / 4; ++g) {
         const f32x4 u = *reinterpret_cast<const f32x4*>(q + 4 * g);
@@ -609,6 +618,19 @@ int lhg_conv2d_thin_forward_amax(const float* x, int N, int H, int W, int Ci, in
   p.wide = x; p.ld_w = ldx; p.cw = Ci; p.out = y; p.ld_o = ldy; p.ct_real = Co; p.thin = nullptr; p.ld_t = 0;
   p.st = Ci * T; p.sw = T;
   return dispatch_thin(K_FANIN, k, p, as_stream(s));
+}
+
+int lhg_conv2d_thin_forward_nchw(const float* x_nchw, int N, int H, int W, int Ci, const float* w, int Co, int k, float* y, int ldy,
+                                 const float* bias, const float* scale, const float* shift, int act, float slope, float* y_absmax, lhg_stream_t s) {
+  LHG_REQUIRE(lhg_conv2d_thin_supported(Ci, Co, k, 1) == 1, "conv2d_thin_forward_nchw: %d -> %d channels, %dx%d is not a thin-INPUT convolution", Ci, Co, k, k);
+  LHG_REQUIRE(!act_is_bf16(), "conv2d_thin_forward_nchw: thin convolutions take fp32 tensors");
+  LHG_REQUIRE(N > 0 && H > 0 && W > 0 && ldy >= Co, "conv2d_thin_forward_nchw: bad extents");
+  ThinParams p{};
+  p.N = N; p.H = H; p.W = W; p.w = w; p.bias = bias; p.scale = scale; p.shift = shift; p.act = act; p.slope = slope; p.sign = 1;
+  const int T = k * k;
+  p.thin = x_nchw; p.ld_t = Ci; p.thin_planar = 1; p.ct_real = Ci; p.out = y; p.ld_o = ldy; p.cw = Co; p.wide = y; p.ld_w = ldy;
+  p.st = T; p.sw = Ci * T; p.out_amax = y_absmax;
+  return dispatch_thin(K_FANOUT, k, p, as_stream(s));
 }
 
 int lhg_conv2d_thin_backward_input(const float* gy, int N, int H, int W, int Co, int ldg, const float* w, int Ci, int k, float* gx,

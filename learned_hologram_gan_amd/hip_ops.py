@@ -996,6 +996,27 @@ def conv2d_forward_raw(x, w, bias, stride, act=ACT_NONE, slope=0.0, scale=None, 
     return y
 
 
+def conv2d_thin_forward_nchw(X, w, bias, act=ACT_NONE, slope=0.0, scale=None, shift=None, out=None, measure_out=False):
+    """y (NHWC) = act((conv(X, w) + bias) * scale + shift) for a thin-INPUT convolution (<= 8 input channels, 3x3 / 1x1, stride 1) that reads
+    the reference's NCHW tensor X directly (lhg_conv2d_thin_forward_nchw): no NCHW -> NHWC(32) conversion of the network input.  No autograd
+    (eval-mode generator: generatePOH.py:41-70)."""
+    N, Ciw, H, W = X.shape
+    Co, Ciw2, KH, KW = w.shape
+    if Ciw2 != Ciw or KH != KW or thin_mode(Ciw, Co, KH, 1) != 1:
+        raise ValueError(f"conv2d_thin_forward_nchw: {Ciw} -> {Co} channels, {KH}x{KW} is not a thin-input convolution of this tensor")
+    Xc = X.detach()
+    if Xc.dtype != torch.float32 or not Xc.is_contiguous():
+        Xc = Xc.float().contiguous()
+    y = _resolve_out(out, (N, H, W, Co), X.device)
+    py, _, _, _, _, ldy = nhwc(y)
+    y_amax = _out_amax(out, X.device) if measure_out else None
+    call("lhg_conv2d_thin_forward_nchw", ptr(Xc), N, H, W, Ciw, ptr(_raw_weight(w)), Co, KH, py, ldy, ptr(bias), ptr(scale), ptr(shift),
+         act, float(slope), ptr(y_amax), stream_ptr())
+    if y_amax is not None:
+        tag_absmax(y, y_amax)
+    return y
+
+
 def _padded_gy(gy, k_multiple=32):
     """The GEMM K axis must be a multiple of 32 channels: zero-pad narrow gradients (head: 6, critic head: 1)."""
     Cc = gy.shape[-1]

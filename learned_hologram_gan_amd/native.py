@@ -69,6 +69,7 @@ _SIGNATURES = {
     "lhg_conv2d_thin_supported": [_i, _i, _i, _i],
     "lhg_conv2d_thin_forward": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _i, _p, _p, _p, _i, _f, _i, _p],
     "lhg_conv2d_thin_forward_amax": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _i, _p, _p, _p, _i, _f, _i, _p, _p],
+    "lhg_conv2d_thin_forward_nchw": [_p, _i, _i, _i, _i, _p, _i, _i, _p, _i, _p, _p, _p, _i, _f, _p, _p],
     "lhg_conv2d_thin_backward_input": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _p, _i, _p],
     "lhg_conv2d_thin_wgrad_workspace": [_i, _i, _i, _i, _i, _i],
     "lhg_conv2d_thin_backward_weight": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _p, _p, _sz, _p],

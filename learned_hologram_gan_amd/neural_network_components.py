@@ -11,6 +11,7 @@ constructor argument with the value the hot path uses.
 
 from __future__ import annotations
 
+import os
 import warnings
 
 import torch
@@ -44,6 +45,7 @@ def _warn_eval_grad(name):
 
 
 _PENDING_COUNTERS: list = []
+_THIN_NCHW = os.environ.get("LHG_THIN_NCHW", "1") != "0"  # 0: the eval-mode generator converts its NCHW input to NHWC(32) first (A/B measurements)
 
 
 def _count_batch(*bns):
@@ -82,7 +84,9 @@ class ResidualBlock(nn.Module):
         self.batch_norm_layer_2 = nn.BatchNorm2d(num_channels)
 
     # NHWC in (channels padded to 32), NHWC out; `out` optionally names the destination view
-    def forward_nhwc(self, x, out: OutSlot | None = None):
+    def forward_nhwc(self, x, out: OutSlot | None = None, x_nchw=None):
+        """``x_nchw`` (eval mode, thin first block only): the block's input as the reference's NCHW tensor — read directly by the two
+        thin-input convs, ``x`` may then be None (no NCHW -> NHWC conversion of the network input)."""
         c1, c2, c3 = self.convolution_layer_1, self.convolution_layer_2, self.convolution_layer_3
         b1, b2 = self.batch_norm_layer_1, self.batch_norm_layer_2
         if self.training:
@@ -99,6 +103,10 @@ class ResidualBlock(nn.Module):
         with torch.no_grad():
             s1, t1 = _bn_eval_affine(b1)
             s2, t2 = _bn_eval_affine(b2)
+            if x_nchw is not None:  # thin first block: both convs read the NCHW input as it is
+                y = ops.conv2d_thin_forward_nchw(x_nchw, c1.weight, c1.bias, act=ACT_RELU, scale=s1, shift=t1, measure_out=True)
+                skip = ops.conv2d_thin_forward_nchw(x_nchw, c3.weight, c3.bias)
+                return ops.conv2d_forward_raw(y, c2.weight, c2.bias, 1, act=ACT_RELU, scale=s2, shift=t2, res=skip, out=out, measure_out=True)
             y = ops.conv2d_forward_raw(x, c1.weight, c1.bias, self.strides, act=ACT_RELU, scale=s1, shift=t1, measure_out=True)
             skip = ops.conv2d_forward_raw(x, c3.weight, c3.bias, self.strides) if c3 is not None else x
             return ops.conv2d_forward_raw(y, c2.weight, c2.bias, 1, act=ACT_RELU, scale=s2, shift=t2, res=skip, out=out, measure_out=True)
@@ -202,7 +210,12 @@ class UNet(nn.Module):
             raise ValueError(f"UNet expects (B,{self.in_channels},H,W) with H, W multiples of 16, got {tuple(X.shape)}")
         N, _, H, W = X.shape
         dev = X.device
-        x = ops.ToNHWC.apply(X, 32)
+        blk1 = self._block(self.encoder1[0])
+        # eval mode: the first block's two thin-input convs (4 -> 64, 3x3 and the 1x1 shortcut) read the NCHW frame directly
+        direct = (_THIN_NCHW and not self.training and not torch.is_grad_enabled() and X.is_cuda and X.dtype == torch.float32 and blk1.strides == 1
+                  and blk1.convolution_layer_3 is not None and ops.activation_storage() == "fp32"
+                  and ops.thin_mode(self.in_channels, 64, 3, 1) == 1 and ops.thin_mode(self.in_channels, 64, 1, 1) == 1)
+        x = None if direct else ops.ToNHWC.apply(X, 32)
         new = lambda h, w, c: ops.new_nhwc(N, h, w, c, dev)  # noqa: E731  (fp32, or bf16 in the bf16 storage mode)
         buf4, buf3, buf2, buf1 = new(H, W, 128), new(H // 2, W // 2, 256), new(H // 4, W // 4, 512), new(H // 8, W // 8, 1024)
         # one max|.| slot per concatenation buffer: the encoder block and the transposed conv that fill its halves both measure into it
@@ -211,7 +224,7 @@ class UNet(nn.Module):
         # (an encoder output feeds the pool and the skip concatenation: maxpool2x2_with_skip hands back an alias for the skip, and the
         #  pool's backward kernel adds the skip's gradient itself)
         pool_skip = ops.maxpool2x2_with_skip
-        e1 = self._block(self.encoder1[0]).forward_nhwc(x, OutSlot(buf4[..., :64], sh4))
+        e1 = blk1.forward_nhwc(x, OutSlot(buf4[..., :64], sh4), x_nchw=X if direct else None)
         p1, e1 = pool_skip(e1)
         e2 = self._block(self.encoder2[1]).forward_nhwc(p1, OutSlot(buf3[..., :128], sh3))
         p2, e2 = pool_skip(e2)
