@@ -514,6 +514,22 @@ def test_thin_conv_epilogues(ops):
             assert rel_err(got, torch.sigmoid(F.conv2d(x3, w3, b3))) < TOL, (n_, h_, w_, planar)
 
 
+def test_thin_conv_reads_the_nchw_input_directly(ops):
+    """lhg_conv2d_thin_forward_nchw (ABI 10): the thin-input convs of an eval-mode generator's first block on the reference's NCHW frame —
+    the same multiply-adds as the NHWC(32) route (conversion pass, then lhg_conv2d_thin_forward), so the same bits: ragged extents,
+    3x3 and 1x1, 4 and 3 input channels, folded affine + activation, max|y|."""
+    for (N, Ci, Co, H, W, k, act) in ((2, 4, 64, 17, 37, 3, ops.ACT_RELU), (1, 4, 64, 9, 70, 1, ops.ACT_NONE), (2, 3, 32, 16, 23, 3, ops.ACT_LEAKY),
+                                      (1, 4, 64, 40, 520, 3, ops.ACT_RELU)):
+        X = rnd(N, Ci, H, W, seed=11).to(DEV)
+        w = rnd(Co, Ci, k, k, seed=12, scale=0.3).to(DEV)
+        b, sc, sh = rnd(Co, seed=13).to(DEV), (rnd(Co, seed=14) + 1.5).to(DEV), rnd(Co, seed=15).to(DEV)
+        x = ops.ToNHWC.apply(X, 32)
+        want = ops.conv2d_forward_raw(x, w, b, 1, act=act, slope=0.2, scale=sc, shift=sh, measure_out=True)
+        got = ops.conv2d_thin_forward_nchw(X, w, b, act=act, slope=0.2, scale=sc, shift=sh, measure_out=True)
+        assert torch.equal(got, want), (N, Ci, Co, H, W, k)
+        assert float(got.__dict__["_lhg_amax"][1]) == float(want.abs().max()), (N, Ci, Co, H, W, k)
+
+
 def test_thin_conv_double_backward(ops):
     """Gradient-penalty pattern through a thin-input conv and a thin-output conv: d/dw of || d sum(y) / d x ||^2."""
     N, H, W = 2, 10, 12
