@@ -191,6 +191,19 @@ int lhg_conv2d_forward_stats(const float* x, int N, int H, int W, int Ci, int ld
                              const float* x_absmax, float* y_absmax,
                              float* stat_partial, int* stat_rows, lhg_stream_t s);
 
+/* ABI 10: lhg_conv2d_forward (3x3, stride 1, at most 64 output channels, NHWC fp32, LHG_PRECISION_F32_SPLIT_F16) whose residual is not a
+ * tensor but a 1x1 convolution of a thin NCHW tensor, evaluated by the epilogue:
+ *   v = act((acc + bias)*scale + shift + res_b[c] + sum_{k < res_c} res_x_nchw[n][k][h][w] * res_w[c*res_c + k])
+ * — the shortcut `convolution_layer_3(X)` of the generator's first ResidualBlock (neural_network_components.py:22-31: X is the 4-channel
+ * RGBD frame) without ever writing it: 2.1 GB written and read back per 4K frame otherwise.  The multiply-adds run in the order of the
+ * thin-input kernel (bias first, channels ascending), so the stored bits are those of lhg_conv2d_thin_forward + lhg_conv2d_forward(res).
+ * res_c in 1..4; images of at least 512 pixels; act NONE / RELU / LEAKY. */
+int lhg_conv2d_forward_thin_res(const float* x, int N, int H, int W, int Ci, int ldx,
+                                const float* wp, int rows_pad, int KH, int KW, int stride,
+                                float* y, int Co, int ldy, const float* bias, const float* scale, const float* shift,
+                                const float* res_x_nchw, int res_c, const float* res_w, const float* res_b, int act, float slope,
+                                const float* x_absmax, float* y_absmax, lhg_stream_t s);
+
 /* ABI 10, split K.  A gather-GEMM launch (lhg_conv2d_forward[_stats], lhg_conv2d_backward_input*) that cannot fill the chip — at most 160
  * output tiles of 128 x 128 and at least 64 K steps: the UNet's 24^2 x 1024-channel bottleneck (neural_network_components.py:246-250) —
  * cuts its K axis into 2 - 4 ranges of whole 32-channel chunks, a function of the geometry alone (LHG_PRECISION_F32_SPLIT_F16 mode).

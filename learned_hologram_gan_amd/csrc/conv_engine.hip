@@ -69,6 +69,10 @@ struct GGParams {
   int ks, ks_chunks;
   float* ks_slab;
   int ks_off;  // set by launch_gg_classes: one launch of several over the same output (parity classes) never splits
+  // thin residual (gg4s_kernel with BN = 64, lhg_conv2d_forward_thin_res): instead of reading a residual tensor the epilogue evaluates a 1x1
+  // convolution of a thin NCHW tensor, res[pixel][col] = tres_b[col] + sum_{c < tres_c} tres_x[n][c][hw] * tres_w[col * tres_c + c]
+  const float* tres_x; const float* tres_w; const float* tres_b;
+  int tres_c, tres_plane;
   int tap_of[9];        // gg4s_kernel: tap index of the 3x3 offset (dy + 1) * 3 + (dx + 1)
   int strip_rev;        // gg4s_kernel: tap_of is the reversed map (input gradient): walk the offsets downwards = taps upwards
   int prio; // gg3s_kernel: 0 no s_setprio, 1 consumers (MFMA waves) raised, 2 producers (load / split waves) raised
@@ -1226,7 +1230,7 @@ static int launch_gg_split(GGParams& p, hipStream_t st) {
     const size_t ws_floats = g_next_ws_floats;
     g_next_ws = nullptr;
     g_next_ws_floats = 0;
-    if (ncls == 1 && !p.planar_out && !p.ks_off) p.ks = splitk_plan(g.M, p.rows_pad, g.Ci, g.T, &p.ks_chunks);
+    if (ncls == 1 && !p.planar_out && !p.ks_off && !p.tres_x) p.ks = splitk_plan(g.M, p.rows_pad, g.Ci, g.T, &p.ks_chunks);
     if (p.ks > 1) {
       const size_t floats = splitk_floats(p.ks, g.M, strips ? (long long)g.N * g.Hi * (g.Wi + 2) : 0, p.rows_pad);
       p.ks_slab = ws_floats >= floats ? ws : splitk_slab(st, floats);
@@ -1240,6 +1244,7 @@ static int launch_gg_split(GGParams& p, hipStream_t st) {
     // swizzled 128 x 64 tile reaches three workgroups per CU only by spilling 131 registers (4 x slower), the swizzled 64 x 64 tile is
     // level with the padded one.  Offered to the tuner / a forced choice only under LHG_GG_EXPERIMENTAL=1.
     static const bool experimental = [] { const char* e = getenv("LHG_GG_EXPERIMENTAL"); return e && atoi(e) != 0; }();
+    if (p.tres_x) return ncls == 1 && f16 && strips && (v == 5 || v == 7 || v == 11);  // thin residual: the 64-column strip kernels
     if (ncls == 1 && v >= 12 && !experimental) return false;
     if (p.ks > 1 && (v == 12 || v == 13)) return false;  // two taps per barrier need an even number of tap steps in every K range
     if (ncls == 1 && v >= 14) return f16 && strips;
@@ -1308,7 +1313,8 @@ static int launch_gg_split(GGParams& p, hipStream_t st) {
                                      p.planar_out + 4 * g_precision + 64 * ncls};
     choice = autotuned_variant(g_gg_choice, key, NV, valid, run, st);
   }
-  if (choice < 0) choice = n128 && blocks(128, 128) >= 200 ? 0 : (blocks(128, 64) >= 256 ? 1 : 2);
+  if (choice < 0) choice = p.tres_x ? 7 : (n128 && blocks(128, 128) >= 200 ? 0 : (blocks(128, 64) >= 256 ? 1 : 2));
+  if (p.tres_x) LHG_REQUIRE(valid(choice), "gather-GEMM: the thin-residual epilogue needs a 3x3 stride-1 launch with 64 padded output channels in the fp32_split_f16 mode");
   // shape of the chosen tiling: pixels per M tile, consumer-wave rows per tile, padded strip coordinates or not
   int sh_bm = 128, sh_wgm = 2;
   bool sh_strip = false;
@@ -1712,6 +1718,25 @@ int lhg_conv2d_forward(const float* x, int N, int H, int W, int Ci, int ldx, con
   p.a_amax = x_absmax; p.w_amax = weight_amax(wp, KH * KW, rows_pad, Ci); p.out_amax = y_absmax;
   p.in = x; p.wp = wp; p.out = y; p.bias = bias; p.scale = scale; p.shift = shift; p.res = res; p.ldres = ldres;
   p.rows_pad = rows_pad; p.act = act; p.slope = slope; p.planar_out = planar_out;
+  return launch_gg(p, as_stream(s));
+}
+
+int lhg_conv2d_forward_thin_res(const float* x, int N, int H, int W, int Ci, int ldx, const float* wp, int rows_pad, int KH, int KW, int stride,
+                                float* y, int Co, int ldy, const float* bias, const float* scale, const float* shift,
+                                const float* res_x_nchw, int res_c, const float* res_w, const float* res_b, int act, float slope,
+                                const float* x_absmax, float* y_absmax, lhg_stream_t s) {
+  LHG_REQUIRE(KH == 3 && KW == 3 && stride == 1, "conv2d_forward_thin_res: 3x3 stride-1 convolutions only (%dx%d stride %d)", KH, KW, stride);
+  LHG_REQUIRE(g_precision == LHG_PRECISION_F32_SPLIT_F16 && !act_is_bf16(), "conv2d_forward_thin_res: fp32_split_f16 mode, fp32 tensors");
+  LHG_REQUIRE(rows_pad == 64 && Co <= 64, "conv2d_forward_thin_res: at most 64 output channels (Co %d, rows_pad %d)", Co, rows_pad);
+  LHG_REQUIRE(res_x_nchw != nullptr && res_w != nullptr && res_c >= 1 && res_c <= 4, "conv2d_forward_thin_res: the shortcut's input has 1 - 4 channels (%d)", res_c);
+  LHG_REQUIRE((long long)H * W >= 512 && (long long)N * H * W < (1ll << 31), "conv2d_forward_thin_res: images of at least 512 pixels (an output tile spans at most two)");
+  LHG_REQUIRE(act == LHG_ACT_NONE || act == LHG_ACT_RELU || act == LHG_ACT_LEAKY, "conv2d_forward_thin_res: activation %d", act);
+  GGParams p{};
+  conv_fwd_geom(p.g, N, H, W, Ci, ldx, Co, ldy, KH, KW, stride);
+  p.a_amax = x_absmax; p.w_amax = weight_amax(wp, KH * KW, rows_pad, Ci); p.out_amax = y_absmax;
+  p.in = x; p.wp = wp; p.out = y; p.bias = bias; p.scale = scale; p.shift = shift;
+  p.rows_pad = rows_pad; p.act = act; p.slope = slope; p.planar_out = 0;
+  p.tres_x = res_x_nchw; p.tres_w = res_w; p.tres_b = res_b; p.tres_c = res_c; p.tres_plane = H * W;
   return launch_gg(p, as_stream(s));
 }
 

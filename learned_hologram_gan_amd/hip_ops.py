@@ -1017,6 +1017,32 @@ def conv2d_thin_forward_nchw(X, w, bias, act=ACT_NONE, slope=0.0, scale=None, sh
     return y
 
 
+def conv2d_forward_thin_res(x, w, bias, X_nchw, w3, b3, act=ACT_NONE, slope=0.0, scale=None, shift=None, out=None, measure_out=False):
+    """y = act((conv3x3(x, w) + bias) * scale + shift + conv1x1(X_nchw, w3) + b3) with the 1x1 shortcut of a thin NCHW tensor (<= 4
+    channels) evaluated inside the GEMM's epilogue (lhg_conv2d_forward_thin_res) — the tail of an eval-mode first ResidualBlock
+    (ref: neural_network_components.py:22-31) without the shortcut tensor.  Returns None when the launch does not qualify (the caller
+    takes the two-kernel route: same bits)."""
+    px, N, H, W, Ci, ldx = nhwc(x)
+    Co, Ciw, KH, KW = w.shape
+    Xc = X_nchw.detach()
+    if (_mode() != _F16_SPLIT or _ACT_DTYPE != torch.float32 or KH != 3 or KW != 3 or Co > 64 or pad_to(Ciw, 32) != Ci or H * W < 512
+            or Xc.dtype != torch.float32 or not Xc.is_contiguous() or Xc.shape[1] > 4 or tuple(Xc.shape[2:]) != (H, W) or tuple(w3.shape[2:]) != (1, 1)):
+        return None
+    wp = pack_weight(w, True)
+    if wp.shape[1] != 64:
+        return None
+    y = _resolve_out(out, (N, H, W, Co), x.device)
+    py, _, _, _, _, ldy = nhwc(y)
+    native.count_flops(0, 2.0 * N * H * W * Co * (Ciw * 9))
+    x_amax = operand_absmax(x)
+    y_amax = _out_amax(out, x.device) if measure_out else None
+    call("lhg_conv2d_forward_thin_res", px, N, H, W, Ci, ldx, ptr(wp), wp.shape[1], 3, 3, 1, py, Co, ldy, ptr(bias), ptr(scale), ptr(shift),
+         ptr(Xc), int(Xc.shape[1]), ptr(_raw_weight(w3)), ptr(b3), act, float(slope), ptr(x_amax), ptr(y_amax), stream_ptr())
+    if y_amax is not None:
+        tag_absmax(y, y_amax)
+    return y
+
+
 def _padded_gy(gy, k_multiple=32):
     """The GEMM K axis must be a multiple of 32 channels: zero-pad narrow gradients (head: 6, critic head: 1)."""
     Cc = gy.shape[-1]

@@ -56,6 +56,7 @@ _SIGNATURES = {
     "lhg_pack_weights": [_p, _i, _p],
     "lhg_conv2d_forward": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _i, _i, _f, _i, _p, _p, _p],
     "lhg_conv2d_stats_rows_bound": [_i, _i, _i],
+    "lhg_conv2d_forward_thin_res": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, _i, _p, _p, _i, _f, _p, _p, _p],
     "lhg_gather_gemm_splitk_floats": [_ll, _ll, _i, _i, _i],
     "lhg_gather_gemm_workspace": [_p, _ll],
     "lhg_conv2d_forward_stats": [_p, _i, _i, _i, _i, _i, _p, _i, _i, _i, _i, _p, _i, _i, _p, _p, _p, _p, C.POINTER(C.c_int), _p],

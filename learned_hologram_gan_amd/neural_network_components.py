@@ -45,6 +45,7 @@ def _warn_eval_grad(name):
 
 
 _PENDING_COUNTERS: list = []
+_THIN_RES = os.environ.get("LHG_THIN_RES", "1") != "0"  # 0: the first block's 1x1 shortcut as a tensor of its own (A/B measurements)
 _THIN_NCHW = os.environ.get("LHG_THIN_NCHW", "1") != "0"  # 0: the eval-mode generator converts its NCHW input to NHWC(32) first (A/B measurements)
 
 
@@ -105,6 +106,11 @@ class ResidualBlock(nn.Module):
             s2, t2 = _bn_eval_affine(b2)
             if x_nchw is not None:  # thin first block: both convs read the NCHW input as it is
                 y = ops.conv2d_thin_forward_nchw(x_nchw, c1.weight, c1.bias, act=ACT_RELU, scale=s1, shift=t1, measure_out=True)
+                if _THIN_RES:  # the 1x1 shortcut evaluated by the second conv's epilogue: the shortcut tensor is never written (same bits)
+                    z = ops.conv2d_forward_thin_res(y, c2.weight, c2.bias, x_nchw, c3.weight, c3.bias, act=ACT_RELU, scale=s2, shift=t2, out=out,
+                                                    measure_out=True)
+                    if z is not None:
+                        return z
                 skip = ops.conv2d_thin_forward_nchw(x_nchw, c3.weight, c3.bias)
                 return ops.conv2d_forward_raw(y, c2.weight, c2.bias, 1, act=ACT_RELU, scale=s2, shift=t2, res=skip, out=out, measure_out=True)
             y = ops.conv2d_forward_raw(x, c1.weight, c1.bias, self.strides, act=ACT_RELU, scale=s1, shift=t1, measure_out=True)

@@ -530,6 +530,23 @@ def test_thin_conv_reads_the_nchw_input_directly(ops):
         assert float(got.__dict__["_lhg_amax"][1]) == float(want.abs().max()), (N, Ci, Co, H, W, k)
 
 
+def test_thin_residual_epilogue_gives_the_two_kernel_routes_bits(ops):
+    """lhg_conv2d_forward_thin_res (ABI 10): the 3x3 conv of an eval-mode first ResidualBlock with the 1x1 shortcut of the NCHW frame evaluated
+    inside the GEMM's epilogue, against shortcut tensor + lhg_conv2d_forward(res=...): bit-identical output and max|y| — ragged extents (tiles
+    that straddle two images, padding columns of the strip kernels), 4 and 3 frame channels, fewer than 64 output channels."""
+    for (N, Cx, Co, H, W, act) in ((3, 4, 64, 24, 23, ops.ACT_RELU), (2, 3, 64, 40, 36, ops.ACT_NONE), (1, 4, 32, 33, 130, ops.ACT_RELU), (2, 4, 64, 96, 96, ops.ACT_LEAKY)):
+        X = rnd(N, Cx, H, W, seed=21).to(DEV)
+        y1 = to_nhwc(rnd(N, 64, H, W, seed=22))
+        w2 = rnd(Co, 64, 3, 3, seed=23, scale=0.05).to(DEV)
+        b2, sc, sh = rnd(Co, seed=24).to(DEV), (rnd(Co, seed=25) + 1.5).to(DEV), rnd(Co, seed=26).to(DEV)
+        w3, b3 = rnd(Co, Cx, 1, 1, seed=27, scale=0.5).to(DEV), rnd(Co, seed=28).to(DEV)
+        skip = ops.conv2d_thin_forward_nchw(X, w3, b3)
+        want = ops.conv2d_forward_raw(y1, w2, b2, 1, act=act, slope=0.1, scale=sc, shift=sh, res=skip, measure_out=True)
+        got = ops.conv2d_forward_thin_res(y1, w2, b2, X, w3, b3, act=act, slope=0.1, scale=sc, shift=sh, measure_out=True)
+        assert got is not None and torch.equal(got, want), (N, Cx, Co, H, W, (got - want).abs().max().item() if got is not None else None)
+        assert float(got.__dict__["_lhg_amax"][1]) == float(want.abs().max())
+
+
 def test_thin_conv_double_backward(ops):
     """Gradient-penalty pattern through a thin-input conv and a thin-output conv: d/dw of || d sum(y) / d x ||^2."""
     N, H, W = 2, 10, 12
