@@ -457,23 +457,23 @@ __global__ __launch_bounds__(256) void bn_bwd_partial(const T* __restrict__ gy, 
 constexpr int RP_SLICES = 64, RP_CH = 16, RP_UNROLL = 16;
 // NS columns (k_stride apart) of the rows slice, slice + SL, ... summed in double.  Every batch of RP_UNROLL rows is requested before any
 // of it is used, rows past the end clamped and zeroed: ONE memory round trip per RP_UNROLL * SL rows for all NS columns.
-template <int NS, int SL>
+template <int NS, int SL, int UN = RP_UNROLL>
 __device__ __forceinline__ void reduce_rows_n(const float* __restrict__ src, size_t k_stride, size_t stride, int nblk, int slice, double (&out)[NS]) {
   double acc[NS][4];
 #pragma unroll
   for (int k = 0; k < NS; ++k) acc[k][0] = acc[k][1] = acc[k][2] = acc[k][3] = 0.0;
-  for (int b = slice; b < nblk; b += RP_UNROLL * SL) {
-    float v[NS][RP_UNROLL];
+  for (int b = slice; b < nblk; b += UN * SL) {
+    float v[NS][UN];
     // rows past the end: the load is CLAMPED to the last row and its value replaced by zero afterwards — a conditional load is a branch,
     // and the requests would wait for each other (the empty asm keeps the compiler from sinking the load under the select again)
 #pragma unroll
-    for (int u = 0; u < RP_UNROLL; ++u) {
+    for (int u = 0; u < UN; ++u) {
       const size_t r = (size_t)min(b + u * SL, nblk - 1) * stride;
 #pragma unroll
       for (int k = 0; k < NS; ++k) v[k][u] = src[r + k * k_stride];
     }
 #pragma unroll
-    for (int u = 0; u < RP_UNROLL; ++u)
+    for (int u = 0; u < UN; ++u)
 #pragma unroll
       for (int k = 0; k < NS; ++k) {
         asm volatile("" : "+v"(v[k][u]));
@@ -1327,15 +1327,15 @@ int lhg_bn_stats(const float* x, long long pixels, int C, int ld, float* stats, 
 int lhg_bn_stats_finish(const float* partial, int rows, const float* shift, long long pixels, int C, float* stats, float* running_mean,
                         float* running_var, float momentum, float eps, lhg_stream_t s) {
   LHG_REQUIRE(partial != nullptr && rows > 0 && pixels > 0 && C > 0, "bn_stats_finish: empty input (rows %d, pixels %lld, C %d)", rows, pixels, C);
-  if (rows > 4096)
-    hipLaunchKernelGGL((bn_stats_finish_kernel<1, 1024>), dim3(C), dim3(1024), 0, as_stream(s), partial, rows, shift, pixels, C, stats,
-                       running_mean, running_var, momentum, eps);
-  else if (rows > 1024)
-    hipLaunchKernelGGL((bn_stats_finish_kernel<4, 256>), dim3((C + 3) / 4), dim3(1024), 0, as_stream(s), partial, rows, shift, pixels, C, stats,
-                       running_mean, running_var, momentum, eps);
-  else
-    hipLaunchKernelGGL((bn_stats_finish_kernel<16, 64>), dim3((C + 15) / 16), dim3(1024), 0, as_stream(s), partial, rows, shift, pixels, C, stats,
-                       running_mean, running_var, momentum, eps);
+#define LHG_FINISH(CH, SL) hipLaunchKernelGGL((bn_stats_finish_kernel<CH, SL>), dim3((C + CH - 1) / CH), dim3(CH * SL), 0, as_stream(s), partial, rows, shift, \
+                                              pixels, C, stats, running_mean, running_var, momentum, eps)
+  // (tools/time_bn_finish.py: 9216 rows x 64 channels 14.6 us on 8 x 128 against 21.8 on 1 x 1024, 18500 rows 47 against 39; thirty-two rows
+  //  in flight per thread instead of sixteen: twice as slow in every form)
+  if (rows > 12288) LHG_FINISH(1, 1024);
+  else if (rows > 4096) LHG_FINISH(8, 128);
+  else if (rows > 1024) LHG_FINISH(4, 256);
+  else LHG_FINISH(16, 64);
+#undef LHG_FINISH
   return check_launch("bn_stats_finish");
 }
 int lhg_bn_apply(const float* x, int ldx, long long pixels, int C, const float* stats, const float* gamma, const float* beta,
