@@ -1579,6 +1579,7 @@ class BatchNormTrainFn(TrackedFunction):
                 if rows is not None and rows[0] == x._version and ldx == Cc:
                     call("lhg_bn_stats_finish", ptr(rows[1]), rows[2], ptr(rows[3]), pixels, Cc, ptr(stats), ptr(running_mean), ptr(running_var),
                          BN_MOMENTUM, BN_EPS, stream_ptr())
+                    del x.__dict__["_lhg_bn_partial"]  # folded: the rows (up to 19 MB per 384^2 layer) go back to the allocator now, not after backward
                 else:
                     call("lhg_bn_stats", px, pixels, Cc, ldx, ptr(stats), ptr(running_mean), ptr(running_var), BN_MOMENTUM, BN_EPS,
                          ptr(_bn_ws(Cc, x.device, 4104)), stream_ptr())
