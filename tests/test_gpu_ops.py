@@ -1053,7 +1053,7 @@ def test_autotune_choices_persist_in_the_cache_file(tmp_path):
             "torch.manual_seed(0)\n"
             "x = torch.randn(2, 24, 24, 64, device='cuda'); w = torch.randn(64, 64, 3, 3, device='cuda')\n"
             "y = ops.conv2d_forward_raw(x, w, None, 1); torch.cuda.synchronize(); print(float(y.abs().sum()))")
-    env = dict(os.environ, LHG_TUNE_CACHE=str(cache))
+    env = dict(os.environ, LHG_TUNE_CACHE=str(cache), LHG_AUTOTUNE="1")  # (an inherited LHG_AUTOTUNE=0 is honoured by every launcher now)
     a = subprocess.run([sys.executable, "-c", code], cwd=root, env=env, capture_output=True, text=True)
     assert a.returncode == 0, a.stderr[-800:]
     lines = cache.read_text().strip().splitlines()
