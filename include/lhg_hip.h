@@ -209,8 +209,8 @@ int lhg_conv2d_forward_thin_res(const float* x, int N, int H, int W, int Ci, int
  * cuts its K axis into 2 - 4 ranges of whole 32-channel chunks, a function of the geometry alone (LHG_PRECISION_F32_SPLIT_F16 mode).
  * lhg_gather_gemm_splitk_floats: the workspace such a launch needs, 0 when it does not split — M output pixels of the launch
  * (N*Ho*Wo; input-gradient: N*H*W), M_padded = N*H*(W+2) for a 3x3 stride-1 launch (else 0), rows_pad of its packed weight, K = the
- * gathered tensor's (padded) channels, taps = KH*KW.  lhg_gather_gemm_workspace hands a buffer to the NEXT gather-GEMM launch of this
- * thread (consumed by it, used or not).  Without one the library keeps a grow-only buffer per stream, which cannot grow inside a graph
+ * gathered tensor's (padded) channels, taps = KH*KW.  lhg_gather_gemm_workspace hands a buffer to the NEXT gather-GEMM launch
+ * (consumed by it, used or not; process-wide like the library's other switches: one host thread drives the library).  Without one the library keeps a grow-only buffer per stream, which cannot grow inside a graph
  * capture: callers that capture pass their own. */
 long long lhg_gather_gemm_splitk_floats(long long M, long long M_padded, int rows_pad, int K, int taps);
 int lhg_gather_gemm_workspace(float* ws, long long floats);
