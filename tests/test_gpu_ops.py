@@ -1233,6 +1233,47 @@ print("HASH", " ".join(hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest()[:16
 """
 
 
+_BF16_CLASSES_CHILD = r"""
+import hashlib, torch
+from learned_hologram_gan_amd import hip_ops as ops
+torch.manual_seed(5)
+out = []
+for storage in ("fp32", "bf16"):
+    with ops.precision("bf16", storage=storage):
+        dt = torch.bfloat16 if storage == "bf16" else torch.float32
+        w = torch.randn(128, 64, 3, 3, device="cuda") * 0.05
+        gy2 = torch.randn(2, 24, 20, 128, device="cuda").to(dt)
+        x = torch.randn(2, 12, 10, 128, device="cuda").to(dt)
+        wt = torch.randn(128, 64, 2, 2, device="cuda") * 0.1
+        with torch.no_grad():
+            gx2 = ops.Conv2dInputGradFn.apply(gy2, w, 2, 48, 40, 64)                      # stride-2 input gradient: four parity classes
+            up = ops.ConvTranspose2x2Fn.apply(x, wt, torch.randn(64, device="cuda"), None)  # 2x2 transposed conv: four one-tap classes
+        torch.cuda.synchronize()
+        out += [gx2.float(), up.float()]
+print("HASH", " ".join(hashlib.sha256(t.cpu().numpy().tobytes()).hexdigest()[:16] for t in out))
+"""
+
+
+def test_bf16_modes_merge_the_parity_classes_bit_identically():
+    """Round 5: the bf16 operand / storage modes launch the output-parity classes of a stride-2 input gradient and of a 2x2 transposed conv as
+    ONE merged gg3s launch (as the fp16-split mode does); LHG_MERGE_CLASSES=0 launches them one by one — the same bits when both run the
+    same kernel (LHG_GGB_VARIANT=8: gg3s 64 x 64 with 64-k steps; the bf16 kernels do not share one K order — gg2b walks taps outermost,
+    gg3s chunks outermost — so the tuner's free choice per class would differ in rounding)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    seen = {}
+    for merge in ("1", "0"):
+        env = dict(os.environ, LHG_MERGE_CLASSES=merge, LHG_GGB_VARIANT="8", LHG_AUTOTUNE="0", PYTHONPATH=root)
+        out = subprocess.run([sys.executable, "-c", _BF16_CLASSES_CHILD], cwd=root, env=env, capture_output=True, text=True)
+        lines = [ln for ln in out.stdout.splitlines() if ln.startswith("HASH")]
+        assert out.returncode == 0 and lines, out.stdout[-800:] + out.stderr[-1500:]
+        seen[merge] = lines[-1]
+    assert seen["1"] == seen["0"], seen
+
+
 def test_every_tiling_variant_gives_the_same_bits():
     """What the autotuner picks must not show in the results: a 3x3 forward, its input gradient (flipped taps), a stride-2 input
     gradient (merged parity classes, and one launch per class) and a weight gradient are bit-identical across the gather variants —
